@@ -1,0 +1,32 @@
+import glob
+import os
+import sys
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+GOLDEN_DIR = os.path.join(ROOT, "tests", "golden")
+GOLDEN_CASES = sorted(os.path.splitext(os.path.basename(p))[0] for p in glob.glob(os.path.join(GOLDEN_DIR, "*.npz")))
+
+
+def pytest_configure(config):
+    config.addinivalue_line("markers", "gpu: needs a real MI355X (run on the GPU box via gpurun)")
+
+
+def load_golden(name):
+    z = np.load(os.path.join(GOLDEN_DIR, name + ".npz"))
+    g = {k: z[k] for k in z.files}
+    g["n_reads"], g["n_refs"], g["alpha"], g["read_len"] = (int(x) for x in g["params"])
+    g["beta"] = float(g["beta"])
+    return g
+
+
+@pytest.fixture(params=GOLDEN_CASES)
+def golden(request):
+    g = load_golden(request.param)
+    g["name"] = request.param
+    return g
