@@ -1,0 +1,170 @@
+/*
+ * lime_hip.h -- C ABI of liblime_hip.so: the MI355X (gfx950) implementation of LiME's
+ * alpha-cluster detection + read x genome similarity accumulation hot path.
+ *
+ * The reference (veronicaguerrini/LiME) has no library or FFI surface: its boundary is
+ * process + argv + files (src/ClusterLCP.cpp:56-71, src/ClusterBWT_DA.cpp:496-529).  The
+ * entry points below are what a binding of that path would call; each names the reference
+ * code it replaces.  The drop-in executables `ClusterLCP` and `ClusterBWT_DA`
+ * (lime_amd/csrc/cli_*.cpp) are thin argv/file shells over this ABI, and
+ * INTEGRATION.md shows the reference-side stub.
+ *
+ * Conventions: plain C types; no exceptions cross the ABI; every function returns LIME_OK
+ * or a negative code, with text in lime_last_error(); one lime_ctx per device per process;
+ * calls on one ctx are not thread-safe.  All files/arrays are little-endian, headerless:
+ *   lcp  u32[N]  lcp[i] = LCP(suffix i-1, suffix i), lcp[0] = 0
+ *   da   u32[N]  document id; ids < n_reads are reads, the others genomes (id - n_reads)
+ *   ebwt u8[N]   symbol preceding suffix i
+ *   sim  u8[n_reads * n_refs] row-major, sums modulo 256 (Tools.h:68 dataTypeSim = uchar)
+ * There is NO CPU fallback: without a usable HIP device lime_init fails.
+ */
+#ifndef LIME_HIP_H
+#define LIME_HIP_H
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define LIME_OK            0
+#define LIME_ERR_ARG      (-1)  /* bad argument (NULL, misaligned, out-of-range cluster, ...) */
+#define LIME_ERR_HIP      (-2)  /* HIP runtime error / no device                              */
+#define LIME_ERR_NOMEM    (-3)  /* host or device allocation failed                           */
+#define LIME_ERR_MAXLEN   (-4)  /* a cluster is longer than LIME_MAX_CLUSTER (ClusterBWT_DA.cpp:558-562) */
+#define LIME_ERR_HALO     (-5)  /* shard: a run owned by this shard does not close inside its halo       */
+#define LIME_ERR_DOCID    (-6)  /* a da value >= n_reads + n_refs was met while scoring       */
+#define LIME_ERR_IO       (-7)  /* file I/O (CLI helpers)                                     */
+
+#define LIME_MAX_CLUSTER  65536u /* Tools.h:33 sizeMaxBuf */
+#define LIME_TILE         4096u  /* positions per workgroup tile; shard cuts must be multiples */
+
+typedef struct lime_ctx lime_ctx;
+
+/* == ElementCluster, Tools.h:85-88; record of fileFasta.<alpha>.clrs */
+typedef struct { uint64_t pStart, len; } lime_cluster_t;
+
+/* Counters of the last scan on a ctx (device-resident until lime_get_stats syncs). */
+typedef struct {
+    uint64_t n_clusters;   /* ClusterLCP.cpp:136 nClusters                                  */
+    uint64_t max_len;      /* ClusterLCP.cpp:136 maxLen                                     */
+    uint64_t n_updates;    /* table cells incremented (t > 0), ClusterBWT_DA.cpp:178-184    */
+    uint32_t n_cross;      /* clusters that crossed a tile edge (scored by the list kernel)  */
+    uint32_t n_big;        /* clusters longer than the in-tile limit (scored by the big kernel) */
+    uint32_t flags;        /* LIME_FLAG_* */
+    uint32_t reserved;
+} lime_stats_t;
+
+#define LIME_FLAG_MAXLEN 1u
+#define LIME_FLAG_HALO   2u
+#define LIME_FLAG_DOCID  4u
+#define LIME_FLAG_BADCLUSTER 8u
+
+/* ---- lifecycle ------------------------------------------------------------------------ */
+/* device < 0: keep the process's current HIP device.  Replaces the reference's
+ * omp_set_num_threads set-up (ClusterLCP.cpp:73-84). */
+int  lime_init(int device, lime_ctx **out);
+void lime_shutdown(lime_ctx *ctx);
+const char *lime_last_error(void);
+void lime_free(void *p);                 /* frees host buffers returned by this library     */
+const char *lime_version(void);
+int  lime_device_count(void);            /* HIP devices visible to the process (0 if none) */
+
+/* ---- host-pointer API (pageable host arrays; the library stages them through HBM) ------ */
+
+/* ClusterLCP main scan, src/ClusterLCP.cpp:140-283 (StartOrRemain :14-32, Close :34-43).
+ * *clusters: library-owned host buffer (lime_free), ascending pStart = the reference's
+ * 1-thread order; *max_len / *n_clusters as written to the aux .out file (:304-308). */
+int lime_detect(lime_ctx *ctx, const uint32_t *lcp, const uint32_t *da, uint64_t n,
+                uint32_t n_reads, uint32_t alpha,
+                lime_cluster_t **clusters, uint64_t *n_clusters, uint64_t *max_len);
+
+/* clusterAnalyze, src/ClusterBWT_DA.cpp:256-358 (Update_ref_symb :81-105,
+ * Analysis_and_updating :107-190 / :192-252).  ebwt == NULL selects the EBWT=0 build.
+ * sim: caller-owned n_reads*n_refs bytes; it is OVERWRITTEN with the table for these
+ * clusters (the reference starts from zero, :606-611).  Clusters may come in any order. */
+int lime_score(lime_ctx *ctx, const uint32_t *da, const uint8_t *ebwt, uint64_t n,
+               const lime_cluster_t *clusters, uint64_t n_clusters,
+               uint32_t n_reads, uint32_t n_refs, uint8_t *sim);
+
+/* ClusterLCP + clusterAnalyze in one pass over the arrays (no .clrs materialised): the
+ * benchmark path, 9 B/symbol (EBWT=1) or 8 B/symbol (ebwt == NULL). */
+int lime_fused(lime_ctx *ctx, const uint32_t *lcp, const uint32_t *da, const uint8_t *ebwt,
+               uint64_t n, uint32_t n_reads, uint32_t n_refs, uint32_t alpha,
+               uint8_t *sim, uint64_t *n_clusters, uint64_t *max_len);
+
+/* clusterChoose row scan, src/ClusterBWT_DA.cpp:385-402: per read the maximum cell and the
+ * number of non-zero cells.  Normalisation/formatting stays on the host (:404-441). */
+int lime_choose(lime_ctx *ctx, const uint8_t *sim, uint32_t n_reads, uint32_t n_refs,
+                uint8_t *row_max, uint32_t *row_nnz);
+
+/* ---- device-pointer API (arrays already resident in HBM; asynchronous on `stream`) ----- *
+ * `stream` is a hipStream_t passed as void* (NULL = default stream).  Device arrays must be
+ * 16-byte aligned (hipMalloc is) and d_sim must be allocated with lime_sim_bytes() bytes.   */
+
+size_t lime_sim_bytes(uint32_t n_reads, uint32_t n_refs);  /* n_reads*n_refs rounded up to 16 */
+
+/* One shard of a position-range partition (single GPU: n_own = n_avail = n, eof = 1).
+ * The arrays hold positions [0, n_avail) of the shard: the first n_own are owned, the rest
+ * is the read-ahead halo (the reference's straddle loop, ClusterLCP.cpp:246-264).  A cluster
+ * belongs to the shard that owns its first position.  eof != 0: the arrays end at the true
+ * end of the collection, so an open run closes at n_avail (ClusterLCP.cpp:244-245).
+ * zero_sim != 0: clear d_sim first.  Counters: lime_get_stats. */
+int lime_fused_dev(lime_ctx *ctx, const uint32_t *d_lcp, const uint32_t *d_da,
+                   const uint8_t *d_ebwt, uint64_t n_own, uint64_t n_avail, int eof,
+                   uint32_t n_reads, uint32_t n_refs, uint32_t alpha,
+                   uint8_t *d_sim, int zero_sim, void *stream);
+
+/* Detection only.  *d_clusters: library-owned DEVICE buffer valid until the next
+ * lime_detect_dev/lime_shutdown on this ctx; pStart = pos_base + local position.
+ * Synchronises `stream` (the record count sizes the output). */
+int lime_detect_dev(lime_ctx *ctx, const uint32_t *d_lcp, const uint32_t *d_da,
+                    uint64_t n_own, uint64_t n_avail, int eof, uint64_t pos_base,
+                    uint32_t n_reads, uint32_t alpha,
+                    const lime_cluster_t **d_clusters, uint64_t *n_clusters, uint64_t *max_len,
+                    void *stream);
+
+/* Scoring of a device-resident cluster list (pStart local to d_da/d_ebwt). */
+int lime_score_dev(lime_ctx *ctx, const uint32_t *d_da, const uint8_t *d_ebwt, uint64_t n,
+                   const lime_cluster_t *d_clusters, uint64_t n_clusters,
+                   uint32_t n_reads, uint32_t n_refs, uint8_t *d_sim, int zero_sim, void *stream);
+
+int lime_choose_dev(lime_ctx *ctx, const uint8_t *d_sim, uint32_t n_reads, uint32_t n_refs,
+                    uint8_t *d_row_max, uint32_t *d_row_nnz, void *stream);
+
+/* Synthetic inputs of SURVEY.md section 8(d): element i is a pure function of (seed, i0+i).
+ * Any of the three outputs may be NULL.  mode 0 = iid, 1 = block-correlated symbols. */
+int lime_synth_dev(lime_ctx *ctx, uint64_t seed, uint64_t i0, uint64_t count,
+                   uint32_t n_reads, uint32_t n_refs, uint32_t alpha, uint32_t mode,
+                   uint32_t *d_lcp, uint32_t *d_da, uint8_t *d_ebwt, void *stream);
+
+/* Waits for `stream`, returns the counters of the last *_dev scan, and maps flags to an
+ * error code (LIME_ERR_MAXLEN / _HALO / _DOCID) -- stats are filled either way. */
+int lime_get_stats(lime_ctx *ctx, lime_stats_t *out, void *stream);
+
+/* Average device time (ms) of the main scan kernel over the launches since the last call,
+ * measured with HIP events on the launch stream; enabled by lime_set_timing(ctx, 1). */
+int lime_set_timing(lime_ctx *ctx, int on);
+int lime_get_timing(lime_ctx *ctx, double *scan_ms_avg, uint64_t *launches);
+
+/* ---- pure host helpers (no device work; used by the CLIs and by CPU-side tests) -------- */
+uint8_t lime_sym_index(uint8_t byte);                              /* ClusterBWT_DA.cpp:455-470 */
+uint8_t lime_pair_score(const uint8_t cr[16], const uint8_t cg[16]); /* :129-177, host build of the device routine */
+
+/* Writers of the reference's files (byte-identical formats). */
+int lime_write_clrs(const char *path, const lime_cluster_t *clusters, uint64_t n_clusters); /* ClusterLCP.cpp:229-235 */
+int lime_write_aux(const char *path, uint32_t n_reads, uint32_t n_refs, uint32_t alpha,
+                   uint64_t max_len, uint64_t n_clusters);                                  /* ClusterLCP.cpp:294-310 */
+int lime_read_aux(const char *path, uint32_t *n_reads, uint32_t *n_refs, uint32_t *alpha,
+                  uint64_t *max_len, uint64_t *n_clusters);                                 /* ClusterBWT_DA.cpp:531-551 */
+/* clusterChoose output, ClusterBWT_DA.cpp:361-450.  row_max may be NULL (then recomputed). */
+int lime_write_res_txt(const char *path, const uint8_t *sim, const uint8_t *row_max,
+                       uint32_t n_reads, uint32_t n_refs, uint32_t norm, float beta);
+int lime_write_res_bin(const char *path_bin, const char *path_pos, const uint8_t *sim,
+                       const uint8_t *row_max, uint32_t n_reads, uint32_t n_refs,
+                       uint32_t norm, float beta);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* LIME_HIP_H */

@@ -1,0 +1,89 @@
+// Drop-in `ClusterBWT_DA` (reference: src/ClusterBWT_DA.cpp:453-773): same argv, same inputs
+// (<base>.out, fileFasta.<alpha>.clrs, fileFasta.da, fileFasta.ebwt), same outputs
+// (fileFasta.res.bin + .res.pos, or fileFasta.res.txt).  The reference's compile-time
+// switches are runtime here: LIME_EBWT (default 1, Makefile:13) and LIME_BIN (default 1,
+// Makefile:12).  Scoring runs on the MI355X through lime_score / lime_choose.
+#include <chrono>
+#include <iostream>
+#include <sstream>
+#include <vector>
+
+#include "cli_common.h"
+
+static int env_flag(const char *name, int dflt)
+{
+    const char *s = getenv(name);
+    return s ? atoi(s) != 0 : dflt;
+}
+
+int main(int argc, char **argv)
+{
+    if (argc != 5) {
+        std::cerr << "Error usage " << argv[0] << " fileFasta readLen beta threads" << std::endl;
+        exit(1);
+    }
+    const int EBWT = env_flag("LIME_EBWT", 1), BIN = env_flag("LIME_BIN", 1);
+    int threads = 1;
+    sscanf(argv[4], "%d", &threads);
+    printf("Number of threads: %d (host); scoring on GPU\n", threads);
+    std::string fileFasta = argv[1];
+    unsigned char readLen = 0;                 // dataTypeSim, parsed with %hhu (:519-521)
+    float beta = 0;
+    sscanf(argv[2], "%hhu", &readLen);
+    sscanf(argv[3], "%f", &beta);
+
+    uint32_t numRead = 0, numRef = 0, minLCP = 0;
+    uint64_t maxLen = 0, nClusters = 0;
+    const std::string fileaux = aux_name(fileFasta);
+    if (lime_read_aux(fileaux.c_str(), &numRead, &numRef, &minLCP, &maxLen, &nClusters) != LIME_OK) {
+        std::cerr << "Error opening " << fileaux << "." << std::endl; exit(EXIT_FAILURE);
+    }
+    std::cout << "numRead: " << numRead << ", numRef: " << numRef << ", minLCP: " << minLCP
+              << ", nClusters: " << nClusters << std::endl;
+    const uint32_t norm = (uint32_t)(readLen + 1 - minLCP);    // :555
+    if (maxLen > LIME_MAX_CLUSTER) {                            // :558-562
+        std::cerr << "Error Usage: maximum cluster size is " << maxLen
+                  << " greater than sizeMaxBuf, please increase sizeMaxBuf in Tools.h" << std::endl;
+        exit(1);
+    }
+    std::stringstream ss;
+    ss << fileFasta << "." << minLCP << ".clrs";
+    const std::string fnCluster = ss.str(), fnDA = fileFasta + ".da", fnBWT = fileFasta + ".ebwt";
+    MappedFile clrs, da, bwt;
+    if (!clrs.open(fnCluster)) { std::cerr << "Error opening " << fnCluster << "." << std::endl; exit(EXIT_FAILURE); }
+    if (!da.open(fnDA)) { std::cerr << "Error opening " << fnDA << "." << std::endl; exit(EXIT_FAILURE); }
+    if (EBWT && !bwt.open(fnBWT)) { std::cerr << "Error opening " << fnBWT << "." << std::endl; exit(EXIT_FAILURE); }
+    if (clrs.bytes / sizeof(lime_cluster_t) < nClusters) nClusters = clrs.bytes / sizeof(lime_cluster_t);
+    const uint64_t n = da.bytes / 4;
+
+    auto t0 = std::chrono::steady_clock::now();
+    std::cerr << "Computing similarity arrays SimArray_i[1,numRead]..." << std::endl;
+    lime_ctx *ctx = nullptr;
+    if (lime_init(pick_device(), &ctx) != LIME_OK) { std::cerr << "Error: " << lime_last_error() << std::endl; exit(EXIT_FAILURE); }
+    std::vector<uint8_t> sim((size_t)numRead * numRef + 16, 0);
+    int rc = lime_score(ctx, (const uint32_t *)da.data, EBWT ? (const uint8_t *)bwt.data : nullptr, n,
+                        (const lime_cluster_t *)clrs.data, nClusters, numRead, numRef, sim.data());
+    if (rc != LIME_OK) { std::cerr << "Error: " << lime_last_error() << std::endl; exit(1); }
+    fprintf(stderr, "TIME clusterAnalyze: %.6lf\n", std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count());
+
+    auto t1 = std::chrono::steady_clock::now();
+    std::vector<uint8_t> rmax(numRead + 1);
+    std::vector<uint32_t> rnnz(numRead + 1);
+    rc = lime_choose(ctx, sim.data(), numRead, numRef, rmax.data(), rnnz.data());
+    if (rc != LIME_OK) { std::cerr << "Error: " << lime_last_error() << std::endl; exit(1); }
+    const std::string fnF = fileFasta + ".res";
+    if (BIN) {
+        std::cerr << "Writing " << fnF << ".pos" << std::endl << "Writing " << fnF << ".bin" << std::endl;
+        rc = lime_write_res_bin((fnF + ".bin").c_str(), (fnF + ".pos").c_str(), sim.data(), rmax.data(), numRead, numRef, norm, beta);
+    } else {
+        std::cerr << "Writing " << fnF << ".txt" << std::endl;
+        rc = lime_write_res_txt((fnF + ".txt").c_str(), sim.data(), rmax.data(), numRead, numRef, norm, beta);
+    }
+    if (rc != LIME_OK) { std::cerr << "Error opening " << fnF << "." << std::endl; exit(EXIT_FAILURE); }
+    fprintf(stdout, "Time: %.6lf\n", std::chrono::duration<double>(std::chrono::steady_clock::now() - t1).count());
+    lime_shutdown(ctx);
+    std::cout << "Cluster analysis completed with beta=" << beta << "." << std::endl;
+    std::cout << "Number of clusters: " << nClusters << "." << std::endl;
+    fprintf(stdout, "Time: %.6lf\n", std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count());
+    return 0;
+}

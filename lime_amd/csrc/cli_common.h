@@ -1,0 +1,53 @@
+// cli_common.h -- shared by the drop-in executables: read-only file mapping and device choice.
+#pragma once
+#include <fcntl.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <sys/mman.h>
+#include <sys/stat.h>
+#include <unistd.h>
+#include <string>
+
+#include "lime_hip.h"
+
+struct MappedFile {
+    const void *data = nullptr;
+    size_t bytes = 0;
+    int fd = -1;
+    bool open(const std::string &path)
+    {
+        fd = ::open(path.c_str(), O_RDONLY);
+        if (fd < 0) return false;
+        struct stat st;
+        if (fstat(fd, &st) != 0) return false;
+        bytes = (size_t)st.st_size;
+        if (bytes) {
+            void *p = mmap(nullptr, bytes, PROT_READ, MAP_PRIVATE, fd, 0);
+            if (p == MAP_FAILED) return false;
+            data = p;
+        }
+        return true;
+    }
+    ~MappedFile()
+    {
+        if (data) munmap(const_cast<void *>(data), bytes);
+        if (fd >= 0) close(fd);
+    }
+};
+
+// LiME_paired.sh starts four ClusterLCP processes at once (LiME_paired.sh:44-53): spread them
+// over the node's GPUs.  LIME_DEVICE pins a device; otherwise pid modulo device count.
+static inline int pick_device()
+{
+    if (const char *s = getenv("LIME_DEVICE")) return atoi(s);
+    int n = lime_device_count();
+    return n > 1 ? (int)(getpid() % n) : 0;
+}
+
+static inline std::string aux_name(const std::string &fileFasta)
+{
+    // fileFasta.substr(0, fileFasta.find(".fasta")) + ".out"  (ClusterLCP.cpp:294)
+    size_t k = fileFasta.find(".fasta");
+    return (k == std::string::npos ? fileFasta : fileFasta.substr(0, k)) + ".out";
+}

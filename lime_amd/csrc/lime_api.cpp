@@ -1,0 +1,459 @@
+// lime_api.cpp -- implementation of the C ABI in include/lime_hip.h on top of the HIP kernels
+// in lime_kernels.hip.  Host side only: argument checks, scratch management in HBM, kernel
+// sequencing on the caller's stream, staging for the host-pointer entry points.
+// There is no CPU code path for the computation: every entry point needs a HIP device.
+#include <hip/hip_runtime.h>
+#include <stdarg.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+#include <string>
+#include <vector>
+
+#include "lime_device.h"
+#include "lime_hip.h"
+#include "lime_kernels.h"
+
+using namespace lime;
+
+static thread_local std::string g_err;
+
+static int fail(int code, const char *fmt, ...)
+{
+    char buf[512];
+    va_list ap; va_start(ap, fmt); vsnprintf(buf, sizeof buf, fmt, ap); va_end(ap);
+    g_err = buf;
+    return code;
+}
+
+#define HIP_TRY(expr)                                                                         \
+    do {                                                                                      \
+        hipError_t e_ = (expr);                                                               \
+        if (e_ != hipSuccess)                                                                 \
+            return fail(e_ == hipErrorOutOfMemory ? LIME_ERR_NOMEM : LIME_ERR_HIP,            \
+                        "%s: %s", #expr, hipGetErrorString(e_));                              \
+    } while (0)
+
+struct lime_ctx {
+    int device = 0;
+    DevStats *d_stats = nullptr;
+    unsigned long long *d_total = nullptr;
+    // per-tile scratch (capacity in tiles)
+    size_t tile_cap = 0;
+    TileSummary *d_summ = nullptr;
+    uint32_t *d_tile_cnt = nullptr;
+    uint64_t *d_tile_off = nullptr;
+    CrossRec *d_cross = nullptr;
+    // cluster lists
+    lime_cluster_t *d_small = nullptr; uint32_t small_cap = 0;
+    lime_cluster_t *d_big = nullptr; uint32_t big_cap = 0;
+    lime_cluster_t *d_out = nullptr; size_t out_cap = 0;
+    uint32_t *d_big_scratch = nullptr;
+    uint32_t max_blocks = 0xFFFFFFFFu;      // grid cap of the tile kernel (LIME_MAX_BLOCKS)
+    uint32_t list_blocks = 8192;
+    // timing of the scan kernel with HIP events on the launch stream
+    bool timing = false;
+    std::vector<hipEvent_t> ev;             // pairs
+    size_t ev_used = 0;
+};
+
+extern "C" const char *lime_last_error(void) { return g_err.c_str(); }
+extern "C" const char *lime_version(void) { return "lime_amd 0.1 (gfx950)"; }
+extern "C" void lime_free(void *p) { free(p); }
+extern "C" int lime_device_count(void)
+{
+    int n = 0;
+    return hipGetDeviceCount(&n) == hipSuccess ? n : 0;
+}
+extern "C" size_t lime_sim_bytes(uint32_t n_reads, uint32_t n_refs)
+{
+    size_t b = (size_t)n_reads * n_refs;
+    return (b + 15u) & ~(size_t)15u;
+}
+
+extern "C" int lime_init(int device, lime_ctx **out)
+{
+    if (!out) return fail(LIME_ERR_ARG, "lime_init: out is NULL");
+    *out = nullptr;
+    int n = 0;
+    hipError_t e = hipGetDeviceCount(&n);
+    if (e != hipSuccess || n <= 0)
+        return fail(LIME_ERR_HIP, "lime_init: no HIP device (%s); this library has no CPU path",
+                    e == hipSuccess ? "count 0" : hipGetErrorString(e));
+    if (device >= 0) HIP_TRY(hipSetDevice(device));
+    lime_ctx *c = new (std::nothrow) lime_ctx();
+    if (!c) return fail(LIME_ERR_NOMEM, "lime_init: out of host memory");
+    HIP_TRY(hipGetDevice(&c->device));
+    HIP_TRY(hipMalloc(&c->d_stats, sizeof(DevStats)));
+    HIP_TRY(hipMalloc(&c->d_total, sizeof(unsigned long long)));
+    HIP_TRY(hipMemset(c->d_stats, 0, sizeof(DevStats)));
+    if (const char *s = getenv("LIME_MAX_BLOCKS")) { long v = atol(s); if (v > 0) c->max_blocks = (uint32_t)v; }
+    *out = c;
+    return LIME_OK;
+}
+
+extern "C" void lime_shutdown(lime_ctx *c)
+{
+    if (!c) return;
+    (void)hipSetDevice(c->device);
+    (void)hipDeviceSynchronize();
+    for (hipEvent_t e : c->ev) (void)hipEventDestroy(e);
+    (void)hipFree(c->d_stats); (void)hipFree(c->d_total); (void)hipFree(c->d_summ);
+    (void)hipFree(c->d_tile_cnt); (void)hipFree(c->d_tile_off); (void)hipFree(c->d_cross);
+    (void)hipFree(c->d_small); (void)hipFree(c->d_big); (void)hipFree(c->d_out);
+    (void)hipFree(c->d_big_scratch);
+    delete c;
+}
+
+template <typename T> static int regrow(T *&p, size_t count)
+{
+    if (p) { (void)hipFree(p); p = nullptr; }
+    HIP_TRY(hipMalloc(&p, count * sizeof(T)));
+    return LIME_OK;
+}
+
+// scratch sized for an array of n_avail positions; grow-only, so steady-state calls allocate nothing
+static int ensure_scratch(lime_ctx *c, uint64_t n_avail, bool detect, bool score, hipStream_t st)
+{
+    const size_t n_tiles = (size_t)((n_avail + TILE - 1) / TILE);
+    int rc;
+    if (n_tiles > c->tile_cap) {
+        HIP_TRY(hipStreamSynchronize(st));
+        size_t cap = n_tiles + 16;
+        if ((rc = regrow(c->d_summ, cap))) return rc;
+        if ((rc = regrow(c->d_tile_cnt, cap))) return rc;
+        if ((rc = regrow(c->d_tile_off, cap))) return rc;
+        if ((rc = regrow(c->d_cross, cap))) return rc;
+        c->tile_cap = cap;
+    }
+    if (score) {
+        const uint64_t want_small = n_tiles + 16, want_big = n_avail / SMALL_MAX + n_tiles + 16;
+        if (want_big > 0xFFFFFFF0ull) return fail(LIME_ERR_ARG, "array too long for one shard: %llu", (unsigned long long)n_avail);
+        if (want_small > c->small_cap) { HIP_TRY(hipStreamSynchronize(st)); if ((rc = regrow(c->d_small, want_small))) return rc; c->small_cap = (uint32_t)want_small; }
+        if (want_big > c->big_cap) { HIP_TRY(hipStreamSynchronize(st)); if ((rc = regrow(c->d_big, want_big))) return rc; c->big_cap = (uint32_t)want_big; }
+        if (!c->d_big_scratch) {
+            const size_t words = (size_t)BIG_GRID * BIG_SCRATCH_WORDS;
+            HIP_TRY(hipMalloc(&c->d_big_scratch, words * sizeof(uint32_t)));
+            HIP_TRY(hipMemsetAsync(c->d_big_scratch, 0, words * sizeof(uint32_t), st));
+            for (uint32_t b = 0; b < BIG_GRID; ++b)
+                launch_fill_u32(c->d_big_scratch + (size_t)b * BIG_SCRATCH_WORDS, HT_SIZE, HT_EMPTY, st);
+            HIP_TRY(hipGetLastError());
+        }
+    }
+    (void)detect;
+    return LIME_OK;
+}
+
+static int check_ctx(lime_ctx *c, const char *who)
+{
+    if (!c) return fail(LIME_ERR_ARG, "%s: ctx is NULL", who);
+    HIP_TRY(hipSetDevice(c->device));
+    return LIME_OK;
+}
+
+static bool misaligned(const void *p, size_t a) { return ((uintptr_t)p & (a - 1)) != 0; }
+
+static ScanArgs base_args(lime_ctx *c, const uint32_t *lcp, const uint32_t *da, const uint8_t *ebwt,
+                          uint64_t n_own, uint64_t n_avail, int eof, uint32_t n_reads, uint32_t n_refs,
+                          uint32_t alpha, uint8_t *sim)
+{
+    ScanArgs a;
+    memset(&a, 0, sizeof a);
+    a.lcp = lcp; a.da = da; a.ebwt = ebwt;
+    a.n_own = n_own; a.n_avail = n_avail; a.pos_base = 0; a.eof = eof;
+    a.n_reads = n_reads; a.n_refs = n_refs; a.alpha = alpha;
+    a.n_tiles = (uint32_t)((n_avail + TILE - 1) / TILE);
+    a.sim = sim; a.summ = c->d_summ; a.stats = c->d_stats;
+    a.small = c->d_small; a.cross_cap = c->small_cap; a.big = c->d_big; a.big_cap = c->big_cap;
+    a.tile_cnt = c->d_tile_cnt; a.tile_off = c->d_tile_off; a.cross = c->d_cross; a.out = c->d_out;
+    return a;
+}
+
+static int flags_to_rc(uint32_t flags)
+{
+    if (flags & LIME_FLAG_BADCLUSTER) return fail(LIME_ERR_ARG, "a cluster record lies outside the arrays");
+    if (flags & LIME_FLAG_MAXLEN) return fail(LIME_ERR_MAXLEN, "maximum cluster size is greater than %u (sizeMaxBuf)", LIME_MAX_CLUSTER);
+    if (flags & LIME_FLAG_HALO) return fail(LIME_ERR_HALO, "a run owned by this shard does not close inside its halo");
+    if (flags & LIME_FLAG_DOCID) return fail(LIME_ERR_DOCID, "a da value >= n_reads + n_refs was met while scoring");
+    return LIME_OK;
+}
+
+extern "C" int lime_set_timing(lime_ctx *c, int on)
+{
+    int rc = check_ctx(c, "lime_set_timing"); if (rc) return rc;
+    c->timing = on != 0; c->ev_used = 0;
+    return LIME_OK;
+}
+
+static int timing_mark(lime_ctx *c, hipStream_t st)
+{
+    if (!c->timing) return LIME_OK;
+    if (c->ev_used == c->ev.size()) { hipEvent_t e; HIP_TRY(hipEventCreate(&e)); c->ev.push_back(e); }
+    HIP_TRY(hipEventRecord(c->ev[c->ev_used++], st));
+    return LIME_OK;
+}
+
+extern "C" int lime_get_timing(lime_ctx *c, double *scan_ms_avg, uint64_t *launches)
+{
+    int rc = check_ctx(c, "lime_get_timing"); if (rc) return rc;
+    double sum = 0; uint64_t n = 0;
+    for (size_t i = 0; i + 1 < c->ev_used; i += 2) {
+        HIP_TRY(hipEventSynchronize(c->ev[i + 1]));
+        float ms = 0; HIP_TRY(hipEventElapsedTime(&ms, c->ev[i], c->ev[i + 1]));
+        sum += ms; ++n;
+    }
+    c->ev_used = 0;
+    if (scan_ms_avg) *scan_ms_avg = n ? sum / (double)n : 0.0;
+    if (launches) *launches = n;
+    return LIME_OK;
+}
+
+// ---- device-pointer API -----------------------------------------------------------------
+extern "C" int lime_fused_dev(lime_ctx *c, const uint32_t *d_lcp, const uint32_t *d_da, const uint8_t *d_ebwt,
+                              uint64_t n_own, uint64_t n_avail, int eof, uint32_t n_reads, uint32_t n_refs,
+                              uint32_t alpha, uint8_t *d_sim, int zero_sim, void *stream)
+{
+    int rc = check_ctx(c, "lime_fused_dev"); if (rc) return rc;
+    hipStream_t st = (hipStream_t)stream;
+    if (n_own > n_avail) return fail(LIME_ERR_ARG, "lime_fused_dev: n_own > n_avail");
+    if (n_avail && (!d_lcp || !d_da || !d_sim)) return fail(LIME_ERR_ARG, "lime_fused_dev: NULL array");
+    if (misaligned(d_lcp, 16) || misaligned(d_da, 16) || misaligned(d_ebwt, 4) || misaligned(d_sim, 4))
+        return fail(LIME_ERR_ARG, "lime_fused_dev: device arrays must be 16-byte aligned (ebwt/sim: 4)");
+    if (!n_reads || !n_refs) return fail(LIME_ERR_ARG, "lime_fused_dev: n_reads and n_refs must be > 0");
+    if ((rc = ensure_scratch(c, n_avail, false, true, st))) return rc;
+    HIP_TRY(hipMemsetAsync(c->d_stats, 0, sizeof(DevStats), st));
+    if (zero_sim) HIP_TRY(hipMemsetAsync(d_sim, 0, lime_sim_bytes(n_reads, n_refs), st));
+    if (!n_avail) return LIME_OK;
+    ScanArgs a = base_args(c, d_lcp, d_da, d_ebwt, n_own, n_avail, eof, n_reads, n_refs, alpha, d_sim);
+    const int ebwt = d_ebwt != nullptr;
+    if ((rc = timing_mark(c, st))) return rc;
+    launch_tile(ebwt, 0, a, c->max_blocks, st);
+    if ((rc = timing_mark(c, st))) return rc;
+    launch_resolve(0, a, st);
+    launch_score_list(ebwt, a, c->d_small, &c->d_stats->n_cross, 0, c->small_cap, 1024, st);
+    launch_score_big(ebwt, a, c->d_big_scratch, st);
+    HIP_TRY(hipGetLastError());
+    return LIME_OK;
+}
+
+extern "C" int lime_get_stats(lime_ctx *c, lime_stats_t *out, void *stream)
+{
+    int rc = check_ctx(c, "lime_get_stats"); if (rc) return rc;
+    hipStream_t st = (hipStream_t)stream;
+    lime_stats_t s;
+    HIP_TRY(hipMemcpyAsync(&s, c->d_stats, sizeof s, hipMemcpyDeviceToHost, st));
+    HIP_TRY(hipStreamSynchronize(st));
+    if (out) *out = s;
+    if ((c->small_cap && s.n_cross > c->small_cap) || (c->big_cap && s.n_big > c->big_cap))
+        return fail(LIME_ERR_NOMEM, "internal cluster list overflow (cross %u/%u, big %u/%u)", s.n_cross,
+                    c->small_cap, s.n_big, c->big_cap);
+    return flags_to_rc(s.flags);
+}
+
+extern "C" int lime_detect_dev(lime_ctx *c, const uint32_t *d_lcp, const uint32_t *d_da, uint64_t n_own,
+                               uint64_t n_avail, int eof, uint64_t pos_base, uint32_t n_reads, uint32_t alpha,
+                               const lime_cluster_t **d_clusters, uint64_t *n_clusters, uint64_t *max_len,
+                               void *stream)
+{
+    int rc = check_ctx(c, "lime_detect_dev"); if (rc) return rc;
+    hipStream_t st = (hipStream_t)stream;
+    if (!d_clusters || !n_clusters || !max_len) return fail(LIME_ERR_ARG, "lime_detect_dev: NULL output");
+    *d_clusters = nullptr; *n_clusters = 0; *max_len = 0;
+    if (n_own > n_avail) return fail(LIME_ERR_ARG, "lime_detect_dev: n_own > n_avail");
+    if (n_avail && (!d_lcp || !d_da)) return fail(LIME_ERR_ARG, "lime_detect_dev: NULL array");
+    if (misaligned(d_lcp, 16) || misaligned(d_da, 16))
+        return fail(LIME_ERR_ARG, "lime_detect_dev: device arrays must be 16-byte aligned");
+    if (!n_avail) return LIME_OK;
+    if ((rc = ensure_scratch(c, n_avail, true, false, st))) return rc;
+    HIP_TRY(hipMemsetAsync(c->d_stats, 0, sizeof(DevStats), st));
+    ScanArgs a = base_args(c, d_lcp, d_da, nullptr, n_own, n_avail, eof, n_reads, 1, alpha, nullptr);
+    a.pos_base = pos_base;
+    launch_tile(0, 1, a, c->max_blocks, st);
+    launch_resolve(1, a, st);
+    launch_scan_tiles(c->d_tile_cnt, c->d_tile_off, a.n_tiles, c->d_total, st);
+    HIP_TRY(hipGetLastError());
+    unsigned long long total = 0;
+    lime_stats_t s;
+    HIP_TRY(hipMemcpyAsync(&total, c->d_total, sizeof total, hipMemcpyDeviceToHost, st));
+    HIP_TRY(hipMemcpyAsync(&s, c->d_stats, sizeof s, hipMemcpyDeviceToHost, st));
+    HIP_TRY(hipStreamSynchronize(st));
+    if ((rc = flags_to_rc(s.flags & LIME_FLAG_HALO))) return rc;
+    if (total != s.n_clusters) return fail(LIME_ERR_HIP, "internal: record count %llu != counter %llu", total, (unsigned long long)s.n_clusters);
+    if (total > c->out_cap) {
+        size_t cap = (size_t)total + (size_t)total / 8 + 1024;
+        if ((rc = regrow(c->d_out, cap))) return rc;
+        c->out_cap = cap;
+    }
+    if (total) {
+        a.out = c->d_out;
+        launch_tile(0, 2, a, c->max_blocks, st);
+        HIP_TRY(hipGetLastError());
+    }
+    *d_clusters = c->d_out; *n_clusters = total; *max_len = s.max_len;
+    return LIME_OK;
+}
+
+extern "C" int lime_score_dev(lime_ctx *c, const uint32_t *d_da, const uint8_t *d_ebwt, uint64_t n,
+                              const lime_cluster_t *d_clusters, uint64_t n_clusters, uint32_t n_reads,
+                              uint32_t n_refs, uint8_t *d_sim, int zero_sim, void *stream)
+{
+    int rc = check_ctx(c, "lime_score_dev"); if (rc) return rc;
+    hipStream_t st = (hipStream_t)stream;
+    if (!d_sim || (n && !d_da) || (n_clusters && !d_clusters)) return fail(LIME_ERR_ARG, "lime_score_dev: NULL array");
+    if (misaligned(d_sim, 4)) return fail(LIME_ERR_ARG, "lime_score_dev: d_sim must be 4-byte aligned");
+    if (!n_reads || !n_refs) return fail(LIME_ERR_ARG, "lime_score_dev: n_reads and n_refs must be > 0");
+    if ((rc = ensure_scratch(c, n, false, true, st))) return rc;
+    // every listed cluster longer than the in-tile limit lands in the big list
+    if (n_clusters + 16 > c->big_cap) {
+        if (n_clusters + 16 > 0xFFFFFFF0ull) return fail(LIME_ERR_ARG, "too many clusters for one call");
+        HIP_TRY(hipStreamSynchronize(st));
+        if ((rc = regrow(c->d_big, (size_t)n_clusters + 16))) return rc;
+        c->big_cap = (uint32_t)(n_clusters + 16);
+    }
+    HIP_TRY(hipMemsetAsync(c->d_stats, 0, sizeof(DevStats), st));
+    if (zero_sim) HIP_TRY(hipMemsetAsync(d_sim, 0, lime_sim_bytes(n_reads, n_refs), st));
+    if (!n_clusters) return LIME_OK;
+    ScanArgs a = base_args(c, nullptr, d_da, d_ebwt, n, n, 1, n_reads, n_refs, 0, d_sim);
+    const int ebwt = d_ebwt != nullptr;
+    uint64_t batches = (n_clusters + LIST_BATCH - 1) / LIST_BATCH;
+    uint32_t blocks = (uint32_t)(batches < c->list_blocks ? batches : c->list_blocks);
+    launch_score_list(ebwt, a, d_clusters, nullptr, n_clusters, 0, blocks, st);
+    launch_score_big(ebwt, a, c->d_big_scratch, st);
+    HIP_TRY(hipGetLastError());
+    return LIME_OK;
+}
+
+extern "C" int lime_choose_dev(lime_ctx *c, const uint8_t *d_sim, uint32_t n_reads, uint32_t n_refs,
+                               uint8_t *d_row_max, uint32_t *d_row_nnz, void *stream)
+{
+    int rc = check_ctx(c, "lime_choose_dev"); if (rc) return rc;
+    if (!d_sim || !d_row_max || !d_row_nnz) return fail(LIME_ERR_ARG, "lime_choose_dev: NULL array");
+    if (misaligned(d_sim, 4)) return fail(LIME_ERR_ARG, "lime_choose_dev: d_sim must be 4-byte aligned");
+    if (!n_reads) return LIME_OK;
+    launch_choose(d_sim, n_reads, n_refs, d_row_max, d_row_nnz, (hipStream_t)stream);
+    HIP_TRY(hipGetLastError());
+    return LIME_OK;
+}
+
+extern "C" int lime_synth_dev(lime_ctx *c, uint64_t seed, uint64_t i0, uint64_t count, uint32_t n_reads,
+                              uint32_t n_refs, uint32_t alpha, uint32_t mode, uint32_t *d_lcp, uint32_t *d_da,
+                              uint8_t *d_ebwt, void *stream)
+{
+    int rc = check_ctx(c, "lime_synth_dev"); if (rc) return rc;
+    if (!n_reads || !n_refs) return fail(LIME_ERR_ARG, "lime_synth_dev: n_reads and n_refs must be > 0");
+    if (!count) return LIME_OK;
+    launch_synth(seed, i0, count, n_reads, n_refs, alpha, mode, d_lcp, d_da, d_ebwt, (hipStream_t)stream);
+    HIP_TRY(hipGetLastError());
+    return LIME_OK;
+}
+
+// ---- host-pointer API: stage through HBM, run the device path, copy back ------------------
+namespace {
+struct DevBuf {
+    void *p = nullptr;
+    ~DevBuf() { if (p) (void)hipFree(p); }
+    int alloc(size_t bytes) { HIP_TRY(hipMalloc(&p, bytes ? bytes : 16)); return LIME_OK; }
+    int upload(const void *src, size_t bytes) {
+        int rc = alloc(bytes + 16); if (rc) return rc;
+        if (bytes) HIP_TRY(hipMemcpy(p, src, bytes, hipMemcpyHostToDevice));
+        return LIME_OK;
+    }
+};
+}
+
+extern "C" int lime_detect(lime_ctx *c, const uint32_t *lcp, const uint32_t *da, uint64_t n, uint32_t n_reads,
+                           uint32_t alpha, lime_cluster_t **clusters, uint64_t *n_clusters, uint64_t *max_len)
+{
+    int rc = check_ctx(c, "lime_detect"); if (rc) return rc;
+    if (!clusters || !n_clusters || !max_len) return fail(LIME_ERR_ARG, "lime_detect: NULL output");
+    *clusters = nullptr; *n_clusters = 0; *max_len = 0;
+    if (n && (!lcp || !da)) return fail(LIME_ERR_ARG, "lime_detect: NULL array");
+    if (!n) return LIME_OK;
+    DevBuf dl, dd;
+    if ((rc = dl.upload(lcp, n * 4))) return rc;
+    if ((rc = dd.upload(da, n * 4))) return rc;
+    const lime_cluster_t *dc = nullptr;
+    rc = lime_detect_dev(c, (const uint32_t *)dl.p, (const uint32_t *)dd.p, n, n, 1, 0, n_reads, alpha, &dc,
+                         n_clusters, max_len, nullptr);
+    if (rc) return rc;
+    if (*n_clusters) {
+        lime_cluster_t *h = (lime_cluster_t *)malloc((size_t)*n_clusters * sizeof(lime_cluster_t));
+        if (!h) return fail(LIME_ERR_NOMEM, "lime_detect: out of host memory");
+        hipError_t e = hipMemcpy(h, dc, (size_t)*n_clusters * sizeof(lime_cluster_t), hipMemcpyDeviceToHost);
+        if (e != hipSuccess) { free(h); return fail(LIME_ERR_HIP, "hipMemcpy: %s", hipGetErrorString(e)); }
+        *clusters = h;
+    } else {
+        HIP_TRY(hipDeviceSynchronize());
+    }
+    return LIME_OK;
+}
+
+extern "C" int lime_score(lime_ctx *c, const uint32_t *da, const uint8_t *ebwt, uint64_t n,
+                          const lime_cluster_t *clusters, uint64_t n_clusters, uint32_t n_reads,
+                          uint32_t n_refs, uint8_t *sim)
+{
+    int rc = check_ctx(c, "lime_score"); if (rc) return rc;
+    if (!sim || (n && !da) || (n_clusters && !clusters)) return fail(LIME_ERR_ARG, "lime_score: NULL array");
+    DevBuf dd, de, dc, ds;
+    if ((rc = dd.upload(da, n * 4))) return rc;
+    if (ebwt && (rc = de.upload(ebwt, n))) return rc;
+    if ((rc = dc.upload(clusters, n_clusters * sizeof(lime_cluster_t)))) return rc;
+    if ((rc = ds.alloc(lime_sim_bytes(n_reads, n_refs)))) return rc;
+    rc = lime_score_dev(c, (const uint32_t *)dd.p, ebwt ? (const uint8_t *)de.p : nullptr, n,
+                        (const lime_cluster_t *)dc.p, n_clusters, n_reads, n_refs, (uint8_t *)ds.p, 1, nullptr);
+    if (rc) return rc;
+    lime_stats_t s;
+    if ((rc = lime_get_stats(c, &s, nullptr))) return rc;
+    HIP_TRY(hipMemcpy(sim, ds.p, (size_t)n_reads * n_refs, hipMemcpyDeviceToHost));
+    return LIME_OK;
+}
+
+extern "C" int lime_fused(lime_ctx *c, const uint32_t *lcp, const uint32_t *da, const uint8_t *ebwt, uint64_t n,
+                          uint32_t n_reads, uint32_t n_refs, uint32_t alpha, uint8_t *sim, uint64_t *n_clusters,
+                          uint64_t *max_len)
+{
+    int rc = check_ctx(c, "lime_fused"); if (rc) return rc;
+    if (!sim || (n && (!lcp || !da))) return fail(LIME_ERR_ARG, "lime_fused: NULL array");
+    DevBuf dl, dd, de, ds;
+    if ((rc = dl.upload(lcp, n * 4))) return rc;
+    if ((rc = dd.upload(da, n * 4))) return rc;
+    if (ebwt && (rc = de.upload(ebwt, n))) return rc;
+    if ((rc = ds.alloc(lime_sim_bytes(n_reads, n_refs)))) return rc;
+    rc = lime_fused_dev(c, (const uint32_t *)dl.p, (const uint32_t *)dd.p, ebwt ? (const uint8_t *)de.p : nullptr,
+                        n, n, 1, n_reads, n_refs, alpha, (uint8_t *)ds.p, 1, nullptr);
+    if (rc) return rc;
+    lime_stats_t s;
+    rc = lime_get_stats(c, &s, nullptr);
+    if (n_clusters) *n_clusters = s.n_clusters;
+    if (max_len) *max_len = s.max_len;
+    if (rc) return rc;
+    HIP_TRY(hipMemcpy(sim, ds.p, (size_t)n_reads * n_refs, hipMemcpyDeviceToHost));
+    return LIME_OK;
+}
+
+extern "C" int lime_choose(lime_ctx *c, const uint8_t *sim, uint32_t n_reads, uint32_t n_refs, uint8_t *row_max,
+                           uint32_t *row_nnz)
+{
+    int rc = check_ctx(c, "lime_choose"); if (rc) return rc;
+    if (!sim || !row_max || !row_nnz) return fail(LIME_ERR_ARG, "lime_choose: NULL array");
+    if (!n_reads) return LIME_OK;
+    DevBuf ds, dm, dz;
+    if ((rc = ds.alloc(lime_sim_bytes(n_reads, n_refs)))) return rc;
+    HIP_TRY(hipMemcpy(ds.p, sim, (size_t)n_reads * n_refs, hipMemcpyHostToDevice));
+    if ((rc = dm.alloc(n_reads))) return rc;
+    if ((rc = dz.alloc((size_t)n_reads * 4))) return rc;
+    if ((rc = lime_choose_dev(c, (const uint8_t *)ds.p, n_reads, n_refs, (uint8_t *)dm.p, (uint32_t *)dz.p, nullptr))) return rc;
+    HIP_TRY(hipMemcpy(row_max, dm.p, n_reads, hipMemcpyDeviceToHost));
+    HIP_TRY(hipMemcpy(row_nnz, dz.p, (size_t)n_reads * 4, hipMemcpyDeviceToHost));
+    return LIME_OK;
+}
+
+// ---- pure host helpers ------------------------------------------------------------------
+extern "C" uint8_t lime_sym_index(uint8_t b) { return (uint8_t)sym_index(b); }
+
+extern "C" uint8_t lime_pair_score(const uint8_t cr[16], const uint8_t cg[16])
+{
+    uint32_t r[4] = {0, 0, 0, 0}, g[4] = {0, 0, 0, 0};
+    for (int i = 0; i < 16; ++i) { r[i >> 2] |= (uint32_t)cr[i] << ((i & 3) * 8); g[i >> 2] |= (uint32_t)cg[i] << ((i & 3) * 8); }
+    return (uint8_t)pair_score(r, g);
+}

@@ -1,0 +1,56 @@
+// lime_kernels.h -- declarations shared by the kernels (lime_kernels.hip) and the C-ABI
+// implementation (lime_api.cpp).  Not part of the public ABI (include/lime_hip.h is).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include "lime_hip.h"
+
+namespace lime {
+
+constexpr int TILE = LIME_TILE;              // positions per workgroup tile
+constexpr int WGSZ = 256;                    // 4 waves of 64
+constexpr int NWORDS = TILE / 64;            // 64-bit mask words per tile
+constexpr uint32_t SMALL_MAX = 64;           // longest cluster scored inside a tile
+constexpr uint32_t NONE32 = 0xFFFFFFFFu;
+constexpr uint32_t LIST_BATCH = 64;          // clusters gathered per workgroup pass in k_score_list
+constexpr uint32_t HT_BITS = 17;             // >= 2 x LIME_MAX_CLUSTER slots: the table never fills
+constexpr uint32_t HT_SIZE = 1u << HT_BITS;
+constexpr uint32_t HT_EMPTY = 0xFFFFFFFFu;
+constexpr uint32_t BIG_GRID = 32;            // workgroups of k_score_big (each owns a scratch table)
+constexpr size_t BIG_SCRATCH_WORDS = (size_t)HT_SIZE + (size_t)HT_SIZE * 16u + 2u * LIME_MAX_CLUSTER;
+
+struct TileSummary { uint32_t first_head, last_head, pre, suf; };   // offsets in tile; flags bit0 read, bit1 genome
+struct CrossRec { uint64_t start, len; };                          // len == 0: none
+
+struct DevStats {                            // same layout as lime_stats_t
+    unsigned long long n_clusters, max_len, n_updates;
+    uint32_t n_cross, n_big, flags, reserved;
+};
+static_assert(sizeof(DevStats) == sizeof(lime_stats_t), "DevStats must mirror lime_stats_t");
+
+struct ScanArgs {
+    const uint32_t *lcp; const uint32_t *da; const uint8_t *ebwt;
+    uint64_t n_own, n_avail, pos_base;
+    int eof;
+    uint32_t n_reads, n_refs, alpha, n_tiles;
+    uint8_t *sim;
+    TileSummary *summ;
+    DevStats *stats;
+    lime_cluster_t *small; uint32_t cross_cap;   // tile-crossing clusters <= SMALL_MAX
+    lime_cluster_t *big; uint32_t big_cap;       // clusters > SMALL_MAX
+    uint32_t *tile_cnt; uint64_t *tile_off; CrossRec *cross; lime_cluster_t *out;   // detect only
+};
+
+void launch_tile(int ebwt, int mode, const ScanArgs &a, uint32_t max_blocks, hipStream_t st);
+void launch_resolve(int mode, const ScanArgs &a, hipStream_t st);
+void launch_scan_tiles(const uint32_t *cnt, uint64_t *off, uint32_t n, unsigned long long *total, hipStream_t st);
+void launch_score_list(int ebwt, const ScanArgs &a, const lime_cluster_t *list, const uint32_t *count_ptr,
+                       uint64_t count, uint32_t cap, uint32_t blocks, hipStream_t st);
+void launch_score_big(int ebwt, const ScanArgs &a, uint32_t *scratch, hipStream_t st);
+void launch_choose(const uint8_t *sim, uint32_t n_reads, uint32_t n_refs, uint8_t *row_max,
+                   uint32_t *row_nnz, hipStream_t st);
+void launch_synth(uint64_t seed, uint64_t i0, uint64_t count, uint32_t n_reads, uint32_t n_refs,
+                  uint32_t alpha, uint32_t mode, uint32_t *lcp, uint32_t *da, uint8_t *ebwt, hipStream_t st);
+void launch_fill_u32(uint32_t *p, size_t n, uint32_t v, hipStream_t st);
+
+} // namespace lime

@@ -1,0 +1,114 @@
+"""CPU-side checks of the product library: it loads, exports every symbol the header
+declares, fails loudly without a GPU, and its pure host helpers (same source as the device
+routines, lime_amd/csrc/lime_device.h) agree with the oracle.  No GPU compute here."""
+import ctypes as C
+import os
+import re
+
+import numpy as np
+import pytest
+
+from lime_amd import _lib
+from oracle import oracle_py as O
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def header_functions():
+    src = open(os.path.join(ROOT, "include", "lime_hip.h")).read()
+    src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
+    return sorted(set(re.findall(r"\b(lime_[a-z_0-9]+)\s*\(", src)))
+
+
+def test_library_exports_every_declared_symbol():
+    lib = _lib.load()
+    names = header_functions()
+    assert len(names) >= 25
+    for n in names:
+        assert hasattr(lib, n), f"{n} declared in include/lime_hip.h but not exported"
+    assert set(names) == set(_lib.SYMBOLS), set(names) ^ set(_lib.SYMBOLS)
+
+
+def test_no_cpu_fallback_without_gpu():
+    lib = _lib.load()
+    if lib.lime_device_count() > 0:
+        pytest.skip("a GPU is present")
+    h = C.c_void_p()
+    rc = lib.lime_init(-1, C.byref(h))
+    assert rc == _lib.ERR_HIP and not h
+    assert b"no CPU path" in lib.lime_last_error()
+    import lime_amd
+    with pytest.raises(lime_amd.LimeError):
+        lime_amd.Context()
+
+
+def test_sym_index_matches_oracle():
+    lib = _lib.load()
+    for b in range(256):
+        assert lib.lime_sym_index(b) == O.sym_index(b), b
+
+
+def test_pair_score_matches_oracle():
+    lib = _lib.load()
+    rng = np.random.default_rng(5)
+    n_bad = 0
+    for k in range(20000):
+        kind = k % 4
+        if kind == 0:      # plain bases only
+            cr = np.zeros(16, np.uint8); cg = np.zeros(16, np.uint8)
+            cr[:4] = rng.integers(0, 6, 4); cg[:4] = rng.integers(0, 6, 4)
+        elif kind == 1:    # sparse IUPAC
+            cr = (rng.integers(0, 4, 16) * (rng.random(16) < 0.3)).astype(np.uint8)
+            cg = (rng.integers(0, 4, 16) * (rng.random(16) < 0.3)).astype(np.uint8)
+        elif kind == 2:    # dense, small counts
+            cr = rng.integers(0, 5, 16).astype(np.uint8); cg = rng.integers(0, 5, 16).astype(np.uint8)
+        else:              # full byte range: wrap of t
+            cr = rng.integers(0, 256, 16).astype(np.uint8); cg = rng.integers(0, 256, 16).astype(np.uint8)
+        a = lib.lime_pair_score(cr.ctypes.data, cg.ctypes.data)
+        b = O.pair_score(cr, cg)
+        n_bad += a != b
+    assert n_bad == 0
+
+
+def test_single_symbol_pairs_match_oracle():
+    """one-hot histograms: the value the in-tile fast path takes from iupac_match()."""
+    lib = _lib.load()
+    for a in range(16):
+        for b in range(16):
+            cr = np.zeros(16, np.uint8); cg = np.zeros(16, np.uint8)
+            cr[a] = 1; cg[b] = 1
+            exp = O.pair_score(cr, cg)
+            assert lib.lime_pair_score(cr.ctypes.data, cg.ctypes.data) == exp
+            assert exp in (0, 1)
+
+
+@pytest.mark.parametrize("ebwt_mode", [1, 0])
+def test_file_writers_match_reference_bytes(golden, ebwt_mode, tmp_path):
+    lib = _lib.load()
+    sim = np.ascontiguousarray(golden[f"sim_e{ebwt_mode}"])
+    nr, ng = sim.shape
+    norm = (golden["read_len"] + 1 - golden["alpha"]) & 0xFFFFFFFF
+    beta = float(np.float32(golden["beta"]))
+    t = str(tmp_path / "x.txt").encode()
+    assert lib.lime_write_res_txt(t, sim.ctypes.data, None, nr, ng, norm, beta) == 0
+    assert open(t, "rb").read() == golden[f"txt_e{ebwt_mode}"].tobytes()
+    b, p = str(tmp_path / "x.bin").encode(), str(tmp_path / "x.pos").encode()
+    mx = sim.max(axis=1).astype(np.uint8) if ng else np.zeros(nr, np.uint8)
+    assert lib.lime_write_res_bin(b, p, sim.ctypes.data, mx.ctypes.data, nr, ng, norm, beta) == 0
+    assert open(b, "rb").read() == golden[f"bin_e{ebwt_mode}"].tobytes()
+    assert open(p, "rb").read() == golden[f"pos_e{ebwt_mode}"].tobytes()
+
+
+def test_clrs_and_aux_writers(golden, tmp_path):
+    lib = _lib.load()
+    cl = np.ascontiguousarray(golden["clrs"])
+    f = str(tmp_path / "c.clrs").encode()
+    assert lib.lime_write_clrs(f, cl.ctypes.data if len(cl) else None, len(cl)) == 0
+    assert open(f, "rb").read() == cl.tobytes()
+    a = str(tmp_path / "c.out").encode()
+    ml = int(cl[:, 1].max()) if len(cl) else 0
+    assert lib.lime_write_aux(a, golden["n_reads"], golden["n_refs"], golden["alpha"], ml, len(cl)) == 0
+    assert open(a, "rb").read() == golden["out"].tobytes()
+    nr, ng, al, m, n = C.c_uint32(), C.c_uint32(), C.c_uint32(), C.c_uint64(), C.c_uint64()
+    assert lib.lime_read_aux(a, C.byref(nr), C.byref(ng), C.byref(al), C.byref(m), C.byref(n)) == 0
+    assert (nr.value, ng.value, al.value, m.value, n.value) == (golden["n_reads"], golden["n_refs"], golden["alpha"], ml, len(cl))

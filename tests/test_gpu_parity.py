@@ -1,0 +1,258 @@
+"""Parity of the HIP path (through the C ABI) with the oracle and the reference's golden
+vectors.  Integer/byte work: every comparison is bit-exact."""
+import os
+import subprocess
+
+import numpy as np
+import pytest
+
+from oracle import oracle_py as O
+
+pytestmark = pytest.mark.gpu
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+BIN = os.path.join(ROOT, "lime_amd", "bin")
+
+
+@pytest.fixture(scope="module")
+def ctx():
+    import lime_amd
+    c = lime_amd.Context()
+    yield c
+    c.close()
+
+
+# ---- golden vectors of the reference -----------------------------------------------------
+def test_detect_golden(ctx, golden):
+    cl, nc, ml = ctx.detect(golden["lcp"], golden["da"], golden["n_reads"], golden["alpha"])
+    assert nc == len(golden["clrs"])
+    assert np.array_equal(cl, golden["clrs"])
+    assert O.out_bytes(golden["n_reads"], golden["n_refs"], golden["alpha"], ml, nc) == golden["out"].tobytes()
+
+
+@pytest.mark.parametrize("ebwt_mode", [1, 0])
+def test_score_golden(ctx, golden, ebwt_mode):
+    eb = golden["ebwt"] if ebwt_mode else None
+    sim = ctx.score(golden["da"], eb, golden["clrs"], golden["n_reads"], golden["n_refs"])
+    assert np.array_equal(sim, golden[f"sim_e{ebwt_mode}"])
+
+
+@pytest.mark.parametrize("ebwt_mode", [1, 0])
+def test_fused_golden(ctx, golden, ebwt_mode):
+    eb = golden["ebwt"] if ebwt_mode else None
+    sim, nc, ml = ctx.fused(golden["lcp"], golden["da"], eb, golden["n_reads"], golden["n_refs"], golden["alpha"])
+    assert nc == len(golden["clrs"])
+    assert ml == (int(golden["clrs"][:, 1].max()) if nc else 0)
+    assert np.array_equal(sim, golden[f"sim_e{ebwt_mode}"])
+
+
+def test_score_accepts_any_cluster_order(ctx, golden):
+    rng = np.random.default_rng(3)
+    cl = golden["clrs"][rng.permutation(len(golden["clrs"]))]
+    sim = ctx.score(golden["da"], golden["ebwt"], cl, golden["n_reads"], golden["n_refs"])
+    assert np.array_equal(sim, golden["sim_e1"])
+
+
+def test_choose_golden(ctx, golden):
+    sim = golden["sim_e1"]
+    mx, nz = ctx.choose(sim)
+    emx, enz = O.choose(sim)
+    assert np.array_equal(mx, emx) and np.array_equal(nz, enz)
+
+
+# ---- the drop-in executables write the reference's bytes -----------------------------------
+@pytest.mark.parametrize("ebwt_mode,binary", [(1, 1), (1, 0), (0, 1), (0, 0)])
+def test_cli_dropin_files(golden, ebwt_mode, binary, tmp_path):
+    g = golden
+    base = str(tmp_path / "X.fasta")
+    g["lcp"].astype("<u4").tofile(base + ".lcp")
+    g["da"].astype("<u4").tofile(base + ".da")
+    g["ebwt"].tofile(base + ".ebwt")
+    env = dict(os.environ, LIME_EBWT=str(ebwt_mode), LIME_BIN=str(binary))
+    r = subprocess.run([f"{BIN}/ClusterLCP", base, str(g["n_reads"]), str(g["n_refs"]), str(g["alpha"]), "4"],
+                       capture_output=True, timeout=300, env=env, cwd=tmp_path)
+    assert r.returncode == 0, r.stderr.decode()
+    assert open(f"{base}.{g['alpha']}.clrs", "rb").read() == g["clrs"].tobytes()
+    assert open(str(tmp_path / "X.out"), "rb").read() == g["out"].tobytes()
+    r = subprocess.run([f"{BIN}/ClusterBWT_DA", base, str(g["read_len"]), repr(g["beta"]), "4"],
+                       capture_output=True, timeout=300, env=env, cwd=tmp_path)
+    assert r.returncode == 0, r.stderr.decode()
+    tag = f"e{ebwt_mode}"
+    if binary:
+        assert open(base + ".res.bin", "rb").read() == g[f"bin_{tag}"].tobytes()
+        assert open(base + ".res.pos", "rb").read() == g[f"pos_{tag}"].tobytes()
+    else:
+        assert open(base + ".res.txt", "rb").read() == g[f"txt_{tag}"].tobytes()
+
+
+def test_cli_usage_errors(tmp_path):
+    r = subprocess.run([f"{BIN}/ClusterLCP", "x"], capture_output=True, timeout=60)
+    assert r.returncode == 1 and b"Error usage" in r.stderr
+    r = subprocess.run([f"{BIN}/ClusterBWT_DA", "x"], capture_output=True, timeout=60)
+    assert r.returncode == 1 and b"Error usage" in r.stderr
+    r = subprocess.run([f"{BIN}/ClusterLCP", str(tmp_path / "nofile.fasta"), "1", "1", "16", "1"],
+                       capture_output=True, timeout=60)
+    assert r.returncode != 0 and b"Error opening" in r.stderr
+
+
+# ---- python mirror of the two programs ------------------------------------------------------
+def test_python_program_mirror(ctx, golden, tmp_path):
+    import lime_amd
+    g = golden
+    base = str(tmp_path / "Y.fasta")
+    g["lcp"].astype("<u4").tofile(base + ".lcp")
+    g["da"].astype("<u4").tofile(base + ".da")
+    g["ebwt"].tofile(base + ".ebwt")
+    lime_amd.cluster_lcp(base, g["n_reads"], g["n_refs"], g["alpha"], ctx=ctx)
+    assert open(f"{base}.{g['alpha']}.clrs", "rb").read() == g["clrs"].tobytes()
+    lime_amd.cluster_bwt_da(base, g["read_len"], g["beta"], ebwt=True, binary=False, ctx=ctx)
+    assert open(base + ".res.txt", "rb").read() == g["txt_e1"].tobytes()
+    lime_amd.cluster_bwt_da(base, g["read_len"], g["beta"], ebwt=False, binary=True, ctx=ctx)
+    assert open(base + ".res.bin", "rb").read() == g["bin_e0"].tobytes()
+    assert open(base + ".res.pos", "rb").read() == g["pos_e0"].tobytes()
+
+
+# ---- seeded synthetic inputs against the oracle ---------------------------------------------
+@pytest.mark.parametrize("n,nr,ng,mode", [
+    (1, 3, 2, 0), (2, 3, 2, 0), (63, 3, 2, 0), (4095, 5, 4, 0), (4096, 5, 4, 1), (4097, 5, 4, 0),
+    (8192, 40, 7, 1), (12289, 40, 7, 0), (300000, 1000, 50, 0), (300001, 200, 9, 1), (2000003, 5000, 120, 0),
+])
+def test_fused_vs_oracle_synth(ctx, n, nr, ng, mode):
+    lcp, da, eb = O.synth(1000 + n, 0, n, nr, ng, 16, mode)
+    cl, nc, ml = O.detect(lcp, da, nr, 16)
+    for e in (eb, None):
+        exp = O.score(da, e, cl, nr, ng, threads=4)
+        sim, gnc, gml = ctx.fused(lcp, da, e, nr, ng, 16)
+        assert (gnc, gml) == (nc, ml)
+        assert np.array_equal(sim, exp)
+    gcl, gnc, gml = ctx.detect(lcp, da, nr, 16)
+    assert np.array_equal(gcl, cl) and (gnc, gml) == (nc, ml)
+
+
+def test_empty_input(ctx):
+    z32 = np.zeros(0, np.uint32)
+    cl, nc, ml = ctx.detect(z32, z32, 3, 16)
+    assert nc == 0 and ml == 0 and cl.shape == (0, 2)
+    sim, nc, ml = ctx.fused(z32, z32, np.zeros(0, np.uint8), 3, 2, 16)
+    assert nc == 0 and not sim.any()
+    sim = ctx.score(z32, None, np.zeros((0, 2), np.uint64), 3, 2)
+    assert not sim.any()
+
+
+@pytest.mark.parametrize("alpha", [1, 16, 40, 63])
+def test_alpha_sweep(ctx, alpha):
+    lcp, da, eb = O.synth(77, 0, 200000, 300, 11, 16, 0)
+    cl, nc, ml = O.detect(lcp, da, 300, alpha)
+    exp = O.score(da, eb, cl, 300, 11, threads=4)
+    sim, gnc, gml = ctx.fused(lcp, da, eb, 300, 11, alpha)
+    assert (gnc, gml) == (nc, ml) and np.array_equal(sim, exp)
+
+
+def test_long_clusters_and_tile_crossings(ctx):
+    """runs of every scale: > 64 (big-cluster kernel), > 4096 (several tiles), reaching EOF;
+    few documents so per-cluster counts pass 255 (genome saturation, read wrap)."""
+    rng = np.random.default_rng(11)
+    n = 150000
+    lcp = np.where(rng.random(n) < 0.97, 20, 3).astype(np.uint32)
+    lcp[0] = 0
+    lcp[20000:45000] = 30          # 25000-long run
+    lcp[45000] = 1
+    lcp[100000:100000 + 65536] = 30  # exactly at the 65536 limit
+    lcp[100000] = 0
+    lcp[100000 + 65536] = 0
+    da = np.where(rng.random(n) < 0.5, rng.integers(0, 3, n), 3 + rng.integers(0, 4, n)).astype(np.uint32)
+    eb = rng.choice(np.frombuffer(b"ACGTNRY\x00", np.uint8), n).astype(np.uint8)
+    cl, nc, ml = O.detect(lcp, da, 3, 16)
+    assert ml == 65536
+    for e in (eb, None):
+        exp = O.score(da, e, cl, 3, 4, threads=4)
+        sim, gnc, gml = ctx.fused(lcp, da, e, 3, 4, 16)
+        assert (gnc, gml) == (nc, ml)
+        assert np.array_equal(sim, exp)
+        assert np.array_equal(ctx.score(da, e, cl, 3, 4), exp)
+
+
+def test_many_docs_big_cluster(ctx):
+    """a long cluster with thousands of distinct reads and genomes (hash table path)."""
+    rng = np.random.default_rng(12)
+    n = 30000
+    lcp = np.full(n, 25, np.uint32); lcp[0] = 0; lcp[20000] = 2; lcp[20001:] = 3
+    nr, ng = 3000, 700
+    da = np.where(rng.random(n) < 0.6, rng.integers(0, nr, n), nr + rng.integers(0, ng, n)).astype(np.uint32)
+    eb = rng.choice(np.frombuffer(b"ACGTN", np.uint8), n).astype(np.uint8)
+    cl, nc, ml = O.detect(lcp, da, nr, 16)
+    assert nc == 1 and ml == 20000
+    exp = O.score(da, eb, cl, nr, ng)
+    sim, gnc, gml = ctx.fused(lcp, da, eb, nr, ng, 16)
+    assert (gnc, gml) == (nc, ml) and np.array_equal(sim, exp)
+
+
+def test_maxlen_error(ctx):
+    import lime_amd
+    n = 70000
+    lcp = np.full(n, 20, np.uint32); lcp[0] = 0
+    da = (np.arange(n) % 2).astype(np.uint32)
+    cl, nc, ml = ctx.detect(lcp, da, 1, 16)           # detection has no limit (ClusterLCP)
+    assert nc == 1 and ml == n
+    with pytest.raises(lime_amd.LimeError) as e:       # scoring refuses > 65536 (ClusterBWT_DA.cpp:558-562)
+        ctx.fused(lcp, da, None, 1, 1, 16)
+    assert e.value.code == -4
+    with pytest.raises(lime_amd.LimeError):
+        ctx.score(da, None, cl, 1, 1)
+
+
+def test_docid_out_of_range_is_reported(ctx):
+    import lime_amd
+    lcp = np.array([0, 20, 20, 0], np.uint32)
+    da = np.array([0, 9, 1, 0], np.uint32)              # 9 >= n_reads + n_refs
+    with pytest.raises(lime_amd.LimeError) as e:
+        ctx.fused(lcp, da, None, 1, 2, 16)
+    assert e.value.code == -6
+
+
+# ---- device-resident API: synthetic generator, shards ----------------------------------------
+def test_device_synth_equals_oracle(ctx):
+    import torch
+    n = 100000
+    for mode in (0, 1):
+        l = torch.empty(n, dtype=torch.int32, device="cuda")
+        d = torch.empty(n, dtype=torch.int32, device="cuda")
+        e = torch.empty(n, dtype=torch.uint8, device="cuda")
+        ctx.synth_dev(42, 5000, n, 321, 17, 16, mode, l, d, e)
+        torch.cuda.synchronize()
+        ol, od, oe = O.synth(42, 5000, n, 321, 17, 16, mode)
+        assert np.array_equal(l.cpu().numpy().view(np.uint32), ol)
+        assert np.array_equal(d.cpu().numpy().view(np.uint32), od)
+        assert np.array_equal(e.cpu().numpy(), oe)
+
+
+@pytest.mark.parametrize("n_shards", [2, 3, 5])
+def test_position_range_shards_sum_to_whole(ctx, n_shards):
+    """shard by contiguous tile-aligned ranges with a halo; per-shard tables add up (mod 256)
+    to the single-pass table and the counters combine (sum / max) -- the multi-GPU scheme."""
+    import torch
+    from lime_amd.dist import shard_ranges
+    n, nr, ng = 700001, 200, 13
+    lcp, da, eb = O.synth(9, 0, n, nr, ng, 16, 1)
+    lcp[300000:300900] = 20                      # a run across a shard cut region
+    cl, nc, ml = O.detect(lcp, da, nr, 16)
+    exp = O.score(da, eb, cl, nr, ng, threads=4)
+    total = np.zeros((nr, ng), np.uint8)
+    tot_c, tot_m = 0, 0
+    for lo, hi, hi_halo in shard_ranges(n, n_shards, halo=65536 + 4096):
+        tl = torch.from_numpy(lcp[lo:hi_halo].view(np.int32)).cuda()
+        td = torch.from_numpy(da[lo:hi_halo].view(np.int32)).cuda()
+        te = torch.from_numpy(eb[lo:hi_halo]).cuda()
+        sim = torch.zeros(lime_sim_bytes(nr, ng), dtype=torch.uint8, device="cuda")
+        ctx.fused_dev(tl, td, te, hi - lo, hi_halo - lo, hi_halo == n, nr, ng, 16, sim)
+        s, rc = ctx.stats()
+        assert rc == 0
+        tot_c += s.n_clusters; tot_m = max(tot_m, s.max_len)
+        total = (total + sim[:nr * ng].cpu().numpy().reshape(nr, ng)).astype(np.uint8)
+    assert (tot_c, tot_m) == (nc, ml)
+    assert np.array_equal(total, exp)
+
+
+def lime_sim_bytes(nr, ng):
+    import lime_amd
+    return lime_amd.sim_bytes(nr, ng)
