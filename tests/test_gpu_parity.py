@@ -152,7 +152,7 @@ def test_long_clusters_and_tile_crossings(ctx):
     """runs of every scale: > 64 (big-cluster kernel), > 4096 (several tiles), reaching EOF;
     few documents so per-cluster counts pass 255 (genome saturation, read wrap)."""
     rng = np.random.default_rng(11)
-    n = 150000
+    n = 200000
     lcp = np.where(rng.random(n) < 0.97, 20, 3).astype(np.uint32)
     lcp[0] = 0
     lcp[20000:45000] = 30          # 25000-long run
