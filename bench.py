@@ -36,7 +36,12 @@ HBM_PEAK_GBS = 8000.0           # MI355X_MICROARCH.md: 8.0 TB/s spec
 def cpu_baseline(lcp_t, da_t, eb_t, n, sample_n):
     """Reference binaries (or the oracle port) on the first `sample_n` symbols, all host cores."""
     import numpy as np
-    cores = os.cpu_count() or 1
+    # the GPU box gives one GPU's share of the host: at most 16 cores (the pool's sizing rule)
+    try:
+        cores = len(os.sched_getaffinity(0))
+    except AttributeError:
+        cores = os.cpu_count() or 1
+    cores = max(1, min(cores, 16))
     sample_n = min(sample_n, n)
     lcp = lcp_t[:sample_n].cpu().numpy().view(np.uint32)
     da = da_t[:sample_n].cpu().numpy().view(np.uint32)
