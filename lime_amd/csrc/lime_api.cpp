@@ -49,8 +49,9 @@ struct lime_ctx {
     lime_cluster_t *d_big = nullptr; uint32_t big_cap = 0;
     lime_cluster_t *d_out = nullptr; size_t out_cap = 0;
     uint32_t *d_big_scratch = nullptr;
-    uint32_t max_blocks = 0xFFFFFFFFu;      // grid cap of the tile kernel (LIME_MAX_BLOCKS)
+    uint32_t max_blocks = 512;              // persistent grid of the tile kernel: 2 workgroups per CU (LIME_MAX_BLOCKS)
     uint32_t list_blocks = 8192;
+    int ablate = 0;                         // LIME_ABLATE: kernel timing experiments (results invalid when != 0)
     // timing of the scan kernel with HIP events on the launch stream
     bool timing = false;
     std::vector<hipEvent_t> ev;             // pairs
@@ -87,6 +88,12 @@ extern "C" int lime_init(int device, lime_ctx **out)
     HIP_TRY(hipMalloc(&c->d_stats, sizeof(DevStats)));
     HIP_TRY(hipMalloc(&c->d_total, sizeof(unsigned long long)));
     HIP_TRY(hipMemset(c->d_stats, 0, sizeof(DevStats)));
+    {
+        hipDeviceProp_t prop;
+        if (hipGetDeviceProperties(&prop, c->device) == hipSuccess && prop.multiProcessorCount > 0)
+            c->max_blocks = 2u * (uint32_t)prop.multiProcessorCount;
+    }
+    if (const char *s = getenv("LIME_ABLATE")) c->ablate = atoi(s);
     if (const char *s = getenv("LIME_MAX_BLOCKS")) { long v = atol(s); if (v > 0) c->max_blocks = (uint32_t)v; }
     *out = c;
     return LIME_OK;
@@ -166,6 +173,7 @@ static ScanArgs base_args(lime_ctx *c, const uint32_t *lcp, const uint32_t *da, 
     a.sim = sim; a.summ = c->d_summ; a.stats = c->d_stats;
     a.small = c->d_small; a.cross_cap = c->small_cap; a.big = c->d_big; a.big_cap = c->big_cap;
     a.tile_cnt = c->d_tile_cnt; a.tile_off = c->d_tile_off; a.cross = c->d_cross; a.out = c->d_out;
+    a.ablate = c->ablate;
     return a;
 }
 

@@ -62,6 +62,8 @@ LIME_HD uint32_t byte_of(const uint32_t (&w)[4], int i) { return (w[i >> 2] >> (
 // Pair score on packed histograms: byte i of (w[i/4]) = count of symbol index i.
 // cr: read counts (already reduced mod 256), cg: genome counts (already saturated at 255).
 // Returns t mod 256.
+LIME_HD uint32_t pair_score_iupac(const uint32_t (&cr)[4], const uint32_t (&cg)[4]);
+
 LIME_HD uint32_t pair_score(const uint32_t (&cr)[4], const uint32_t (&cg)[4])
 {
     // No IUPAC code (indices 4..14) on either side: the cross-match block (:146-177) adds
@@ -73,25 +75,45 @@ LIME_HD uint32_t pair_score(const uint32_t (&cr)[4], const uint32_t (&cg)[4])
         uint32_t sd = sad_u8(cr[0], cg[0], sad_u8(cr[3], cg[3], 0u));
         return ((sr + sg - sd) >> 1) & 255u;
     }
-    uint32_t t = 0, rr[16], rg[16];
-#pragma unroll
-    for (int i = 0; i < 16; i++) {               // :133-144
-        uint32_t a = byte_of(cr, i), b = byte_of(cg, i);
-        uint32_t mn = a < b ? a : b;
-        t += mn; rr[i] = a - mn; rg[i] = b - mn;
+    return pair_score_iupac(cr, cg);
+}
+
+// byte i (0..15) of a packed histogram, dynamic i, no memory indexing
+LIME_HD uint32_t hist_get(const uint32_t (&w)[4], uint32_t i)
+{
+    const uint32_t x = (i & 8u) ? ((i & 4u) ? w[3] : w[2]) : ((i & 4u) ? w[1] : w[0]);
+    return (x >> ((i & 3u) * 8u)) & 255u;
+}
+LIME_HD void hist_set(uint32_t (&w)[4], uint32_t i, uint32_t v)
+{
+    const uint32_t sh = (i & 3u) * 8u, keep = ~(255u << sh), k = i >> 2;
+    w[0] = (k == 0u) ? ((w[0] & keep) | (v << sh)) : w[0];
+    w[1] = (k == 1u) ? ((w[1] & keep) | (v << sh)) : w[1];
+    w[2] = (k == 2u) ? ((w[2] & keep) | (v << sh)) : w[2];
+    w[3] = (k == 3u) ? ((w[3] & keep) | (v << sh)) : w[3];
+}
+
+// the general case (rare): rolled loops over packed leftovers, to keep the kernels small
+LIME_HD uint32_t pair_score_iupac(const uint32_t (&cr)[4], const uint32_t (&cg)[4])
+{
+    uint32_t t = 0, rr[4] = {0u, 0u, 0u, 0u}, rg[4] = {0u, 0u, 0u, 0u};
+    for (uint32_t i = 0; i < 16u; i++) {         // :133-144
+        const uint32_t a = hist_get(cr, i), b = hist_get(cg, i);
+        const uint32_t mn = a < b ? a : b;
+        t += mn; hist_set(rr, i, a - mn); hist_set(rg, i, b - mn);
     }
-#pragma unroll
-    for (int i = 0; i < 4; i++) {                // :146-177
-#pragma unroll
-        for (int a = 4; a < 15; a++) {
-            if (!((CORR_PACKED >> (a * 4 + i)) & 1ull)) continue;
-            if (rg[a] > 0) {                     // :150-161 (as written: the zeroed side is "subtracted")
-                if (rg[a] > rr[i]) { t += rr[i]; rr[i] = 0; }
-                else               { t += rg[a]; rg[a] = 0; }
+    for (uint32_t i = 0; i < 4u; i++) {          // :146-177
+        for (uint32_t a = 4; a < 15u; a++) {
+            if (!((CORR_PACKED >> (a * 4u + i)) & 1ull)) continue;
+            uint32_t ga = hist_get(rg, a), ri = hist_get(rr, i);
+            if (ga > 0u) {                       // :150-161 (as written: the zeroed side is "subtracted")
+                if (ga > ri) { t += ri; ri = 0u; hist_set(rr, i, 0u); }
+                else         { t += ga; hist_set(rg, a, 0u); }
             }
-            if (rr[a] > 0) {                     // :163-174
-                if (rr[a] > rg[i]) { t += rg[i]; rr[a] -= rg[i]; rg[i] = 0; }
-                else               { t += rr[a]; rg[i] -= rr[a]; rr[a] = 0; }
+            uint32_t ra = hist_get(rr, a), gi = hist_get(rg, i);
+            if (ra > 0u) {                       // :163-174
+                if (ra > gi) { t += gi; hist_set(rr, a, ra - gi); hist_set(rg, i, 0u); }
+                else         { t += ra; hist_set(rg, i, gi - ra); hist_set(rr, a, 0u); }
             }
         }
     }

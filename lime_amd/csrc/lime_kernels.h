@@ -8,11 +8,12 @@
 namespace lime {
 
 constexpr int TILE = LIME_TILE;              // positions per workgroup tile
-constexpr int WGSZ = 256;                    // 4 waves of 64
+constexpr int WGSZ = 512;                    // 8 waves of 64
+constexpr uint32_t WPW = (LIME_TILE / 64) / (WGSZ / 64);   // mask words owned by a wave
 constexpr int NWORDS = TILE / 64;            // 64-bit mask words per tile
-constexpr uint32_t SMALL_MAX = 64;           // longest cluster scored inside a tile
+constexpr uint32_t SMALL_MAX = 16;           // longest cluster scored inside a tile (quadratic lane loops)
 constexpr uint32_t NONE32 = 0xFFFFFFFFu;
-constexpr uint32_t LIST_BATCH = 64;          // clusters gathered per workgroup pass in k_score_list
+constexpr uint32_t LIST_BATCH = 256;         // clusters gathered per workgroup pass in k_score_list
 constexpr uint32_t HT_BITS = 17;             // >= 2 x LIME_MAX_CLUSTER slots: the table never fills
 constexpr uint32_t HT_SIZE = 1u << HT_BITS;
 constexpr uint32_t HT_EMPTY = 0xFFFFFFFFu;
@@ -39,6 +40,7 @@ struct ScanArgs {
     lime_cluster_t *small; uint32_t cross_cap;   // tile-crossing clusters <= SMALL_MAX
     lime_cluster_t *big; uint32_t big_cap;       // clusters > SMALL_MAX
     uint32_t *tile_cnt; uint64_t *tile_off; CrossRec *cross; lime_cluster_t *out;   // detect only
+    int ablate;                                  // timing experiments only (LIME_ABLATE): 0 = full kernel
 };
 
 void launch_tile(int ebwt, int mode, const ScanArgs &a, uint32_t max_blocks, hipStream_t st);

@@ -256,3 +256,25 @@ def test_position_range_shards_sum_to_whole(ctx, n_shards):
 def lime_sim_bytes(nr, ng):
     import lime_amd
     return lime_amd.sim_bytes(nr, ng)
+
+
+@pytest.mark.parametrize("max_blocks", [1, 3, 7, 64])
+def test_persistent_workgroups_walk_many_tiles(max_blocks, monkeypatch):
+    """few persistent workgroups, each walking many tiles with the next tile prefetched."""
+    import lime_amd
+    monkeypatch.setenv("LIME_MAX_BLOCKS", str(max_blocks))
+    c = lime_amd.Context()
+    try:
+        for seed, mode in ((5, 0), (6, 1)):
+            n, nr, ng = 700000 + seed, 300, 20
+            lcp, da, eb = O.synth(seed, 0, n, nr, ng, 16, mode)
+            cl, nc, ml = O.detect(lcp, da, nr, 16)
+            gcl, gnc, gml = c.detect(lcp, da, nr, 16)
+            assert np.array_equal(gcl, cl) and (gnc, gml) == (nc, ml)
+            for e in (eb, None):
+                exp = O.score(da, e, cl, nr, ng, threads=4)
+                sim, gnc, gml = c.fused(lcp, da, e, nr, ng, 16)
+                assert (gnc, gml) == (nc, ml)
+                assert np.array_equal(sim, exp)
+    finally:
+        c.close()
