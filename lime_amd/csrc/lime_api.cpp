@@ -49,7 +49,7 @@ struct lime_ctx {
     lime_cluster_t *d_big = nullptr; uint32_t big_cap = 0;
     lime_cluster_t *d_out = nullptr; size_t out_cap = 0;
     uint32_t *d_big_scratch = nullptr;
-    uint32_t max_blocks = 512;              // persistent grid of the tile kernel: 2 workgroups per CU (LIME_MAX_BLOCKS)
+    uint32_t max_blocks = 0;                // persistent grid of the scan kernel; 0 = as many workgroups as fit the device (LIME_MAX_BLOCKS)
     uint32_t list_blocks = 8192;
     int ablate = 0;                         // LIME_ABLATE: kernel timing experiments (results invalid when != 0)
     // timing of the scan kernel with HIP events on the launch stream
@@ -88,11 +88,6 @@ extern "C" int lime_init(int device, lime_ctx **out)
     HIP_TRY(hipMalloc(&c->d_stats, sizeof(DevStats)));
     HIP_TRY(hipMalloc(&c->d_total, sizeof(unsigned long long)));
     HIP_TRY(hipMemset(c->d_stats, 0, sizeof(DevStats)));
-    {
-        hipDeviceProp_t prop;
-        if (hipGetDeviceProperties(&prop, c->device) == hipSuccess && prop.multiProcessorCount > 0)
-            c->max_blocks = 2u * (uint32_t)prop.multiProcessorCount;
-    }
     if (const char *s = getenv("LIME_ABLATE")) c->ablate = atoi(s);
     if (const char *s = getenv("LIME_MAX_BLOCKS")) { long v = atol(s); if (v > 0) c->max_blocks = (uint32_t)v; }
     *out = c;
@@ -122,7 +117,7 @@ template <typename T> static int regrow(T *&p, size_t count)
 // scratch sized for an array of n_avail positions; grow-only, so steady-state calls allocate nothing
 static int ensure_scratch(lime_ctx *c, uint64_t n_avail, bool detect, bool score, hipStream_t st)
 {
-    const size_t n_tiles = (size_t)((n_avail + TILE - 1) / TILE);
+    const size_t n_tiles = (size_t)((n_avail + WIN - 1) / WIN);
     int rc;
     if (n_tiles > c->tile_cap) {
         HIP_TRY(hipStreamSynchronize(st));
@@ -134,7 +129,8 @@ static int ensure_scratch(lime_ctx *c, uint64_t n_avail, bool detect, bool score
         c->tile_cap = cap;
     }
     if (score) {
-        const uint64_t want_small = n_tiles + 16, want_big = n_avail / SMALL_MAX + n_tiles + 16;
+        // clusters longer than SMALL_MAX; at most n/(SMALL_MAX+1) exist, sized for 1 in 4 of that
+        const uint64_t want_small = 16, want_big = n_avail / (4u * SMALL_MAX) + 65536u;
         if (want_big > 0xFFFFFFF0ull) return fail(LIME_ERR_ARG, "array too long for one shard: %llu", (unsigned long long)n_avail);
         if (want_small > c->small_cap) { HIP_TRY(hipStreamSynchronize(st)); if ((rc = regrow(c->d_small, want_small))) return rc; c->small_cap = (uint32_t)want_small; }
         if (want_big > c->big_cap) { HIP_TRY(hipStreamSynchronize(st)); if ((rc = regrow(c->d_big, want_big))) return rc; c->big_cap = (uint32_t)want_big; }
@@ -169,7 +165,7 @@ static ScanArgs base_args(lime_ctx *c, const uint32_t *lcp, const uint32_t *da, 
     a.lcp = lcp; a.da = da; a.ebwt = ebwt;
     a.n_own = n_own; a.n_avail = n_avail; a.pos_base = 0; a.eof = eof;
     a.n_reads = n_reads; a.n_refs = n_refs; a.alpha = alpha;
-    a.n_tiles = (uint32_t)((n_avail + TILE - 1) / TILE);
+    a.n_tiles = (uint32_t)((n_avail + WIN - 1) / WIN);
     a.sim = sim; a.summ = c->d_summ; a.stats = c->d_stats;
     a.small = c->d_small; a.cross_cap = c->small_cap; a.big = c->d_big; a.big_cap = c->big_cap;
     a.tile_cnt = c->d_tile_cnt; a.tile_off = c->d_tile_off; a.cross = c->d_cross; a.out = c->d_out;
@@ -225,8 +221,8 @@ extern "C" int lime_fused_dev(lime_ctx *c, const uint32_t *d_lcp, const uint32_t
     hipStream_t st = (hipStream_t)stream;
     if (n_own > n_avail) return fail(LIME_ERR_ARG, "lime_fused_dev: n_own > n_avail");
     if (n_avail && (!d_lcp || !d_da || !d_sim)) return fail(LIME_ERR_ARG, "lime_fused_dev: NULL array");
-    if (misaligned(d_lcp, 16) || misaligned(d_da, 16) || misaligned(d_ebwt, 4) || misaligned(d_sim, 4))
-        return fail(LIME_ERR_ARG, "lime_fused_dev: device arrays must be 16-byte aligned (ebwt/sim: 4)");
+    if (misaligned(d_lcp, 16) || misaligned(d_da, 16) || misaligned(d_ebwt, 8) || misaligned(d_sim, 4))
+        return fail(LIME_ERR_ARG, "lime_fused_dev: device arrays must be 16-byte aligned (ebwt: 8, sim: 4)");
     if (!n_reads || !n_refs) return fail(LIME_ERR_ARG, "lime_fused_dev: n_reads and n_refs must be > 0");
     if ((rc = ensure_scratch(c, n_avail, false, true, st))) return rc;
     HIP_TRY(hipMemsetAsync(c->d_stats, 0, sizeof(DevStats), st));
@@ -238,7 +234,6 @@ extern "C" int lime_fused_dev(lime_ctx *c, const uint32_t *d_lcp, const uint32_t
     launch_tile(ebwt, 0, a, c->max_blocks, st);
     if ((rc = timing_mark(c, st))) return rc;
     launch_resolve(0, a, st);
-    launch_score_list(ebwt, a, c->d_small, &c->d_stats->n_cross, 0, c->small_cap, 1024, st);
     launch_score_big(ebwt, a, c->d_big_scratch, st);
     HIP_TRY(hipGetLastError());
     return LIME_OK;
@@ -252,9 +247,8 @@ extern "C" int lime_get_stats(lime_ctx *c, lime_stats_t *out, void *stream)
     HIP_TRY(hipMemcpyAsync(&s, c->d_stats, sizeof s, hipMemcpyDeviceToHost, st));
     HIP_TRY(hipStreamSynchronize(st));
     if (out) *out = s;
-    if ((c->small_cap && s.n_cross > c->small_cap) || (c->big_cap && s.n_big > c->big_cap))
-        return fail(LIME_ERR_NOMEM, "internal cluster list overflow (cross %u/%u, big %u/%u)", s.n_cross,
-                    c->small_cap, s.n_big, c->big_cap);
+    if (c->big_cap && s.n_big > c->big_cap)
+        return fail(LIME_ERR_NOMEM, "more clusters longer than %u symbols (%u) than the list holds (%u)", SMALL_MAX, s.n_big, c->big_cap);
     return flags_to_rc(s.flags);
 }
 
@@ -323,9 +317,9 @@ extern "C" int lime_score_dev(lime_ctx *c, const uint32_t *d_da, const uint8_t *
     if (!n_clusters) return LIME_OK;
     ScanArgs a = base_args(c, nullptr, d_da, d_ebwt, n, n, 1, n_reads, n_refs, 0, d_sim);
     const int ebwt = d_ebwt != nullptr;
-    uint64_t batches = (n_clusters + LIST_BATCH - 1) / LIST_BATCH;
+    uint64_t batches = (n_clusters + 255) / 256;          // 64 clusters per wave, 4 waves per workgroup
     uint32_t blocks = (uint32_t)(batches < c->list_blocks ? batches : c->list_blocks);
-    launch_score_list(ebwt, a, d_clusters, nullptr, n_clusters, 0, blocks, st);
+    launch_score_list(ebwt, a, d_clusters, n_clusters, blocks, st);
     launch_score_big(ebwt, a, c->d_big_scratch, st);
     HIP_TRY(hipGetLastError());
     return LIME_OK;

@@ -7,20 +7,20 @@
 
 namespace lime {
 
-constexpr int TILE = LIME_TILE;              // positions per workgroup tile
-constexpr int WGSZ = 512;                    // 8 waves of 64
-constexpr uint32_t WPW = (LIME_TILE / 64) / (WGSZ / 64);   // mask words owned by a wave
-constexpr int NWORDS = TILE / 64;            // 64-bit mask words per tile
-constexpr uint32_t SMALL_MAX = 16;           // longest cluster scored inside a tile (quadratic lane loops)
+constexpr uint32_t WIN = 512;                // positions a wave owns per window (8 per lane)
+constexpr uint32_t HALO = 16;                // read-ahead positions behind a window (>= SMALL_MAX)
+constexpr uint32_t WPOS = WIN + HALO;
+constexpr int SCAN_WG = 256;                 // 4 independent waves per workgroup of the scan kernels
+constexpr int WGSZ = 512;                    // workgroup of the helper kernels (big clusters, choose, synth)
+constexpr uint32_t SMALL_MAX = 16;           // longest cluster scored inside a window
 constexpr uint32_t NONE32 = 0xFFFFFFFFu;
-constexpr uint32_t LIST_BATCH = 256;         // clusters gathered per workgroup pass in k_score_list
 constexpr uint32_t HT_BITS = 17;             // >= 2 x LIME_MAX_CLUSTER slots: the table never fills
 constexpr uint32_t HT_SIZE = 1u << HT_BITS;
 constexpr uint32_t HT_EMPTY = 0xFFFFFFFFu;
 constexpr uint32_t BIG_GRID = 32;            // workgroups of k_score_big (each owns a scratch table)
 constexpr size_t BIG_SCRATCH_WORDS = (size_t)HT_SIZE + (size_t)HT_SIZE * 16u + 2u * LIME_MAX_CLUSTER;
 
-struct TileSummary { uint32_t first_head, last_head, pre, suf; };   // offsets in tile; flags bit0 read, bit1 genome
+struct TileSummary { uint32_t first_head, last_head, pre, suf; };   // per window: offsets in window; flags bit0 read, bit1 genome
 struct CrossRec { uint64_t start, len; };                          // len == 0: none
 
 struct DevStats {                            // same layout as lime_stats_t
@@ -33,7 +33,7 @@ struct ScanArgs {
     const uint32_t *lcp; const uint32_t *da; const uint8_t *ebwt;
     uint64_t n_own, n_avail, pos_base;
     int eof;
-    uint32_t n_reads, n_refs, alpha, n_tiles;
+    uint32_t n_reads, n_refs, alpha, n_tiles;    // n_tiles: number of WIN-position windows
     uint8_t *sim;
     TileSummary *summ;
     DevStats *stats;
@@ -46,8 +46,7 @@ struct ScanArgs {
 void launch_tile(int ebwt, int mode, const ScanArgs &a, uint32_t max_blocks, hipStream_t st);
 void launch_resolve(int mode, const ScanArgs &a, hipStream_t st);
 void launch_scan_tiles(const uint32_t *cnt, uint64_t *off, uint32_t n, unsigned long long *total, hipStream_t st);
-void launch_score_list(int ebwt, const ScanArgs &a, const lime_cluster_t *list, const uint32_t *count_ptr,
-                       uint64_t count, uint32_t cap, uint32_t blocks, hipStream_t st);
+void launch_score_list(int ebwt, const ScanArgs &a, const lime_cluster_t *list, uint64_t count, uint32_t blocks, hipStream_t st);
 void launch_score_big(int ebwt, const ScanArgs &a, uint32_t *scratch, hipStream_t st);
 void launch_choose(const uint8_t *sim, uint32_t n_reads, uint32_t n_refs, uint8_t *row_max,
                    uint32_t *row_nnz, hipStream_t st);

@@ -2,15 +2,19 @@
 // alpha-cluster detection over lcp/da (reference: src/ClusterLCP.cpp:140-283) and per-cluster
 // read x genome similarity accumulation over ebwt/da (reference: src/ClusterBWT_DA.cpp:256-358).
 //
-// Design: the unit of work is a POSITION; clusters are segments delimited
-// by head(i) := lcp[i] < alpha.  A workgroup streams one 4096-position tile with 16-byte
-// coalesced loads, stages da + a flag byte per position in LDS, derives 64-bit head / read /
-// genome masks with wave ballots, resolves every segment that lies inside the tile with
-// bit-scans on those masks, and scores it from LDS.  Segments that leave the tile are closed
-// from per-tile summaries by k_resolve and scored by the list kernel; clusters longer than
-// the in-tile limit go to a one-workgroup-per-cluster hash kernel.  Integer/byte work only:
-// no MFMA, HBM-bound; the score table is updated with 32-bit CAS on the packed byte cells so
-// that every cell is exact modulo 256 like the reference's unsigned char.
+// Design: the unit of work is a POSITION; clusters are segments delimited by
+// head(i) := lcp[i] < alpha.  Every WAVE is an independent worker: it streams 512-position
+// windows (+16 positions of read-ahead) with 16-byte loads, 8 consecutive positions per lane,
+// keeps the next window's loads in flight while it works on the current one, and never meets
+// a workgroup barrier.  Per window: head / read / genome bits of a lane's 8 positions become
+// bytes of 64-bit masks (lane = mask word); which heads open an accepted cluster is decided by
+// carry-ripple arithmetic on those masks; the clusters (<= 16 symbols) are scored by groups of
+// 4 or 16 lanes that rotate the cluster's elements past each other with DPP moves; table
+// updates are queued in LDS and applied together.  Clusters that do not close inside the
+// read-ahead are closed from per-window summaries by k_resolve; clusters longer than 16 go to
+// a one-workgroup-per-cluster hash kernel.  Integer/byte work only: no MFMA, HBM-bound; the
+// score table is updated with 32-bit CAS on the packed byte cells so that every cell is exact
+// modulo 256 like the reference's unsigned char.
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include "lime_device.h"
@@ -23,26 +27,21 @@ constexpr uint32_t F_SYM = 0x0F;
 constexpr uint32_t F_HEAD = 0x10;
 constexpr uint32_t F_READ = 0x20;
 constexpr uint32_t F_GEN = 0x40;
-constexpr uint32_t LDS_PAD = 16;      // clusters are read up to 16 wide from any start
 
-// accepted clusters of a tile, by length class; an entry is start | (len-1) << 12
-constexpr uint32_t CAP_A = TILE / 2, CAP_B = TILE / 5 + 1, CAP_C = TILE / 9 + 1, CAP_D = TILE / 2;
 constexpr uint32_t QCAP = 128;        // pending table updates per wave
-constexpr uint32_t NWAVES = WGSZ / 64;
-constexpr uint32_t T_SHIFT = 27;      // queue entry: genome | t << 27 (t <= SMALL_MAX)
+constexpr uint32_t T_SHIFT = 27;      // queue entry: genome | t << 27 (t <= SMALL_MAX < 32)
+constexpr uint32_t CAP_A = 256;       // clusters (2..SMALL_MAX symbols) a window can own
+constexpr uint32_t CAP_D = 256;       // of those, clusters with a repeated document (general routine)
 
-struct TileLds {
-    uint32_t da[TILE + LDS_PAD];
-    uint8_t fl[TILE + LDS_PAD];
-    uint16_t listA[CAP_A];            // len 2..4
-    uint16_t listB[CAP_B];            // len 5..8
-    uint16_t listC[CAP_C];            // len 9..SMALL_MAX
-    uint16_t listD[CAP_D];            // clusters with a repeated document (general routine)
-    uint32_t q_read[NWAVES][QCAP], q_gen[NWAVES][QCAP];
-    uint64_t H[NWORDS], R[NWORDS], G[NWORDS], A[NWORDS];
-    uint32_t esuf[NWORDS], apre[NWORDS];
-    uint32_t nA, nB, nC, nD, cnt, upd;
-    unsigned long long maxlen;
+// LDS of ONE wave: the staged window and its work lists.  `da`/`fl` are sized by the kernel.
+template <uint32_t NPOS>
+struct alignas(16) WaveLds {
+    uint32_t da[NPOS];
+    uint8_t fl[NPOS];
+    uint8_t hb[72], gb[72];           // per lane: head / genome bits of its 8 positions
+    uint8_t rb[NPOS / 8 + 8];         // read bit of every staged position (byte k = positions 8k..8k+7)
+    uint16_t listA[CAP_A], listD[CAP_D];   // entry: start | (len-1) << 12
+    uint32_t q_read[QCAP], q_gen[QCAP];
 };
 
 __device__ __forceinline__ uint32_t lane_id() { return threadIdx.x & 63u; }
@@ -51,6 +50,22 @@ __device__ __forceinline__ uint32_t rl32(uint32_t v, uint32_t l) { return (uint3
 __device__ __forceinline__ uint64_t rl64(uint64_t v, uint32_t l)
 {
     return ((uint64_t)rl32((uint32_t)(v >> 32), l) << 32) | rl32((uint32_t)v, l);
+}
+__device__ __forceinline__ uint64_t shfl64(uint64_t v, int l)
+{
+    return ((uint64_t)(uint32_t)__shfl((int)(v >> 32), l) << 32) | (uint32_t)__shfl((int)(uint32_t)v, l);
+}
+__device__ __forceinline__ uint32_t wave_sum(uint32_t v)
+{
+#pragma unroll
+    for (int d = 32; d > 0; d >>= 1) v += __shfl_xor(v, d);
+    return v;
+}
+__device__ __forceinline__ uint32_t wave_max(uint32_t v)
+{
+#pragma unroll
+    for (int d = 32; d > 0; d >>= 1) { const uint32_t o = __shfl_xor(v, d); v = o > v ? o : v; }
+    return v;
 }
 
 // exact "cell += t (mod 256)" on the byte table through a 32-bit CAS on the containing word.
@@ -70,124 +85,8 @@ __device__ __forceinline__ void sim_add(uint8_t *sim, uint64_t cell, uint32_t t)
     }
 }
 
-// ---- masks from the staged flag bytes: wave k owns the 64-bit words [k*WPW, (k+1)*WPW) --
-__device__ __forceinline__ void build_masks(TileLds &L)
-{
-    const uint32_t wave = threadIdx.x >> 6, lane = lane_id();
-#pragma unroll
-    for (uint32_t j = 0; j < WPW; ++j) {
-        const uint32_t w = wave * WPW + j;
-        uint32_t f = L.fl[w * 64u + lane];
-        uint64_t h = __ballot((f & F_HEAD) != 0u);
-        uint64_t r = __ballot((f & F_READ) != 0u);
-        uint64_t g = __ballot((f & F_GEN) != 0u);
-        if (lane == 0) { L.H[w] = h; L.R[w] = r; L.G[w] = g; }
-    }
-}
-
-// ---- phase A, by ONE wave with lane = mask word: all 64 words of the tile at once ---------
-// Which heads open an accepted cluster.  Segments wholly inside a word are decided by
-// bit-parallel arithmetic on that word's masks; the segment headed at a word's LAST head may
-// run into later words: its end and its read/genome content come from the words after it,
-// found with bit-scans on the wave-wide "word has a head" ballot.
-struct TileCtx {
-    uint64_t h, r, g;   // masks of this lane's word
-    uint64_t ah;        // heads of accepted, owned clusters that close inside the tile
-    uint32_t e_suf;     // tile position where the segment of the word's last head ends (NONE32: leaves the tile)
-};
-
-__device__ __forceinline__ TileCtx tile_context(const TileLds &L, uint64_t own_lim)
-{
-    const uint32_t lane = lane_id();
-    TileCtx c;
-    c.h = L.H[lane]; c.r = L.R[lane]; c.g = L.G[lane];
-    const bool has_h = c.h != 0ull;
-    const uint64_t HW = __ballot(has_h), RW = __ballot(c.r != 0ull), GW = __ballot(c.g != 0ull);
-    const uint32_t fh = has_h ? (uint32_t)__builtin_ctzll(c.h) : 64u;
-    const uint32_t lh = has_h ? 63u - (uint32_t)__clzll((long long)c.h) : 0u;
-    const uint64_t lowm = fh >= 64u ? ~0ull : ((1ull << fh) - 1ull);
-    const uint32_t pre_r = (c.r & lowm) != 0ull, pre_g = (c.g & lowm) != 0ull;   // headless: whole word
-    const uint64_t him = has_h ? (~0ull << lh) : 0ull;
-    const uint32_t suf_r = (c.r & him) != 0ull, suf_g = (c.g & him) != 0ull;
-    const uint64_t gt = (lane == 63u) ? 0ull : (~0ull << (lane + 1u));
-    const uint64_t above = HW & gt;
-    const bool has_next = above != 0ull;
-    const uint32_t wn = has_next ? (uint32_t)__builtin_ctzll(above) : 64u;
-    const uint64_t between = gt & (wn >= 64u ? ~0ull : ((1ull << wn) - 1ull));   // headless words after this one
-    const uint32_t mid_r = (RW & between) != 0ull, mid_g = (GW & between) != 0ull;
-    const int src = has_next ? (int)wn : (int)lane;
-    const uint32_t n_r = __shfl(pre_r, src), n_g = __shfl(pre_g, src), n_fh = __shfl(fh, src);
-    c.e_suf = has_next ? wn * 64u + n_fh : NONE32;
-    const uint64_t acc_suf = (has_next && (suf_r | mid_r | n_r) && (suf_g | mid_g | n_g)) ? 1ull : 0ull;
-    // "segment contains a read / a genome", gathered onto the segment's head bit: in
-    // bit-reversed order a head is the TOP of its segment, and adding the seeds to the
-    // "may receive from below" mask ripples a carry through each segment up to its head.
-    const uint64_t Hr = brev64(c.h), Mr = ~(Hr << 1);
-    uint64_t Xr = brev64(c.r), Y = (Xr << 1) & Mr;
-    const uint64_t RH = (Xr | (((Mr + Y) ^ Mr) & Mr) | Y) & Hr;
-    Xr = brev64(c.g); Y = (Xr << 1) & Mr;
-    const uint64_t GH = (Xr | (((Mr + Y) ^ Mr) & Mr) | Y) & Hr;
-    uint64_t ah = brev64(RH & GH);
-    ah = (ah & ~(1ull << lh)) | (acc_suf << lh);                  // last head: decided with the words after
-    const uint64_t wlo = (uint64_t)lane * 64u;                     // ownership (last tiles of a shard)
-    ah &= own_lim >= wlo + 64u ? ~0ull : (own_lim <= wlo ? 0ull : ((1ull << (own_lim - wlo)) - 1ull));
-    c.ah = has_h ? ah : 0ull;
-    return c;
-}
-
-// Each lane walks the accepted heads of its word, measures the cluster and files it under its
-// length class (MODE 0).  Slots come from wave ballots: no atomics.  Returns via LDS counters.
-template <int MODE>
-__device__ __forceinline__ void phase_a(TileLds &L, const TileCtx &c, uint64_t tile_lo, const ScanArgs &a)
-{
-    const uint32_t lane = lane_id();
-    const uint64_t lt = (1ull << lane) - 1ull;
-    uint64_t ah = c.ah;
-    uint32_t nA = 0, nB = 0, nC = 0, maxlen = 0;
-    uint32_t n_acc = (uint32_t)__popcll(ah);
-    while (__ballot(ah != 0ull)) {
-        const bool act = ah != 0ull;
-        const uint32_t b = act ? (uint32_t)__builtin_ctzll(ah) : 0u;
-        ah &= ah - 1ull;
-        const uint32_t p = lane * 64u + b;
-        const uint64_t ha = (b == 63u) ? 0ull : (c.h & (~0ull << (b + 1u)));
-        const uint32_t e = ha ? lane * 64u + (uint32_t)__builtin_ctzll(ha) : c.e_suf;
-        const uint32_t len = act ? e - p : 0u;
-        maxlen = len > maxlen ? len : maxlen;
-        if (MODE == 0) {
-            const bool cA = act && len <= 4u, cB = act && len > 4u && len <= 8u;
-            const bool cC = act && len > 8u && len <= SMALL_MAX, cD = act && len > SMALL_MAX;
-            const uint16_t item = (uint16_t)(p | ((len - 1u) << 12));
-            const uint64_t mA = __ballot(cA), mB = __ballot(cB), mC = __ballot(cC);
-            if (cA) L.listA[nA + (uint32_t)__popcll(mA & lt)] = item;
-            nA += (uint32_t)__popcll(mA);
-            if (mB) { if (cB) L.listB[nB + (uint32_t)__popcll(mB & lt)] = item; nB += (uint32_t)__popcll(mB); }
-            if (mC) { if (cC) L.listC[nC + (uint32_t)__popcll(mC & lt)] = item; nC += (uint32_t)__popcll(mC); }
-            if (__ballot(cD)) {                                   // rare: too long for the in-tile path
-                if (cD) {
-                    if (len > LIME_MAX_CLUSTER) atomicOr(&a.stats->flags, LIME_FLAG_MAXLEN);
-                    else {
-                        uint32_t k = atomicAdd(&a.stats->n_big, 1u);
-                        if (k < a.big_cap) { a.big[k].pStart = tile_lo + p; a.big[k].len = len; }
-                    }
-                }
-            }
-        }
-    }
-#pragma unroll
-    for (int d = 32; d > 0; d >>= 1) {
-        const uint32_t om = __shfl_xor(maxlen, d), on = __shfl_xor(n_acc, d);
-        maxlen = om > maxlen ? om : maxlen; n_acc += on;
-    }
-    if (lane == 0) { L.nA = nA; L.nB = nB; L.nC = nC; L.cnt = n_acc; L.maxlen = maxlen; }
-    if (MODE == 2) { L.A[lane] = c.ah; L.esuf[lane] = c.e_suf; }
-}
-
-// ---- phase B -------------------------------------------------------------------------------
-// A wave's table updates are queued in its own LDS ring and applied together afterwards, so
-// that the round trips of the compare-and-swaps overlap instead of following one another.
-// (Kept small on purpose: everything below is rolled loops with ONE emit and ONE drain site per
-// routine -- an unrolled version of this kernel overflowed the instruction cache.)
+// ---- table updates of a wave: queued in its LDS ring, applied together so that the round
+// trips of the compare-and-swaps overlap instead of following one another -----------------
 struct UpdQueue { uint32_t *qr, *qg; uint32_t n; };
 
 __device__ __forceinline__ void drain(UpdQueue &q, const ScanArgs &a)
@@ -217,43 +116,62 @@ __device__ __forceinline__ uint32_t emit(UpdQueue &q, const ScanArgs &a, bool on
     return on ? 1u : 0u;
 }
 
-// G lanes per cluster (len <= G), element i of the cluster on sub-lane i.  Rotating the group
-// shows every lane every other element: a repeated document sends the cluster to the general
-// list; otherwise each read lane scores each genome it meets (distinct documents: the pair
-// score is iupac_match of the two symbols with EBWT, 1 without).
-template <int EBWT, int G>
-__device__ __forceinline__ uint32_t cluster_group(TileLds &L, UpdQueue &qu, const ScanArgs &a,
-                                                  const uint16_t *list, uint32_t n, uint32_t k_base)
+// ---- cluster scoring ----------------------------------------------------------------------
+// One lane per cluster of the list (<= SMALL_MAX symbols, staged at L.da/L.fl[s..s+len)).  The
+// cluster's read and genome positions are bit masks cut out of the window's mask bytes; the
+// lane walks reads x genomes by popping bits (typically one or two pairs).  With all documents
+// distinct -- checked only among documents of the same kind, the only ones that can repeat --
+// a pair scores iupac_match of its two symbols (EBWT) or 1; a cluster with a repeated document
+// goes to the general list instead.
+template <int EBWT, typename LDS>
+__device__ __forceinline__ uint32_t cluster_pairs(LDS &L, UpdQueue &qu, const ScanArgs &a, const uint16_t *list,
+                                                  uint32_t n, uint32_t k_base, uint32_t &nD)
 {
-    const uint32_t lane = lane_id(), sub = lane & (G - 1u), gbase = lane & ~(G - 1u);
-    const uint32_t k = k_base + lane / G;
+    const uint32_t lane = lane_id();
+    const uint32_t k = k_base + lane;
     const bool on = k < n;
     const uint32_t item = list[on ? k : 0u];
     const uint32_t s = item & 0xFFFu, len = on ? (item >> 12) + 1u : 0u;
-    const bool have = sub < len;
-    const uint32_t d = L.da[s + sub];
-    const uint32_t f = have ? L.fl[s + sub] : 0u;
-    uint32_t dup = 0, hits = 0;
-    for (uint32_t r = 1; r < (uint32_t)G; ++r) {
-        const int partner = (int)(gbase | ((sub + r) & (G - 1u)));
-        const uint32_t pd = __shfl(d, partner), pf = __shfl(f, partner);
-        const bool both = have && (pf & (F_READ | F_GEN));
-        dup |= (uint32_t)(both && pd == d);
-        const bool pair = both && (f & F_READ) && (pf & F_GEN);
-        const uint32_t t = EBWT ? iupac_match(f & F_SYM, pf & F_SYM) : 1u;
-        hits |= (uint32_t)(pair && t) << r;
+    const uint32_t kb = s >> 3, lenm = (1u << len) - 1u;
+    const uint32_t rbits = (uint32_t)L.rb[kb] | ((uint32_t)L.rb[kb + 1u] << 8) | ((uint32_t)L.rb[kb + 2u] << 16);
+    const uint32_t rmask = (rbits >> (s & 7u)) & lenm, gmask = ~rmask & lenm;
+    // repeated document?  (reads among reads, genomes among genomes)
+    uint32_t dup = 0;
+#pragma unroll 1
+    for (int kind = 0; kind < 2; ++kind) {
+        uint32_t mi = kind ? gmask : rmask;
+        while (__ballot((mi & (mi - 1u)) != 0u)) {
+            const uint32_t rest = mi & (mi - 1u);
+            const uint32_t di = L.da[s + (rest ? (uint32_t)__builtin_ctz(mi) : 0u)];
+            uint32_t mj = rest;
+            while (__ballot(mj != 0u)) {
+                const bool actj = mj != 0u;
+                const uint32_t dj = L.da[s + (actj ? (uint32_t)__builtin_ctz(mj) : 0u)];
+                dup |= (uint32_t)(actj && dj == di);
+                mj &= mj - 1u;
+            }
+            mi = rest;
+        }
     }
     const uint64_t dm = __ballot(dup != 0u);
-    const bool gdup = ((dm >> gbase) & ((G >= 64) ? ~0ull : ((1ull << G) - 1ull))) != 0ull;
-    if (gdup && sub == 0u) L.listD[atomicAdd(&L.nD, 1u)] = (uint16_t)item;
-    if (gdup) hits = 0u;
+    if (dup) L.listD[nD + (uint32_t)__popcll(dm & ((1ull << lane) - 1ull))] = (uint16_t)item;
+    nD += (uint32_t)__popcll(dm);
     uint32_t nupd = 0;
-    for (uint32_t r = 1; r < (uint32_t)G; ++r) {
-        const bool hit = (hits >> r) & 1u;
-        if (__ballot(hit) == 0ull) continue;
-        const int partner = (int)(gbase | ((sub + r) & (G - 1u)));
-        const uint32_t pd = __shfl(d, partner);
-        nupd += emit(qu, a, hit, d, pd, 1u);
+    uint32_t mr = dup ? 0u : rmask;
+    while (__ballot(mr != 0u)) {
+        const bool actr = mr != 0u;
+        const uint32_t i = actr ? (uint32_t)__builtin_ctz(mr) : 0u;
+        mr &= mr - 1u;
+        const uint32_t rdoc = L.da[s + i], rsym = L.fl[s + i] & F_SYM;
+        uint32_t mg = actr ? gmask : 0u;
+        while (__ballot(mg != 0u)) {
+            const bool actg = mg != 0u;
+            const uint32_t j = actg ? (uint32_t)__builtin_ctz(mg) : 0u;
+            mg &= mg - 1u;
+            const uint32_t gdoc = L.da[s + j];
+            const uint32_t t = EBWT ? iupac_match(rsym, L.fl[s + j] & F_SYM) : 1u;
+            nupd += emit(qu, a, actg && t, rdoc, gdoc, 1u);
+        }
     }
     return nupd;
 }
@@ -261,8 +179,8 @@ __device__ __forceinline__ uint32_t cluster_group(TileLds &L, UpdQueue &qu, cons
 // General routine, one lane per cluster [s, s+len) staged in LDS (len <= SMALL_MAX), any mix of
 // repeated documents.  For every read (first occurrence) and every genome (first occurrence)
 // the counts / 16-bin histograms are rebuilt by walking the cluster.  Quadratic, rare.
-template <int EBWT>
-__device__ __forceinline__ uint32_t cluster_general(TileLds &L, UpdQueue &qu, const ScanArgs &a, bool on, uint32_t s, uint32_t len)
+template <int EBWT, typename LDS>
+__device__ __forceinline__ uint32_t cluster_general(LDS &L, UpdQueue &qu, const ScanArgs &a, bool on, uint32_t s, uint32_t len)
 {
     const uint32_t e = on ? s + len : s;
     uint32_t nupd = 0;
@@ -303,205 +221,286 @@ __device__ __forceinline__ uint32_t cluster_general(TileLds &L, UpdQueue &qu, co
     return nupd;
 }
 
-template <int EBWT>
-__device__ __forceinline__ void phase_b(TileLds &L, const ScanArgs &a)
+// all clusters filed in the wave's list; returns the number of table cells incremented (per lane)
+template <int EBWT, typename LDS>
+__device__ __forceinline__ uint32_t score_lists(LDS &L, const ScanArgs &a, uint32_t nA)
 {
-    const uint32_t wave = threadIdx.x >> 6;
-    UpdQueue qu; qu.qr = L.q_read[wave]; qu.qg = L.q_gen[wave]; qu.n = 0;
-    uint32_t nupd = 0;
-    const uint32_t nA = L.nA, nB = L.nB, nC = L.nC;
-    for (uint32_t k0 = wave * 16u; k0 < nA; k0 += NWAVES * 16u) nupd += cluster_group<EBWT, 4>(L, qu, a, L.listA, nA, k0);
-    for (uint32_t k0 = wave * 8u; k0 < nB; k0 += NWAVES * 8u) nupd += cluster_group<EBWT, 8>(L, qu, a, L.listB, nB, k0);
-    for (uint32_t k0 = wave * 4u; k0 < nC; k0 += NWAVES * 4u) nupd += cluster_group<EBWT, 16>(L, qu, a, L.listC, nC, k0);
-    __syncthreads();                              // clusters with repeated documents are now in list D
-    const uint32_t nD = L.nD;
-    for (uint32_t k0 = wave * 64u; k0 < nD; k0 += WGSZ) {
+    UpdQueue qu; qu.qr = L.q_read; qu.qg = L.q_gen; qu.n = 0;
+    uint32_t nupd = 0, nD = 0;
+    for (uint32_t k0 = 0; k0 < nA; k0 += 64u) nupd += cluster_pairs<EBWT>(L, qu, a, L.listA, nA, k0, nD);
+    for (uint32_t k0 = 0; k0 < nD; k0 += 64u) {
         const uint32_t k = k0 + lane_id();
         const uint32_t item = L.listD[k < nD ? k : 0u];
         nupd += cluster_general<EBWT>(L, qu, a, k < nD, item & 0xFFFu, (item >> 12) + 1u);
     }
     drain(qu, a);
-#pragma unroll
-    for (int d = 32; d > 0; d >>= 1) nupd += __shfl_xor(nupd, d);
-    if (lane_id() == 0 && nupd) atomicAdd(&L.upd, nupd);
+    return nupd;
 }
 
-__device__ __forceinline__ void lds_reset(TileLds &L)
+// ---- window context, lane = 64-bit mask word (words 0..7 owned, word 8 = read-ahead) --------
+// Which heads open an accepted cluster.  Segments wholly inside a word are decided by
+// carry-ripple arithmetic on that word's masks; the segment headed at a word's LAST head may
+// run into later words: its end and its read/genome content come from the words after it,
+// found with bit-scans on the wave-wide "word has a head" ballot.
+struct WinCtx {
+    uint64_t h, r, g;   // masks of this lane's word
+    uint64_t ah;        // heads of accepted, owned clusters that close inside window + read-ahead
+    uint32_t e_suf;     // window position where the segment of the word's last head ends (NONE32: open)
+};
+
+__device__ __forceinline__ WinCtx window_context(uint64_t h, uint64_t r, uint64_t g, uint64_t own_lim)
 {
-    if (threadIdx.x == 0) { L.nA = 0; L.nB = 0; L.nC = 0; L.nD = 0; L.cnt = 0; L.upd = 0; L.maxlen = 0; }
+    const uint32_t lane = lane_id();
+    WinCtx c;
+    c.h = h; c.r = r; c.g = g;
+    const bool has_h = h != 0ull;
+    const uint64_t HW = __ballot(has_h), RW = __ballot(r != 0ull), GW = __ballot(g != 0ull);
+    const uint32_t fh = has_h ? (uint32_t)__builtin_ctzll(h) : 64u;
+    const uint32_t lh = has_h ? 63u - (uint32_t)__clzll((long long)h) : 0u;
+    const uint64_t lowm = fh >= 64u ? ~0ull : ((1ull << fh) - 1ull);
+    const uint32_t pre_r = (r & lowm) != 0ull, pre_g = (g & lowm) != 0ull;       // headless: whole word
+    const uint64_t him = has_h ? (~0ull << lh) : 0ull;
+    const uint32_t suf_r = (r & him) != 0ull, suf_g = (g & him) != 0ull;
+    const uint64_t gt = (lane == 63u) ? 0ull : (~0ull << (lane + 1u));
+    const uint64_t above = HW & gt;
+    const bool has_next = above != 0ull;
+    const uint32_t wn = has_next ? (uint32_t)__builtin_ctzll(above) : 64u;
+    const uint64_t between = gt & (wn >= 64u ? ~0ull : ((1ull << wn) - 1ull));   // headless words after this one
+    const uint32_t mid_r = (RW & between) != 0ull, mid_g = (GW & between) != 0ull;
+    const int src = has_next ? (int)wn : (int)lane;
+    const uint32_t n_r = __shfl(pre_r, src), n_g = __shfl(pre_g, src), n_fh = __shfl(fh, src);
+    c.e_suf = has_next ? wn * 64u + n_fh : NONE32;
+    const uint64_t acc_suf = (has_next && (suf_r | mid_r | n_r) && (suf_g | mid_g | n_g)) ? 1ull : 0ull;
+    // "segment contains a read / a genome", gathered onto the segment's head bit: in
+    // bit-reversed order a head is the TOP of its segment, and adding the seeds to the
+    // "may receive from below" mask ripples a carry through each segment up to its head.
+    const uint64_t Hr = brev64(h), Mr = ~(Hr << 1);
+    uint64_t Xr = brev64(r), Y = (Xr << 1) & Mr;
+    const uint64_t RH = (Xr | (((Mr + Y) ^ Mr) & Mr) | Y) & Hr;
+    Xr = brev64(g); Y = (Xr << 1) & Mr;
+    const uint64_t GH = (Xr | (((Mr + Y) ^ Mr) & Mr) | Y) & Hr;
+    uint64_t ah = brev64(RH & GH);
+    ah = (ah & ~(1ull << lh)) | (acc_suf << lh);                  // last head: decided with the words after
+    const uint64_t wlo = (uint64_t)lane * 64u;                     // ownership: window part owned by this shard
+    ah &= own_lim >= wlo + 64u ? ~0ull : (own_lim <= wlo ? 0ull : ((1ull << (own_lim - wlo)) - 1ull));
+    c.ah = has_h ? ah : 0ull;
+    return c;
 }
 
-// ---- tile loads: 2 x (16 B lcp + 16 B da + 4 B ebwt) per lane, fully coalesced; kept in
-// registers so that the NEXT tile's loads are in flight while the current tile is processed
-constexpr int LOAD_K = TILE / (WGSZ * 4);
-struct TileRegs { uint32_t lv[LOAD_K][4], dv[LOAD_K][4], bv[LOAD_K]; };
+// ---- window loads: lane l holds positions [8l, 8l+8) of the window (2 x 16 B lcp, 2 x 16 B da,
+// 8 B ebwt) and position WIN + l of the read-ahead (lanes < HALO) ------------------------------
+struct WinRegs { uint32_t lv[8], dv[8], bv[2], hl, hd, hb; };
 
 template <int EBWT>
-__device__ __forceinline__ void tile_load(TileRegs &t, const ScanArgs &a, uint64_t tile_lo)
+__device__ __forceinline__ void window_load(WinRegs &t, const ScanArgs &a, uint64_t lo)
 {
+    const uint32_t lane = lane_id();
+    const uint64_t g = lo + 8u * lane;
+    t.bv[0] = 0u; t.bv[1] = 0u;
+    if (g + 8u <= a.n_avail) {
+        const uint4 l0 = *reinterpret_cast<const uint4 *>(a.lcp + g), l1 = *reinterpret_cast<const uint4 *>(a.lcp + g + 4);
+        const uint4 d0 = *reinterpret_cast<const uint4 *>(a.da + g), d1 = *reinterpret_cast<const uint4 *>(a.da + g + 4);
+        t.lv[0] = l0.x; t.lv[1] = l0.y; t.lv[2] = l0.z; t.lv[3] = l0.w; t.lv[4] = l1.x; t.lv[5] = l1.y; t.lv[6] = l1.z; t.lv[7] = l1.w;
+        t.dv[0] = d0.x; t.dv[1] = d0.y; t.dv[2] = d0.z; t.dv[3] = d0.w; t.dv[4] = d1.x; t.dv[5] = d1.y; t.dv[6] = d1.z; t.dv[7] = d1.w;
+        if (EBWT) { const uint2 b = *reinterpret_cast<const uint2 *>(a.ebwt + g); t.bv[0] = b.x; t.bv[1] = b.y; }
+    } else {
+#pragma unroll 1
+        for (int j = 0; j < 8; ++j) {
+            const bool ok = g + j < a.n_avail;
+            const uint32_t l = ok ? a.lcp[g + j] : 0u, d = ok ? a.da[g + j] : 0u;
+            const uint32_t b = (EBWT && ok) ? a.ebwt[g + j] : 0u;
 #pragma unroll
-    for (int k = 0; k < LOAD_K; ++k) {
-        const uint64_t g = tile_lo + (uint32_t)k * (WGSZ * 4) + threadIdx.x * 4u;
-        t.bv[k] = 0u;
-        if (g + 4u <= a.n_avail) {
-            const uint4 l4 = *reinterpret_cast<const uint4 *>(a.lcp + g);
-            const uint4 d4 = *reinterpret_cast<const uint4 *>(a.da + g);
-            t.lv[k][0] = l4.x; t.lv[k][1] = l4.y; t.lv[k][2] = l4.z; t.lv[k][3] = l4.w;
-            t.dv[k][0] = d4.x; t.dv[k][1] = d4.y; t.dv[k][2] = d4.z; t.dv[k][3] = d4.w;
-            if (EBWT) t.bv[k] = *reinterpret_cast<const uint32_t *>(a.ebwt + g);
-        } else {
-#pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                const bool ok = g + j < a.n_avail;
-                t.lv[k][j] = ok ? a.lcp[g + j] : 0u;
-                t.dv[k][j] = ok ? a.da[g + j] : 0u;
-                if (EBWT && ok) t.bv[k] |= (uint32_t)a.ebwt[g + j] << (8 * j);
-            }
+            for (int k = 0; k < 8; ++k) if (k == j) { t.lv[k] = l; t.dv[k] = d; }
+            if (j < 4) t.bv[0] |= b << (8 * j); else t.bv[1] |= b << (8 * (j - 4));
         }
     }
+    const uint64_t hp = lo + WIN + lane;
+    const bool hok = lane < HALO && hp < a.n_avail;
+    t.hl = hok ? a.lcp[hp] : 0u;
+    t.hd = hok ? a.da[hp] : 0u;
+    t.hb = (EBWT && hok) ? a.ebwt[hp] : 0u;
 }
 
-template <int EBWT>
-__device__ __forceinline__ void tile_stage(TileLds &L, const TileRegs &t, const ScanArgs &a, uint64_t tile_lo)
+__device__ __forceinline__ uint32_t make_flag(int ebwt, bool valid, uint32_t l, uint32_t d, uint32_t b, const ScanArgs &a)
 {
-#pragma unroll
-    for (int k = 0; k < LOAD_K; ++k) {
-        const uint32_t idx = (uint32_t)k * (WGSZ * 4) + threadIdx.x * 4u;
-        const uint64_t g = tile_lo + idx;
-        uint32_t fw = 0u;
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            uint32_t f = EBWT ? sym_index((t.bv[k] >> (8 * j)) & 255u) : 0u;
-            if (g + j >= a.n_avail) f = F_HEAD;                       // padding closes runs
-            else {
-                if (t.lv[k][j] < a.alpha) f |= F_HEAD;
-                f |= (t.dv[k][j] < a.n_reads) ? F_READ : F_GEN;
-            }
-            fw |= f << (8 * j);
-        }
-        *reinterpret_cast<uint4 *>(&L.da[idx]) = make_uint4(t.dv[k][0], t.dv[k][1], t.dv[k][2], t.dv[k][3]);
-        *reinterpret_cast<uint32_t *>(&L.fl[idx]) = fw;
-    }
+    uint32_t f = ebwt ? sym_index(b) : 0u;
+    if (!valid) return F_HEAD;                                      // padding closes runs
+    if (l < a.alpha) f |= F_HEAD;
+    f |= (d < a.n_reads) ? F_READ : F_GEN;
+    return f;
 }
 
 // =========================================================================================
-// k_tile: the streaming scan.  Persistent 512-thread workgroups walk the 4096-position tiles
-// with stride gridDim.x; the next tile's loads are issued before the current one is processed.
+// k_scan: the streaming scan.  Every wave is an independent worker over windows of WIN
+// positions (stride = number of waves in the grid); no workgroup barrier anywhere.
+// MODE: 0 detect + score, 1 count clusters per window, 2 emit cluster records in order.
 // =========================================================================================
 template <int EBWT, int MODE>
-__global__ __launch_bounds__(WGSZ, 4) void k_tile(ScanArgs a)
+__global__ __launch_bounds__(SCAN_WG) void k_scan(ScanArgs a)
 {
-    __shared__ TileLds L;
-    const uint32_t tid = threadIdx.x;
-    uint32_t tile = blockIdx.x;
-    if (tile >= a.n_tiles) return;
-    TileRegs regs;
-    tile_load<EBWT>(regs, a, (uint64_t)tile * TILE);
+    __shared__ WaveLds<WPOS> lds[SCAN_WG / 64];
+    const uint32_t lane = lane_id(), wave = threadIdx.x >> 6;
+    WaveLds<WPOS> &L = lds[wave];
+    const uint32_t n_win = a.n_tiles, stride = gridDim.x * (SCAN_WG / 64);
+    uint32_t win = blockIdx.x * (SCAN_WG / 64) + wave;
+    if (win >= n_win) return;
+    WinRegs regs;
+    window_load<EBWT>(regs, a, (uint64_t)win * WIN);
+    uint32_t acc_n = 0, acc_max = 0, acc_upd = 0;          // per-lane partial counters, reduced once at the end
+    const uint64_t lt = (1ull << lane) - 1ull;
     for (;;) {
-        const uint64_t tile_lo = (uint64_t)tile * TILE;
-        const uint64_t own_lim = a.n_own > tile_lo ? a.n_own - tile_lo : 0ull;
-        lds_reset(L);
-        tile_stage<EBWT>(L, regs, a, tile_lo);
-        const uint32_t next = tile + gridDim.x;
-        if (next < a.n_tiles && a.ablate != 8) tile_load<EBWT>(regs, a, (uint64_t)next * TILE);
-        __syncthreads();
+        const uint64_t lo = (uint64_t)win * WIN;
+        const uint64_t own_lim = a.n_own > lo ? (a.n_own - lo < WIN ? a.n_own - lo : (uint64_t)WIN) : 0ull;
+        // ---- stage the window in LDS; head / read / genome bits of the lane's 8 positions ----
+        {
+            uint32_t hb = 0, rb = 0, gb = 0, fw[2] = {0u, 0u};
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                const uint32_t f = make_flag(EBWT, lo + 8u * lane + j < a.n_avail, regs.lv[j], regs.dv[j],
+                                             (regs.bv[j >> 2] >> (8 * (j & 3))) & 255u, a);
+                hb |= ((f >> 4) & 1u) << j; rb |= ((f >> 5) & 1u) << j; gb |= ((f >> 6) & 1u) << j;
+                fw[j >> 2] |= f << (8 * (j & 3));
+            }
+            *reinterpret_cast<uint4 *>(&L.da[8u * lane]) = make_uint4(regs.dv[0], regs.dv[1], regs.dv[2], regs.dv[3]);
+            *reinterpret_cast<uint4 *>(&L.da[8u * lane + 4u]) = make_uint4(regs.dv[4], regs.dv[5], regs.dv[6], regs.dv[7]);
+            *reinterpret_cast<uint2 *>(&L.fl[8u * lane]) = make_uint2(fw[0], fw[1]);
+            L.hb[lane] = (uint8_t)hb; L.rb[lane] = (uint8_t)rb; L.gb[lane] = (uint8_t)gb;
+        }
+        const uint32_t hf = lane < HALO ? make_flag(EBWT, lo + WIN + lane < a.n_avail, regs.hl, regs.hd, regs.hb, a) : 0u;
+        if (lane < HALO) { L.da[WIN + lane] = regs.hd; L.fl[WIN + lane] = (uint8_t)hf; }
+        const uint64_t H8 = __ballot((hf & F_HEAD) != 0u), R8 = __ballot((hf & F_READ) != 0u), G8 = __ballot((hf & F_GEN) != 0u);
+        if (lane < 3u) L.rb[64u + lane] = (uint8_t)(R8 >> (8u * lane));     // read bits of the read-ahead
+        // ---- the next window's loads go out now and land while this one is processed ----------
+        const uint32_t next = win + stride;
+        if (next < n_win && a.ablate != 8) window_load<EBWT>(regs, a, (uint64_t)next * WIN);
         if (a.ablate != 1) {
-        build_masks(L);
-        __syncthreads();
-        if (tid < 64u) {
-            // ---- phase A and the tile summary: wave 0, lane = mask word ---------------------
-            const TileCtx c = tile_context(L, own_lim);
-            if (a.ablate != 3) phase_a<MODE>(L, c, tile_lo, a);
-            const uint64_t hw = __ballot(c.h != 0ull);
+        // ---- masks with lane = word: bytes of 8 lanes make one 64-bit word ---------------------
+        uint64_t h = 0ull, r = 0ull, g = 0ull;
+        if (lane < WIN / 64) {
+            h = *reinterpret_cast<const uint64_t *>(&L.hb[8u * lane]);
+            r = *reinterpret_cast<const uint64_t *>(&L.rb[8u * lane]);
+            g = *reinterpret_cast<const uint64_t *>(&L.gb[8u * lane]);
+        } else if (lane == WIN / 64) { h = H8; r = R8; g = G8; }
+        const WinCtx c = window_context(h, r, g, own_lim);
+
+        // ---- window summary for the segment that is still open after the read-ahead ------------
+        {
+            const uint64_t oh = lane < WIN / 64 ? c.h : 0ull, orr = lane < WIN / 64 ? c.r : 0ull, og = lane < WIN / 64 ? c.g : 0ull;
+            const uint64_t hw = __ballot(oh != 0ull);
             TileSummary sm;
             sm.first_head = NONE32; sm.last_head = NONE32; sm.pre = 0; sm.suf = 0;
             uint32_t fw = 64u, lw = 0u;
             if (hw) {
                 fw = (uint32_t)__builtin_ctzll(hw);
                 lw = 63u - (uint32_t)__clzll((long long)hw);
-                const uint64_t hf = rl64(c.h, fw), hl = rl64(c.h, lw);
-                sm.first_head = fw * 64u + (uint32_t)__builtin_ctzll(hf);
-                sm.last_head = lw * 64u + 63u - (uint32_t)__clzll((long long)hl);
+                const uint64_t hf0 = rl64(oh, fw), hl0 = rl64(oh, lw);
+                sm.first_head = fw * 64u + (uint32_t)__builtin_ctzll(hf0);
+                sm.last_head = lw * 64u + 63u - (uint32_t)__clzll((long long)hl0);
             }
-            // prefix [0, first_head) (whole tile when there is no head); suffix [last_head, TILE)
-            uint64_t pr = c.r, pg = c.g, sr = 0ull, sg = 0ull;
+            uint64_t pr = orr, pg = og, sr = 0ull, sg = 0ull;       // prefix [0, first_head); suffix [last_head, WIN)
             if (hw) {
                 const uint32_t fb = sm.first_head & 63u, lb = sm.last_head & 63u;
                 const uint64_t below = fb ? (~0ull >> (64u - fb)) : 0ull;
                 const uint64_t from = ~0ull << lb;
-                pr = (tid < fw) ? c.r : (tid == fw ? (c.r & below) : 0ull);
-                pg = (tid < fw) ? c.g : (tid == fw ? (c.g & below) : 0ull);
-                sr = (tid > lw) ? c.r : (tid == lw ? (c.r & from) : 0ull);
-                sg = (tid > lw) ? c.g : (tid == lw ? (c.g & from) : 0ull);
+                pr = (lane < fw) ? orr : (lane == fw ? (orr & below) : 0ull);
+                pg = (lane < fw) ? og : (lane == fw ? (og & below) : 0ull);
+                sr = (lane > lw) ? orr : (lane == lw ? (orr & from) : 0ull);
+                sg = (lane > lw) ? og : (lane == lw ? (og & from) : 0ull);
             }
             const uint32_t pre = (__ballot(pr != 0ull) ? 1u : 0u) | (__ballot(pg != 0ull) ? 2u : 0u);
             const uint32_t suf = (__ballot(sr != 0ull) ? 1u : 0u) | (__ballot(sg != 0ull) ? 2u : 0u);
-            if (tid == 0) { sm.pre = pre; sm.suf = suf; a.summ[tile] = sm; }
-            // a run closed by padding instead of data while more data exists beyond the halo:
-            // the last data head of the tile is owned and nothing but padding follows it
-            if (!a.eof && tile_lo + TILE > a.n_avail) {
-                const uint64_t lim = a.n_avail - tile_lo, wl = (uint64_t)tid * 64u;
+            if (lane == 0 && MODE != 2) { sm.pre = pre; sm.suf = suf; a.summ[win] = sm; }
+            // a run closed by padding instead of data while more data exists beyond the shard's
+            // halo: the last data head in sight is owned and nothing but padding follows it
+            if (!a.eof && lo + WPOS > a.n_avail) {
+                const uint64_t lim = a.n_avail - lo, wl = (uint64_t)lane * 64u;
                 const uint64_t dh = wl >= lim ? 0ull : (wl + 64u <= lim ? c.h : (c.h & ((1ull << (lim - wl)) - 1ull)));
                 const uint64_t dw = __ballot(dh != 0ull);
                 if (dw) {
                     const uint32_t lw2 = 63u - (uint32_t)__clzll((long long)dw);
-                    const uint64_t hl = rl64(dh, lw2);
-                    const uint64_t sstar = (uint64_t)lw2 * 64u + 63u - (uint32_t)__clzll((long long)hl);
-                    if (tid == 0 && sstar < own_lim) atomicOr(&a.stats->flags, LIME_FLAG_HALO);
+                    const uint64_t hl2 = rl64(dh, lw2);
+                    const uint64_t sstar = (uint64_t)lw2 * 64u + 63u - (uint32_t)__clzll((long long)hl2);
+                    if (lane == 0 && sstar < own_lim) atomicOr(&a.stats->flags, LIME_FLAG_HALO);
                 }
             }
         }
-        __syncthreads();
-        if (MODE == 0 && a.ablate != 4 && a.ablate != 3) { phase_b<EBWT>(L, a); __syncthreads(); }
-        if (tid == 0) {
-            if (MODE == 1) a.tile_cnt[tile] = L.cnt;
-            if (MODE != 2 && L.cnt) atomicAdd(&a.stats->n_clusters, (unsigned long long)L.cnt);
-            if (MODE != 2 && L.maxlen) atomicMax(&a.stats->max_len, L.maxlen);
-            if (MODE == 0 && L.upd) atomicAdd(&a.stats->n_updates, (unsigned long long)L.upd);
-        }
-        if (MODE == 2) {
-            // ordered emission: rank of each accepted head inside the tile
-            if (tid < 64u) {
-                uint32_t cN = (uint32_t)__popcll(L.A[tid]);
-                uint32_t x = cN;
+
+        // ---- phase A: lane l walks the accepted heads among ITS 8 positions ---------------------
+        if (a.ablate != 3) {
+        const uint32_t w = lane >> 3, o = lane & 7u;
+        const uint64_t AHw = shfl64(c.ah, (int)w), Hw = shfl64(c.h, (int)w);
+        const uint32_t e_suf = __shfl(c.e_suf, (int)w);
+        uint32_t ahb = (uint32_t)(AHw >> (8u * o)) & 255u;
+        const uint32_t my_n = (uint32_t)__popc(ahb);
+        acc_n += my_n;
+        uint32_t nA = 0, rank = 0, win_cnt = 0;
+        if (MODE != 0) {                                            // ordered output needs ranks
+            uint32_t x = my_n;
 #pragma unroll
-                for (int d = 1; d < 64; d <<= 1) { uint32_t y = __shfl_up(x, d); if ((int)tid >= d) x += y; }
-                L.apre[tid] = x - cN;
+            for (int d = 1; d < 64; d <<= 1) { const uint32_t y = __shfl_up(x, d); if ((int)lane >= d) x += y; }
+            rank = x - my_n; win_cnt = rl32(x, 63);
+            if (MODE == 1 && lane == 0) a.tile_cnt[win] = win_cnt;
+        }
+        while (__ballot(ahb != 0u)) {
+            const bool act = ahb != 0u;
+            const uint32_t b = act ? (uint32_t)__builtin_ctz(ahb) : 0u;
+            ahb &= ahb - 1u;
+            const uint32_t bit = 8u * o + b, p = 64u * w + bit;
+            const uint64_t ha = (bit == 63u) ? 0ull : (Hw & (~0ull << (bit + 1u)));
+            const uint32_t e = ha ? 64u * w + (uint32_t)__builtin_ctzll(ha) : e_suf;
+            const uint32_t len = act ? e - p : 0u;
+            acc_max = len > acc_max ? len : acc_max;
+            if (MODE == 2 && act) {
+                lime_cluster_t rec; rec.pStart = a.pos_base + lo + p; rec.len = len;
+                a.out[a.tile_off[win] + rank] = rec; ++rank;
             }
-            __syncthreads();
-            const uint64_t base = a.tile_off[tile];
-            const uint32_t wave = tid >> 6, lane = tid & 63u;
-            for (uint32_t j = 0; j < WPW; ++j) {
-                const uint32_t w = wave * WPW + j;
-                const uint64_t am = L.A[w];
-                if (!((am >> lane) & 1ull)) continue;
-                const uint32_t s = w * 64u + lane;
-                const uint64_t ha = (lane == 63u) ? 0ull : (L.H[w] & (~0ull << (lane + 1u)));
-                const uint32_t e = ha ? w * 64u + (uint32_t)__builtin_ctzll(ha) : L.esuf[w];
-                const uint32_t rank = L.apre[w] + (uint32_t)__popcll(am & ((1ull << lane) - 1ull));
-                lime_cluster_t rec; rec.pStart = a.pos_base + tile_lo + s; rec.len = e - s;
-                a.out[base + rank] = rec;
-            }
-            if (tid == 0) {
-                const CrossRec cr = a.cross[tile];
-                if (cr.len) {
-                    lime_cluster_t rec; rec.pStart = a.pos_base + cr.start; rec.len = cr.len;
-                    a.out[base + L.cnt] = rec;
+            if (MODE == 0) {
+                const bool cA = act && len <= SMALL_MAX, cD = act && len > SMALL_MAX;
+                const uint16_t item = (uint16_t)(p | ((len - 1u) << 12));
+                const uint64_t mA = __ballot(cA);
+                if (cA) L.listA[nA + (uint32_t)__popcll(mA & lt)] = item;
+                nA += (uint32_t)__popcll(mA);
+                if (__ballot(cD)) {                               // rare: too long for the in-window path
+                    if (cD) {
+                        if (len > LIME_MAX_CLUSTER) atomicOr(&a.stats->flags, LIME_FLAG_MAXLEN);
+                        else {
+                            const uint32_t k = atomicAdd(&a.stats->n_big, 1u);
+                            if (k < a.big_cap) { a.big[k].pStart = lo + p; a.big[k].len = len; }
+                        }
+                    }
                 }
             }
         }
+        if (MODE == 2 && lane == 0) {
+            const CrossRec cr = a.cross[win];
+            if (cr.len) {
+                lime_cluster_t rec; rec.pStart = a.pos_base + cr.start; rec.len = cr.len;
+                a.out[a.tile_off[win] + win_cnt] = rec;
+            }
         }
-        __syncthreads();
-        if (next >= a.n_tiles) break;
-        if (a.ablate == 8) tile_load<EBWT>(regs, a, (uint64_t)next * TILE);
-        tile = next;
+        // ---- phase B: score the window's clusters ------------------------------------------------
+        if (MODE == 0 && a.ablate != 4) acc_upd += score_lists<EBWT>(L, a, nA);
+        }
+        }
+        if (next >= n_win) break;
+        if (a.ablate == 8) window_load<EBWT>(regs, a, (uint64_t)next * WIN);
+        win = next;
+    }
+    if (MODE != 2) {
+        const uint32_t tn = wave_sum(acc_n), tm = wave_max(acc_max), tu = wave_sum(acc_upd);
+        if (lane == 0) {
+            if (tn) atomicAdd(&a.stats->n_clusters, (unsigned long long)tn);
+            if (tm) atomicMax(&a.stats->max_len, (unsigned long long)tm);
+            if (MODE == 0 && tu) atomicAdd(&a.stats->n_updates, (unsigned long long)tu);
+        }
     }
 }
 
 // =========================================================================================
-// k_resolve: closes the segment that leaves each tile from the summaries of the tiles after
-// it (the reference's straddle loop, ClusterLCP.cpp:246-264, and EOF closure :244-245).
-// One thread per tile.  MODE 0: push to the small / big score lists; MODE 1: record for emit.
+// k_resolve: closes the segment that is still open after a window's read-ahead, from the
+// summaries of the windows after it (the reference's straddle loop, ClusterLCP.cpp:246-264,
+// and EOF closure :244-245).  One thread per window.  Such a cluster is longer than the
+// read-ahead, hence longer than SMALL_MAX.  MODE 0: push to the big list; 1: record for emit.
 // =========================================================================================
 template <int MODE>
 __global__ __launch_bounds__(256) void k_resolve(ScanArgs a)
@@ -511,7 +510,7 @@ __global__ __launch_bounds__(256) void k_resolve(ScanArgs a)
     if (MODE == 1) { CrossRec z; z.start = 0; z.len = 0; a.cross[t] = z; }
     const TileSummary me = a.summ[t];
     if (me.last_head == NONE32) return;
-    const uint64_t s = (uint64_t)t * TILE + me.last_head;
+    const uint64_t s = (uint64_t)t * WIN + me.last_head;
     if (s >= a.n_own) return;                                   // owned by the next shard / padding
     uint32_t fl = me.suf;
     uint64_t e = a.n_avail;
@@ -519,26 +518,23 @@ __global__ __launch_bounds__(256) void k_resolve(ScanArgs a)
     for (uint32_t u = t + 1u; u < a.n_tiles; ++u) {
         const TileSummary o = a.summ[u];
         fl |= o.pre;
-        if (o.first_head != NONE32) { e = (uint64_t)u * TILE + o.first_head; closed_by_data = true; break; }
+        if (o.first_head != NONE32) { e = (uint64_t)u * WIN + o.first_head; closed_by_data = true; break; }
     }
     if (e >= a.n_avail) { e = a.n_avail; closed_by_data = false; }
+    if (e < ((uint64_t)t + 1u) * WIN + HALO) return;            // seen (and handled) inside the window's read-ahead
     if (!closed_by_data && !a.eof) { atomicOr(&a.stats->flags, LIME_FLAG_HALO); return; }
     const uint64_t len = e - s;
     if (fl != 3u || len < 2u) return;
     atomicAdd(&a.stats->n_clusters, 1ull);
     atomicMax(&a.stats->max_len, (unsigned long long)len);
+    atomicAdd(&a.stats->n_cross, 1u);
     if (MODE == 1) {
         CrossRec c; c.start = s; c.len = len; a.cross[t] = c;
         a.tile_cnt[t] += 1u;
     } else {
         if (len > LIME_MAX_CLUSTER) { atomicOr(&a.stats->flags, LIME_FLAG_MAXLEN); return; }
-        if (len > SMALL_MAX) {
-            uint32_t k = atomicAdd(&a.stats->n_big, 1u);
-            if (k < a.big_cap) { a.big[k].pStart = s; a.big[k].len = len; }
-        } else {
-            uint32_t k = atomicAdd(&a.stats->n_cross, 1u);
-            if (k < a.cross_cap) { a.small[k].pStart = s; a.small[k].len = len; }
-        }
+        const uint32_t k = atomicAdd(&a.stats->n_big, 1u);
+        if (k < a.big_cap) { a.big[k].pStart = s; a.big[k].len = len; }
     }
 }
 
@@ -572,75 +568,60 @@ __global__ __launch_bounds__(1024) void k_scan_tiles(const uint32_t *cnt, uint64
 }
 
 // =========================================================================================
-// k_score_list: scores clusters given as (pStart,len) records.  A workgroup gathers a batch of
-// LIST_BATCH clusters (each <= SMALL_MAX long) side by side into LDS, makes one work item per
-// read position and runs the same phase B as the tile kernel; longer clusters are pushed to
-// the big list.  `count_ptr` (device) or `count` gives the number of records.
+// k_score_list: scores clusters given as (pStart,len) records.  Each wave gathers 64 clusters
+// (each <= SMALL_MAX long) side by side into its LDS, files them under their length class and
+// runs the same scoring routines as the scan; longer clusters are pushed to the big list.
 // =========================================================================================
 template <int EBWT>
-__global__ __launch_bounds__(WGSZ) void k_score_list(ScanArgs a, const lime_cluster_t *list,
-                                                     const uint32_t *count_ptr, uint64_t count,
-                                                     uint32_t cap)
+__global__ __launch_bounds__(SCAN_WG) void k_score_list(ScanArgs a, const lime_cluster_t *list, uint64_t n_list)
 {
-    __shared__ TileLds L;
-    __shared__ uint32_t c_off[LIST_BATCH + 1];
-    __shared__ uint64_t c_ps[LIST_BATCH];
-    __shared__ uint32_t w_tot[LIST_BATCH / 64];
-    const uint32_t tid = threadIdx.x, lane = tid & 63u;
-    const uint64_t n_list = count_ptr ? (uint64_t)(*count_ptr < cap ? *count_ptr : cap) : count;
-    const uint64_t n_batches = (n_list + LIST_BATCH - 1) / LIST_BATCH;
-    for (uint64_t b = blockIdx.x; b < n_batches; b += gridDim.x) {
-        lds_reset(L);
-        uint32_t len32 = 0, incl = 0;
-        if (tid < LIST_BATCH) {
-            const uint64_t c = b * LIST_BATCH + tid;
-            uint64_t ps = 0, len = 0;
-            if (c < n_list) { ps = list[c].pStart; len = list[c].len; }
-            const bool bad = (len > LIME_MAX_CLUSTER) || (ps > a.n_avail) || (len > a.n_avail - ps);
-            if (bad) { atomicOr(&a.stats->flags, len > LIME_MAX_CLUSTER ? LIME_FLAG_MAXLEN : LIME_FLAG_BADCLUSTER); len = 0; }
-            if (len > SMALL_MAX) {
-                uint32_t k = atomicAdd(&a.stats->n_big, 1u);
-                if (k < a.big_cap) { a.big[k].pStart = ps; a.big[k].len = len; }
-                len = 0;
-            }
-            if (len < 2u) len = 0;                 // a 0/1-symbol cluster cannot hold a read and a genome
-            len32 = (uint32_t)len;
-            incl = len32;
+    __shared__ WaveLds<64 * SMALL_MAX> lds[SCAN_WG / 64];
+    __shared__ uint32_t c_off[SCAN_WG / 64][65];
+    const uint32_t lane = lane_id(), wave = threadIdx.x >> 6;
+    WaveLds<64 * SMALL_MAX> &L = lds[wave];
+    uint32_t *off = c_off[wave];
+    const uint64_t n_batches = (n_list + 63u) / 64u, stride = (uint64_t)gridDim.x * (SCAN_WG / 64);
+    const uint64_t lt = (1ull << lane) - 1ull;
+    uint32_t acc_upd = 0;
+    for (uint64_t b = (uint64_t)blockIdx.x * (SCAN_WG / 64) + wave; b < n_batches; b += stride) {
+        const uint64_t c = b * 64u + lane;
+        uint64_t ps = 0, len = 0;
+        if (c < n_list) { ps = list[c].pStart; len = list[c].len; }
+        const bool bad = (len > LIME_MAX_CLUSTER) || (ps > a.n_avail) || (len > a.n_avail - ps);
+        if (bad) { atomicOr(&a.stats->flags, len > LIME_MAX_CLUSTER ? LIME_FLAG_MAXLEN : LIME_FLAG_BADCLUSTER); len = 0; }
+        if (len > SMALL_MAX) {
+            const uint32_t k = atomicAdd(&a.stats->n_big, 1u);
+            if (k < a.big_cap) { a.big[k].pStart = ps; a.big[k].len = len; }
+            len = 0;
+        }
+        if (len < 2u) len = 0;                     // a 0/1-symbol cluster cannot hold a read and a genome
+        const uint32_t len32 = (uint32_t)len;
+        uint32_t incl = len32;
 #pragma unroll
-            for (int d = 1; d < 64; d <<= 1) { uint32_t y = __shfl_up(incl, d); if ((int)lane >= d) incl += y; }
-            if (lane == 63u) w_tot[tid >> 6] = incl;
-            c_ps[tid] = ps;
-        }
-        __syncthreads();
-        if (tid < LIST_BATCH) {
-            uint32_t pre = 0;
-            for (uint32_t k = 0; k < (tid >> 6); ++k) pre += w_tot[k];
-            c_off[tid] = pre + incl - len32;
-            if (tid == LIST_BATCH - 1) c_off[LIST_BATCH] = pre + incl;
-        }
-        __syncthreads();
-        const uint32_t total = c_off[LIST_BATCH];
-        for (uint32_t i = tid; i < total; i += WGSZ) {
-            uint32_t lo = 0, hi = LIST_BATCH - 1;       // last cluster with c_off <= i
-            while (lo < hi) { uint32_t mid = (lo + hi + 1u) >> 1; if (c_off[mid] <= i) lo = mid; else hi = mid - 1u; }
-            const uint64_t g = c_ps[lo] + (i - c_off[lo]);
+        for (int d = 1; d < 64; d <<= 1) { const uint32_t y = __shfl_up(incl, d); if ((int)lane >= d) incl += y; }
+        const uint32_t my_off = incl - len32, total = rl32(incl, 63);
+        off[lane] = my_off;
+        if (lane == 63u) off[64] = total;
+        for (uint32_t i0 = 0; i0 < total; i0 += 64u) {
+            const uint32_t i = i0 + lane < total ? i0 + lane : total - 1u;
+            uint32_t lo = 0, hi = 63u;                // last cluster with off <= i
+            while (lo < hi) { const uint32_t mid = (lo + hi + 1u) >> 1; if (off[mid] <= i) lo = mid; else hi = mid - 1u; }
+            const uint64_t g = shfl64(ps, (int)lo) + (i - off[lo]);
             const uint32_t d = a.da[g];
             uint32_t f = EBWT ? sym_index(a.ebwt[g]) : 0u;
             f |= (d < a.n_reads) ? F_READ : F_GEN;
             L.da[i] = d; L.fl[i] = (uint8_t)f;
+            const uint64_t rm = __ballot(d < a.n_reads && i0 + lane < total);
+            if (lane == 0) *reinterpret_cast<uint64_t *>(&L.rb[i0 >> 3]) = rm;
         }
-        if (tid < LIST_BATCH && len32) {
-            const uint16_t item = (uint16_t)(c_off[tid] | ((len32 - 1u) << 12));
-            if (len32 <= 4u) L.listA[atomicAdd(&L.nA, 1u)] = item;
-            else if (len32 <= 8u) L.listB[atomicAdd(&L.nB, 1u)] = item;
-            else L.listC[atomicAdd(&L.nC, 1u)] = item;
-        }
-        __syncthreads();
-        phase_b<EBWT>(L, a);
-        __syncthreads();
-        if (tid == 0 && L.upd) atomicAdd(&a.stats->n_updates, (unsigned long long)L.upd);
-        __syncthreads();
+        const bool cA = len32 >= 2u;
+        const uint16_t item = (uint16_t)(my_off | ((len32 - 1u) << 12));
+        const uint64_t mA = __ballot(cA);
+        if (cA) L.listA[(uint32_t)__popcll(mA & lt)] = item;
+        acc_upd += score_lists<EBWT>(L, a, (uint32_t)__popcll(mA));
     }
+    const uint32_t tu = wave_sum(acc_upd);
+    if (lane == 0 && tu) atomicAdd(&a.stats->n_updates, (unsigned long long)tu);
 }
 
 // =========================================================================================
@@ -798,20 +779,32 @@ __global__ void k_fill_u32(uint32_t *p, size_t n, uint32_t v)
 }
 
 // ---- launch wrappers (host) ------------------------------------------------------------
-static inline uint32_t tile_grid(uint32_t n_tiles, uint32_t max_blocks)
+template <typename K> static uint32_t resident_blocks(K kernel, int block)
 {
-    uint32_t g = n_tiles < max_blocks ? n_tiles : max_blocks;
-    return g ? g : 1u;
+    int per_cu = 0, dev = 0;
+    hipDeviceProp_t prop;
+    if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&prop, dev) != hipSuccess) return 1024u;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kernel, block, 0) != hipSuccess || per_cu < 1) per_cu = 2;
+    return (uint32_t)per_cu * (uint32_t)prop.multiProcessorCount;
+}
+
+template <typename K> static void launch_scan_kernel(K kernel, const ScanArgs &a, uint32_t max_blocks, hipStream_t st)
+{
+    static uint32_t resident = 0;                 // per instantiation: blocks that fit the device at once
+    if (!resident) resident = resident_blocks(kernel, SCAN_WG);
+    uint32_t want = (a.n_tiles + SCAN_WG / 64 - 1) / (SCAN_WG / 64);
+    uint32_t cap = max_blocks ? max_blocks : resident;
+    uint32_t grid = want < cap ? want : cap;
+    hipLaunchKernelGGL(kernel, dim3(grid ? grid : 1u), dim3(SCAN_WG), 0, st, a);
 }
 
 void launch_tile(int ebwt, int mode, const ScanArgs &a, uint32_t max_blocks, hipStream_t st)
 {
-    const dim3 grid(tile_grid(a.n_tiles, max_blocks)), block(WGSZ);
     if (mode == 0) {
-        if (ebwt) hipLaunchKernelGGL((k_tile<1, 0>), grid, block, 0, st, a);
-        else      hipLaunchKernelGGL((k_tile<0, 0>), grid, block, 0, st, a);
-    } else if (mode == 1) hipLaunchKernelGGL((k_tile<0, 1>), grid, block, 0, st, a);
-    else                  hipLaunchKernelGGL((k_tile<0, 2>), grid, block, 0, st, a);
+        if (ebwt) launch_scan_kernel(k_scan<1, 0>, a, max_blocks, st);
+        else      launch_scan_kernel(k_scan<0, 0>, a, max_blocks, st);
+    } else if (mode == 1) launch_scan_kernel(k_scan<0, 1>, a, max_blocks, st);
+    else                  launch_scan_kernel(k_scan<0, 2>, a, max_blocks, st);
 }
 
 void launch_resolve(int mode, const ScanArgs &a, hipStream_t st)
@@ -826,11 +819,10 @@ void launch_scan_tiles(const uint32_t *cnt, uint64_t *off, uint32_t n, unsigned 
     hipLaunchKernelGGL(k_scan_tiles, dim3(1), dim3(1024), 0, st, cnt, off, n, total);
 }
 
-void launch_score_list(int ebwt, const ScanArgs &a, const lime_cluster_t *list, const uint32_t *count_ptr,
-                       uint64_t count, uint32_t cap, uint32_t blocks, hipStream_t st)
+void launch_score_list(int ebwt, const ScanArgs &a, const lime_cluster_t *list, uint64_t count, uint32_t blocks, hipStream_t st)
 {
-    if (ebwt) hipLaunchKernelGGL((k_score_list<1>), dim3(blocks), dim3(WGSZ), 0, st, a, list, count_ptr, count, cap);
-    else      hipLaunchKernelGGL((k_score_list<0>), dim3(blocks), dim3(WGSZ), 0, st, a, list, count_ptr, count, cap);
+    if (ebwt) hipLaunchKernelGGL((k_score_list<1>), dim3(blocks), dim3(SCAN_WG), 0, st, a, list, count);
+    else      hipLaunchKernelGGL((k_score_list<0>), dim3(blocks), dim3(SCAN_WG), 0, st, a, list, count);
 }
 
 void launch_score_big(int ebwt, const ScanArgs &a, uint32_t *scratch, hipStream_t st)
