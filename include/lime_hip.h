@@ -52,13 +52,14 @@ typedef struct {
     uint32_t n_cross;      /* clusters that crossed a tile edge (scored by the list kernel)  */
     uint32_t n_big;        /* clusters longer than the in-tile limit (scored by the big kernel) */
     uint32_t flags;        /* LIME_FLAG_* */
-    uint32_t reserved;
+    uint32_t n_med;        /* clusters of 5..16 symbols handed from the scan to the list kernel */
 } lime_stats_t;
 
 #define LIME_FLAG_MAXLEN 1u
 #define LIME_FLAG_HALO   2u
 #define LIME_FLAG_DOCID  4u
 #define LIME_FLAG_BADCLUSTER 8u
+#define LIME_FLAG_OVERFLOW 16u   /* an internal cluster list was too small (cannot happen with the default sizing) */
 
 /* ---- lifecycle ------------------------------------------------------------------------ */
 /* device < 0: keep the process's current HIP device.  Replaces the reference's

@@ -47,6 +47,7 @@ struct lime_ctx {
     // cluster lists
     lime_cluster_t *d_small = nullptr; uint32_t small_cap = 0;
     lime_cluster_t *d_big = nullptr; uint32_t big_cap = 0;
+    uint64_t *d_med = nullptr; uint32_t med_cap = 0;
     lime_cluster_t *d_out = nullptr; size_t out_cap = 0;
     uint32_t *d_big_scratch = nullptr;
     uint32_t max_blocks = 0;                // persistent grid of the scan kernel; 0 = as many workgroups as fit the device (LIME_MAX_BLOCKS)
@@ -102,7 +103,7 @@ extern "C" void lime_shutdown(lime_ctx *c)
     for (hipEvent_t e : c->ev) (void)hipEventDestroy(e);
     (void)hipFree(c->d_stats); (void)hipFree(c->d_total); (void)hipFree(c->d_summ);
     (void)hipFree(c->d_tile_cnt); (void)hipFree(c->d_tile_off); (void)hipFree(c->d_cross);
-    (void)hipFree(c->d_small); (void)hipFree(c->d_big); (void)hipFree(c->d_out);
+    (void)hipFree(c->d_small); (void)hipFree(c->d_big); (void)hipFree(c->d_med); (void)hipFree(c->d_out);
     (void)hipFree(c->d_big_scratch);
     delete c;
 }
@@ -134,6 +135,13 @@ static int ensure_scratch(lime_ctx *c, uint64_t n_avail, bool detect, bool score
         if (want_big > 0xFFFFFFF0ull) return fail(LIME_ERR_ARG, "array too long for one shard: %llu", (unsigned long long)n_avail);
         if (want_small > c->small_cap) { HIP_TRY(hipStreamSynchronize(st)); if ((rc = regrow(c->d_small, want_small))) return rc; c->small_cap = (uint32_t)want_small; }
         if (want_big > c->big_cap) { HIP_TRY(hipStreamSynchronize(st)); if ((rc = regrow(c->d_big, want_big))) return rc; c->big_cap = (uint32_t)want_big; }
+        // every cluster the scan does not score itself (5..16 symbols, or a repeated document): at most one
+        // per two positions, plus the chunk each wave keeps reserved
+        const uint64_t want_med = n_avail / 2u + 1048576u;
+        if (want_med > c->med_cap) {
+            if (want_med > 0xFFFFFFF0ull) return fail(LIME_ERR_ARG, "array too long for one shard: %llu", (unsigned long long)n_avail);
+            HIP_TRY(hipStreamSynchronize(st)); if ((rc = regrow(c->d_med, want_med))) return rc; c->med_cap = (uint32_t)want_med;
+        }
         if (!c->d_big_scratch) {
             const size_t words = (size_t)BIG_GRID * BIG_SCRATCH_WORDS;
             HIP_TRY(hipMalloc(&c->d_big_scratch, words * sizeof(uint32_t)));
@@ -168,6 +176,7 @@ static ScanArgs base_args(lime_ctx *c, const uint32_t *lcp, const uint32_t *da, 
     a.n_tiles = (uint32_t)((n_avail + WIN - 1) / WIN);
     a.sim = sim; a.summ = c->d_summ; a.stats = c->d_stats;
     a.small = c->d_small; a.cross_cap = c->small_cap; a.big = c->d_big; a.big_cap = c->big_cap;
+    a.med = c->d_med; a.med_cap = c->med_cap;
     a.tile_cnt = c->d_tile_cnt; a.tile_off = c->d_tile_off; a.cross = c->d_cross; a.out = c->d_out;
     a.ablate = c->ablate;
     return a;
@@ -176,6 +185,7 @@ static ScanArgs base_args(lime_ctx *c, const uint32_t *lcp, const uint32_t *da, 
 static int flags_to_rc(uint32_t flags)
 {
     if (flags & LIME_FLAG_BADCLUSTER) return fail(LIME_ERR_ARG, "a cluster record lies outside the arrays");
+    if (flags & LIME_FLAG_OVERFLOW) return fail(LIME_ERR_NOMEM, "internal cluster list overflow");
     if (flags & LIME_FLAG_MAXLEN) return fail(LIME_ERR_MAXLEN, "maximum cluster size is greater than %u (sizeMaxBuf)", LIME_MAX_CLUSTER);
     if (flags & LIME_FLAG_HALO) return fail(LIME_ERR_HALO, "a run owned by this shard does not close inside its halo");
     if (flags & LIME_FLAG_DOCID) return fail(LIME_ERR_DOCID, "a da value >= n_reads + n_refs was met while scoring");
@@ -234,6 +244,7 @@ extern "C" int lime_fused_dev(lime_ctx *c, const uint32_t *d_lcp, const uint32_t
     launch_tile(ebwt, 0, a, c->max_blocks, st);
     if ((rc = timing_mark(c, st))) return rc;
     launch_resolve(0, a, st);
+    launch_score_med(ebwt, a, 2048, st);
     launch_score_big(ebwt, a, c->d_big_scratch, st);
     HIP_TRY(hipGetLastError());
     return LIME_OK;

@@ -25,7 +25,7 @@ struct CrossRec { uint64_t start, len; };                          // len == 0: 
 
 struct DevStats {                            // same layout as lime_stats_t
     unsigned long long n_clusters, max_len, n_updates;
-    uint32_t n_cross, n_big, flags, reserved;
+    uint32_t n_cross, n_big, flags, n_med;
 };
 static_assert(sizeof(DevStats) == sizeof(lime_stats_t), "DevStats must mirror lime_stats_t");
 
@@ -39,6 +39,7 @@ struct ScanArgs {
     DevStats *stats;
     lime_cluster_t *small; uint32_t cross_cap;   // tile-crossing clusters <= SMALL_MAX
     lime_cluster_t *big; uint32_t big_cap;       // clusters > SMALL_MAX
+    uint64_t *med; uint32_t med_cap;             // clusters the scan lists for k_score_med: pStart | (len-1) << 48
     uint32_t *tile_cnt; uint64_t *tile_off; CrossRec *cross; lime_cluster_t *out;   // detect only
     int ablate;                                  // timing experiments only (LIME_ABLATE): 0 = full kernel
 };
@@ -47,6 +48,7 @@ void launch_tile(int ebwt, int mode, const ScanArgs &a, uint32_t max_blocks, hip
 void launch_resolve(int mode, const ScanArgs &a, hipStream_t st);
 void launch_scan_tiles(const uint32_t *cnt, uint64_t *off, uint32_t n, unsigned long long *total, hipStream_t st);
 void launch_score_list(int ebwt, const ScanArgs &a, const lime_cluster_t *list, uint64_t count, uint32_t blocks, hipStream_t st);
+void launch_score_med(int ebwt, const ScanArgs &a, uint32_t blocks, hipStream_t st);
 void launch_score_big(int ebwt, const ScanArgs &a, uint32_t *scratch, hipStream_t st);
 void launch_choose(const uint8_t *sim, uint32_t n_reads, uint32_t n_refs, uint8_t *row_max,
                    uint32_t *row_nnz, hipStream_t st);

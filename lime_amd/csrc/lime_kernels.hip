@@ -28,7 +28,8 @@ constexpr uint32_t F_HEAD = 0x10;
 constexpr uint32_t F_READ = 0x20;
 constexpr uint32_t F_GEN = 0x40;
 
-constexpr uint32_t QCAP = 128;        // pending table updates per wave
+constexpr uint32_t QCAP = 320;        // pending table updates per wave (a batch of 64 small clusters adds <= 256)
+constexpr uint32_t MED_CHUNK = 128;   // slots of the medium-cluster list a wave reserves at a time
 constexpr uint32_t T_SHIFT = 27;      // queue entry: genome | t << 27 (t <= SMALL_MAX < 32)
 constexpr uint32_t CAP_A = 256;       // clusters (2..SMALL_MAX symbols) a window can own
 constexpr uint32_t CAP_D = 256;       // of those, clusters with a repeated document (general routine)
@@ -38,8 +39,10 @@ template <uint32_t NPOS>
 struct alignas(16) WaveLds {
     uint32_t da[NPOS];
     uint8_t fl[NPOS];
-    uint8_t hb[72], gb[72];           // per lane: head / genome bits of its 8 positions
+    uint8_t hb[72];                   // head bit of every staged position of the scan (bytes 64..66: read-ahead)
     uint8_t rb[NPOS / 8 + 8];         // read bit of every staged position (byte k = positions 8k..8k+7)
+    uint64_t asw[8];                  // scan: per mask word, heads of the clusters scored in the window
+    uint32_t prew[8];                 //       and how many such heads the words before hold
     uint16_t listA[CAP_A], listD[CAP_D];   // entry: start | (len-1) << 12
     uint32_t q_read[QCAP], q_gen[QCAP];
 };
@@ -66,6 +69,34 @@ __device__ __forceinline__ uint32_t wave_max(uint32_t v)
 #pragma unroll
     for (int d = 32; d > 0; d >>= 1) { const uint32_t o = __shfl_xor(v, d); v = o > v ? o : v; }
     return v;
+}
+
+// inclusive prefix sum over the 64 lanes with DPP row shifts / row broadcasts (no LDS)
+__device__ __forceinline__ uint32_t wave_incl_scan(uint32_t v)
+{
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x111, 0xF, 0xF, false);   // row_shr:1
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x112, 0xF, 0xF, false);   // row_shr:2
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x114, 0xF, 0xF, false);   // row_shr:4
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x118, 0xF, 0xF, false);   // row_shr:8
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x142, 0xA, 0xF, false);   // row_bcast:15 -> rows 1,3
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x143, 0xC, 0xF, false);   // row_bcast:31 -> rows 2,3
+    return v;
+}
+
+// byte -> symbol index, and symbol index -> set of symbol indices it scores 1 against
+// (iupac_match); filled once per workgroup
+struct WgTables { uint8_t symidx[256]; uint16_t compat[16]; };
+
+__device__ __forceinline__ void tables_init(WgTables &T)
+{
+    const uint32_t t = threadIdx.x;
+    if (t < 256u) T.symidx[t] = (uint8_t)sym_index(t);
+    if (t < 16u) {
+        uint32_t m = 0;
+        for (uint32_t b = 0; b < 16u; ++b) m |= iupac_match(t, b) << b;
+        T.compat[t] = (uint16_t)m;
+    }
+    __syncthreads();
 }
 
 // exact "cell += t (mod 256)" on the byte table through a 32-bit CAS on the containing word.
@@ -114,6 +145,37 @@ __device__ __forceinline__ uint32_t emit(UpdQueue &q, const ScanArgs &a, bool on
     }
     q.n += (uint32_t)__popcll(m);
     return on ? 1u : 0u;
+}
+
+// ---- the scan's list of clusters it does not score itself (5..SMALL_MAX symbols, or a repeated
+// document): packed records pStart | (len-1) << 48.  Slots come from a chunk the wave reserved
+// with ONE atomic (a shared counter bumped per cluster would serialise the grid on one address);
+// the unused tail of a chunk is filled with empty (zero) records.
+struct MedState { uint32_t base, used; };
+
+__device__ __forceinline__ void med_fill(const ScanArgs &a, const MedState &ms)
+{
+    for (uint32_t i = ms.used + lane_id(); i < MED_CHUNK; i += 64u)
+        if (ms.base + i < a.med_cap) a.med[ms.base + i] = 0ull;
+}
+
+__device__ __forceinline__ void med_push(const ScanArgs &a, MedState &ms, bool on, uint64_t rec)
+{
+    const uint64_t m = __ballot(on);
+    if (m == 0ull) return;
+    const uint32_t cnt = (uint32_t)__popcll(m);
+    if (ms.used + cnt > MED_CHUNK) {
+        med_fill(a, ms);
+        uint32_t b = 0;
+        if (lane_id() == 0) b = atomicAdd(&a.stats->n_med, MED_CHUNK);
+        ms.base = __builtin_amdgcn_readfirstlane(b); ms.used = 0;
+    }
+    if (on) {
+        const uint32_t slot = ms.base + ms.used + (uint32_t)__popcll(m & ((1ull << lane_id()) - 1ull));
+        if (slot < a.med_cap) a.med[slot] = rec;
+        else atomicOr(&a.stats->flags, LIME_FLAG_OVERFLOW);
+    }
+    ms.used += cnt;
 }
 
 // ---- cluster scoring ----------------------------------------------------------------------
@@ -179,39 +241,39 @@ __device__ __forceinline__ uint32_t cluster_pairs(LDS &L, UpdQueue &qu, const Sc
 // General routine, one lane per cluster [s, s+len) staged in LDS (len <= SMALL_MAX), any mix of
 // repeated documents.  For every read (first occurrence) and every genome (first occurrence)
 // the counts / 16-bin histograms are rebuilt by walking the cluster.  Quadratic, rare.
-template <int EBWT, typename LDS>
-__device__ __forceinline__ uint32_t cluster_general(LDS &L, UpdQueue &qu, const ScanArgs &a, bool on, uint32_t s, uint32_t len)
+template <int EBWT>
+__device__ __forceinline__ uint32_t cluster_general(const uint32_t *da, const uint8_t *fl, UpdQueue &qu, const ScanArgs &a, bool on, uint32_t s, uint32_t len)
 {
     const uint32_t e = on ? s + len : s;
     uint32_t nupd = 0;
     for (uint32_t p = s; __ballot(p < e); ++p) {
         const bool pon = p < e;
-        const uint32_t fp = pon ? L.fl[p] : 0u;
+        const uint32_t fp = pon ? fl[p] : 0u;
         const bool isr = pon && (fp & F_READ);
-        const uint32_t rdoc = isr ? L.da[p] : 0u;
+        const uint32_t rdoc = isr ? da[p] : 0u;
         uint32_t earlier = 0, rcount = 0;
         uint32_t cr[4] = {0u, 0u, 0u, 0u};
         if (isr)
             for (uint32_t q = s; q < e; ++q) {
-                const uint32_t same = (L.da[q] == rdoc);
+                const uint32_t same = (da[q] == rdoc);
                 rcount += same;
                 earlier |= same & (uint32_t)(q < p);
-                if (EBWT) hist_add(cr, L.fl[q] & F_SYM, same);
+                if (EBWT) hist_add(cr, fl[q] & F_SYM, same);
             }
         const bool rlead = isr && !earlier;
         for (uint32_t q = s; __ballot(rlead && q < e); ++q) {
             const bool qon = rlead && q < e;
-            const uint32_t fq = qon ? L.fl[q] : 0u;
+            const uint32_t fq = qon ? fl[q] : 0u;
             const bool isg = qon && (fq & F_GEN);
-            const uint32_t gdoc = isg ? L.da[q] : 0u;
+            const uint32_t gdoc = isg ? da[q] : 0u;
             uint32_t gearlier = 0, gcount = 0;
             uint32_t cg[4] = {0u, 0u, 0u, 0u};
             if (isg)
                 for (uint32_t x = s; x < e; ++x) {
-                    const uint32_t same = (L.da[x] == gdoc);
+                    const uint32_t same = (da[x] == gdoc);
                     gcount += same;
                     gearlier |= same & (uint32_t)(x < q);
-                    if (EBWT) hist_add(cg, L.fl[x] & F_SYM, same);
+                    if (EBWT) hist_add(cg, fl[x] & F_SYM, same);
                 }
             uint32_t t = 0;
             if (isg && !gearlier) t = EBWT ? pair_score(cr, cg) : (rcount < gcount ? rcount : gcount);
@@ -231,10 +293,73 @@ __device__ __forceinline__ uint32_t score_lists(LDS &L, const ScanArgs &a, uint3
     for (uint32_t k0 = 0; k0 < nD; k0 += 64u) {
         const uint32_t k = k0 + lane_id();
         const uint32_t item = L.listD[k < nD ? k : 0u];
-        nupd += cluster_general<EBWT>(L, qu, a, k < nD, item & 0xFFFu, (item >> 12) + 1u);
+        nupd += cluster_general<EBWT>(L.da, L.fl, qu, a, k < nD, item & 0xFFFu, (item >> 12) + 1u);
     }
     drain(qu, a);
     return nupd;
+}
+
+// Clusters of 2..4 symbols (the bulk), one lane per cluster, no loops.  `p` is the window
+// position of the cluster's head; its length and which of its symbols are reads come from the
+// window's head / read bytes; the 4 documents and ebwt bytes sit in registers.  Two equal
+// documents hand the cluster to the medium list (general routine there); otherwise each of the
+// 6 position pairs that joins a read with a genome scores 1 if their symbols are compatible.
+// Hits go straight into the update queue at slots from one wave prefix sum.
+template <int EBWT, typename LDS>
+__device__ __forceinline__ uint32_t score_small(LDS &L, const WgTables &T, UpdQueue &qu, MedState &ms, const ScanArgs &a,
+                                                uint64_t lo, bool on, uint32_t p)
+{
+    if (qu.n > QCAP - 256u) drain(qu, a);
+    const uint32_t kb = p >> 3, sh = p & 7u;
+    const uint32_t hbits = (uint32_t)L.hb[kb] | ((uint32_t)L.hb[kb + 1u] << 8) | ((uint32_t)L.hb[kb + 2u] << 16);
+    const uint32_t rbits = (uint32_t)L.rb[kb] | ((uint32_t)L.rb[kb + 1u] << 8) | ((uint32_t)L.rb[kb + 2u] << 16);
+    const uint32_t after = (hbits >> (sh + 1u)) | 0x8u;            // next head at distance <= 4 for this class
+    const uint32_t len = on ? (uint32_t)__builtin_ctz(after) + 1u : 0u;
+    const uint32_t rmask = (rbits >> sh) & ((1u << len) - 1u);
+    uint32_t d[4], sy[4], cs[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        d[i] = L.da[p + i];
+        sy[i] = EBWT ? T.symidx[L.fl[p + i]] : 0u;
+        cs[i] = EBWT ? T.compat[sy[i]] : 0xFFFFu;
+    }
+    uint32_t dup = 0;
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = i + 1; j < 4; ++j) dup |= (uint32_t)(d[i] == d[j]) & (uint32_t)((uint32_t)j < len);
+    med_push(a, ms, dup != 0u, (lo + p) | ((uint64_t)(len - 1u) << 48));
+    uint32_t hits = 0, bad = 0;
+    int pi = 0;
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = i + 1; j < 4; ++j, ++pi) {
+            const uint32_t ri = (rmask >> i) & 1u, rj = (rmask >> j) & 1u;
+            const uint32_t g = (ri ? d[j] : d[i]) - a.n_reads;
+            uint32_t ok = (uint32_t)((uint32_t)j < len) & (ri ^ rj) & ((cs[i] >> sy[j]) & 1u) & (uint32_t)!dup;
+            bad |= ok & (uint32_t)(g >= a.n_refs);
+            ok &= (uint32_t)(g < a.n_refs);
+            hits |= ok << pi;
+        }
+    if (__ballot(bad != 0u)) { if (bad) atomicOr(&a.stats->flags, LIME_FLAG_DOCID); }
+    const uint32_t nh = (uint32_t)__popc(hits);
+    const uint32_t incl = wave_incl_scan(nh);
+    uint32_t slot = qu.n + incl - nh;
+    pi = 0;
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = i + 1; j < 4; ++j, ++pi) {
+            if ((hits >> pi) & 1u) {
+                const bool ri = (rmask >> i) & 1u;
+                qu.qr[slot] = ri ? d[i] : d[j];
+                qu.qg[slot] = ((ri ? d[j] : d[i]) - a.n_reads) | (1u << T_SHIFT);
+                ++slot;
+            }
+        }
+    qu.n += rl32(incl, 63);
+    return nh;
 }
 
 // ---- window context, lane = 64-bit mask word (words 0..7 owned, word 8 = read-ahead) --------
@@ -321,29 +446,24 @@ __device__ __forceinline__ void window_load(WinRegs &t, const ScanArgs &a, uint6
     t.hb = (EBWT && hok) ? a.ebwt[hp] : 0u;
 }
 
-__device__ __forceinline__ uint32_t make_flag(int ebwt, bool valid, uint32_t l, uint32_t d, uint32_t b, const ScanArgs &a)
-{
-    uint32_t f = ebwt ? sym_index(b) : 0u;
-    if (!valid) return F_HEAD;                                      // padding closes runs
-    if (l < a.alpha) f |= F_HEAD;
-    f |= (d < a.n_reads) ? F_READ : F_GEN;
-    return f;
-}
-
 // =========================================================================================
 // k_scan: the streaming scan.  Every wave is an independent worker over windows of WIN
-// positions (stride = number of waves in the grid); no workgroup barrier anywhere.
+// positions (stride = number of waves in the grid); no workgroup barrier in the loop.
 // MODE: 0 detect + score, 1 count clusters per window, 2 emit cluster records in order.
 // =========================================================================================
 template <int EBWT, int MODE>
 __global__ __launch_bounds__(SCAN_WG) void k_scan(ScanArgs a)
 {
     __shared__ WaveLds<WPOS> lds[SCAN_WG / 64];
+    __shared__ WgTables T;
     const uint32_t lane = lane_id(), wave = threadIdx.x >> 6;
     WaveLds<WPOS> &L = lds[wave];
+    tables_init(T);                                        // the only workgroup barrier of the kernel
     const uint32_t n_win = a.n_tiles, stride = gridDim.x * (SCAN_WG / 64);
     uint32_t win = blockIdx.x * (SCAN_WG / 64) + wave;
     if (win >= n_win) return;
+    UpdQueue qu; qu.qr = L.q_read; qu.qg = L.q_gen; qu.n = 0;
+    MedState ms = {0u, MED_CHUNK};                         // no chunk reserved yet
     WinRegs regs;
     window_load<EBWT>(regs, a, (uint64_t)win * WIN);
     uint32_t acc_n = 0, acc_max = 0, acc_upd = 0;          // per-lane partial counters, reduced once at the end
@@ -351,36 +471,46 @@ __global__ __launch_bounds__(SCAN_WG) void k_scan(ScanArgs a)
     for (;;) {
         const uint64_t lo = (uint64_t)win * WIN;
         const uint64_t own_lim = a.n_own > lo ? (a.n_own - lo < WIN ? a.n_own - lo : (uint64_t)WIN) : 0ull;
-        // ---- stage the window in LDS; head / read / genome bits of the lane's 8 positions ----
+        const uint64_t lim = a.n_avail - lo;               // valid positions of the window + read-ahead: [0, lim)
+        // ---- stage the window in LDS: documents, raw ebwt bytes, and per lane one byte each of
+        // head bits (lcp < alpha) and read bits (da < n_reads) of its 8 positions -------------------
         {
-            uint32_t hb = 0, rb = 0, gb = 0, fw[2] = {0u, 0u};
+            uint32_t hb = 0, rb = 0;
 #pragma unroll
             for (int j = 0; j < 8; ++j) {
-                const uint32_t f = make_flag(EBWT, lo + 8u * lane + j < a.n_avail, regs.lv[j], regs.dv[j],
-                                             (regs.bv[j >> 2] >> (8 * (j & 3))) & 255u, a);
-                hb |= ((f >> 4) & 1u) << j; rb |= ((f >> 5) & 1u) << j; gb |= ((f >> 6) & 1u) << j;
-                fw[j >> 2] |= f << (8 * (j & 3));
+                hb |= (uint32_t)(regs.lv[j] < a.alpha) << j;
+                rb |= (uint32_t)(regs.dv[j] < a.n_reads) << j;
+            }
+            uint32_t hh = (uint32_t)(lane < HALO && regs.hl < a.alpha), hr = (uint32_t)(lane < HALO && regs.hd < a.n_reads);
+            if (lim < WPOS) {                              // the end of the data: padding closes runs, is nobody's
+                const uint32_t v0 = 8u * lane;
+                const uint32_t vb = lim >= v0 + 8u ? 255u : (lim <= v0 ? 0u : ((1u << (lim - v0)) - 1u));
+                hb |= ~vb & 255u; rb &= vb;
+                const bool hv = WIN + lane < lim;
+                hh = (uint32_t)(lane < HALO && (!hv || regs.hl < a.alpha)); hr = hr & (uint32_t)hv;
             }
             *reinterpret_cast<uint4 *>(&L.da[8u * lane]) = make_uint4(regs.dv[0], regs.dv[1], regs.dv[2], regs.dv[3]);
             *reinterpret_cast<uint4 *>(&L.da[8u * lane + 4u]) = make_uint4(regs.dv[4], regs.dv[5], regs.dv[6], regs.dv[7]);
-            *reinterpret_cast<uint2 *>(&L.fl[8u * lane]) = make_uint2(fw[0], fw[1]);
-            L.hb[lane] = (uint8_t)hb; L.rb[lane] = (uint8_t)rb; L.gb[lane] = (uint8_t)gb;
+            if (EBWT) *reinterpret_cast<uint2 *>(&L.fl[8u * lane]) = make_uint2(regs.bv[0], regs.bv[1]);
+            L.hb[lane] = (uint8_t)hb; L.rb[lane] = (uint8_t)rb;
+            if (lane < HALO) { L.da[WIN + lane] = regs.hd; if (EBWT) L.fl[WIN + lane] = (uint8_t)regs.hb; }
+            const uint64_t H8 = __ballot(hh != 0u), R8 = __ballot(hr != 0u);
+            if (lane < 3u) { L.hb[64u + lane] = (uint8_t)(H8 >> (8u * lane)); L.rb[64u + lane] = (uint8_t)(R8 >> (8u * lane)); }
         }
-        const uint32_t hf = lane < HALO ? make_flag(EBWT, lo + WIN + lane < a.n_avail, regs.hl, regs.hd, regs.hb, a) : 0u;
-        if (lane < HALO) { L.da[WIN + lane] = regs.hd; L.fl[WIN + lane] = (uint8_t)hf; }
-        const uint64_t H8 = __ballot((hf & F_HEAD) != 0u), R8 = __ballot((hf & F_READ) != 0u), G8 = __ballot((hf & F_GEN) != 0u);
-        if (lane < 3u) L.rb[64u + lane] = (uint8_t)(R8 >> (8u * lane));     // read bits of the read-ahead
         // ---- the next window's loads go out now and land while this one is processed ----------
         const uint32_t next = win + stride;
         if (next < n_win && a.ablate != 8) window_load<EBWT>(regs, a, (uint64_t)next * WIN);
         if (a.ablate != 1) {
-        // ---- masks with lane = word: bytes of 8 lanes make one 64-bit word ---------------------
+        // ---- masks with lane = word: bytes of 8 lanes make one 64-bit word (word 8: read-ahead) --
         uint64_t h = 0ull, r = 0ull, g = 0ull;
-        if (lane < WIN / 64) {
+        if (lane <= WIN / 64) {
             h = *reinterpret_cast<const uint64_t *>(&L.hb[8u * lane]);
             r = *reinterpret_cast<const uint64_t *>(&L.rb[8u * lane]);
-            g = *reinterpret_cast<const uint64_t *>(&L.gb[8u * lane]);
-        } else if (lane == WIN / 64) { h = H8; r = R8; g = G8; }
+            const uint64_t wl = 64ull * lane;
+            const uint64_t v = lim >= wl + 64u ? ~0ull : (lim <= wl ? 0ull : ((1ull << (lim - wl)) - 1ull));
+            g = v & ~r;
+            if (lane == WIN / 64) { h &= 0xFFFFull; g &= 0xFFFFull; }
+        }
         const WinCtx c = window_context(h, r, g, own_lim);
 
         // ---- window summary for the segment that is still open after the read-ahead ------------
@@ -412,8 +542,8 @@ __global__ __launch_bounds__(SCAN_WG) void k_scan(ScanArgs a)
             if (lane == 0 && MODE != 2) { sm.pre = pre; sm.suf = suf; a.summ[win] = sm; }
             // a run closed by padding instead of data while more data exists beyond the shard's
             // halo: the last data head in sight is owned and nothing but padding follows it
-            if (!a.eof && lo + WPOS > a.n_avail) {
-                const uint64_t lim = a.n_avail - lo, wl = (uint64_t)lane * 64u;
+            if (!a.eof && lim < WPOS) {
+                const uint64_t wl = (uint64_t)lane * 64u;
                 const uint64_t dh = wl >= lim ? 0ull : (wl + 64u <= lim ? c.h : (c.h & ((1ull << (lim - wl)) - 1ull)));
                 const uint64_t dw = __ballot(dh != 0ull);
                 if (dw) {
@@ -424,43 +554,29 @@ __global__ __launch_bounds__(SCAN_WG) void k_scan(ScanArgs a)
                 }
             }
         }
-
-        // ---- phase A: lane l walks the accepted heads among ITS 8 positions ---------------------
         if (a.ablate != 3) {
-        const uint32_t w = lane >> 3, o = lane & 7u;
-        const uint64_t AHw = shfl64(c.ah, (int)w), Hw = shfl64(c.h, (int)w);
-        const uint32_t e_suf = __shfl(c.e_suf, (int)w);
-        uint32_t ahb = (uint32_t)(AHw >> (8u * o)) & 255u;
-        const uint32_t my_n = (uint32_t)__popc(ahb);
-        acc_n += my_n;
-        uint32_t nA = 0, rank = 0, win_cnt = 0;
-        if (MODE != 0) {                                            // ordered output needs ranks
-            uint32_t x = my_n;
-#pragma unroll
-            for (int d = 1; d < 64; d <<= 1) { const uint32_t y = __shfl_up(x, d); if ((int)lane >= d) x += y; }
-            rank = x - my_n; win_cnt = rl32(x, 63);
-            if (MODE == 1 && lane == 0) a.tile_cnt[win] = win_cnt;
-        }
-        while (__ballot(ahb != 0u)) {
-            const bool act = ahb != 0u;
-            const uint32_t b = act ? (uint32_t)__builtin_ctz(ahb) : 0u;
-            ahb &= ahb - 1u;
-            const uint32_t bit = 8u * o + b, p = 64u * w + bit;
-            const uint64_t ha = (bit == 63u) ? 0ull : (Hw & (~0ull << (bit + 1u)));
-            const uint32_t e = ha ? 64u * w + (uint32_t)__builtin_ctzll(ha) : e_suf;
-            const uint32_t len = act ? e - p : 0u;
-            acc_max = len > acc_max ? len : acc_max;
-            if (MODE == 2 && act) {
-                lime_cluster_t rec; rec.pStart = a.pos_base + lo + p; rec.len = len;
-                a.out[a.tile_off[win] + rank] = rec; ++rank;
-            }
-            if (MODE == 0) {
-                const bool cA = act && len <= SMALL_MAX, cD = act && len > SMALL_MAX;
-                const uint16_t item = (uint16_t)(p | ((len - 1u) << 12));
-                const uint64_t mA = __ballot(cA);
-                if (cA) L.listA[nA + (uint32_t)__popcll(mA & lt)] = item;
-                nA += (uint32_t)__popcll(mA);
-                if (__ballot(cD)) {                               // rare: too long for the in-window path
+        acc_n += (uint32_t)__popcll(c.ah);
+        if (MODE == 0) {
+            // ---- accepted heads by cluster length, still lane = word: the next head after an
+            // accepted head b is at b+2, b+3 or b+4 for clusters of 2, 3, 4 symbols -------------
+            const uint64_t hn = shfl64(c.h, (int)(lane < 63u ? lane + 1u : lane));
+            const uint64_t n2 = (c.h >> 2) | (hn << 62), n3 = (c.h >> 3) | (hn << 61), n4 = (c.h >> 4) | (hn << 60);
+            const uint64_t as = c.ah & (n2 | n3 | n4);         // 2..4 symbols: scored here, one lane per cluster
+            uint64_t al = c.ah & ~(n2 | n3 | n4);              // longer: measured below, scored by other kernels
+            const uint32_t small_max = (c.ah & ~n2 & ~n3 & n4) ? 4u : ((c.ah & ~n2 & n3) ? 3u : ((c.ah & n2) ? 2u : 0u));
+            acc_max = small_max > acc_max ? small_max : acc_max;
+            while (__ballot(al != 0ull)) {
+                const bool act = al != 0ull;
+                const uint32_t b = act ? (uint32_t)__builtin_ctzll(al) : 0u;
+                al &= al - 1ull;
+                const uint32_t p = 64u * lane + b;
+                const uint64_t ha = (b == 63u) ? 0ull : (c.h & (~0ull << (b + 1u)));
+                const uint32_t e = ha ? 64u * lane + (uint32_t)__builtin_ctzll(ha) : c.e_suf;
+                const uint32_t len = act ? e - p : 0u;
+                acc_max = len > acc_max ? len : acc_max;
+                med_push(a, ms, act && len <= SMALL_MAX, (lo + p) | ((uint64_t)(len - 1u) << 48));
+                const bool cD = act && len > SMALL_MAX;
+                if (__ballot(cD)) {                               // rare: one workgroup per such cluster later
                     if (cD) {
                         if (len > LIME_MAX_CLUSTER) atomicOr(&a.stats->flags, LIME_FLAG_MAXLEN);
                         else {
@@ -470,22 +586,69 @@ __global__ __launch_bounds__(SCAN_WG) void k_scan(ScanArgs a)
                     }
                 }
             }
-        }
-        if (MODE == 2 && lane == 0) {
-            const CrossRec cr = a.cross[win];
-            if (cr.len) {
-                lime_cluster_t rec; rec.pStart = a.pos_base + cr.start; rec.len = cr.len;
-                a.out[a.tile_off[win] + win_cnt] = rec;
+            // ---- hand the small clusters to lanes: lane t takes the t-th set bit of `as` -------
+            if (a.ablate != 4) {
+            const uint32_t cnt = (uint32_t)__popcll(as);
+            uint32_t incl = cnt;
+            incl += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)incl, 0x111, 0xF, 0xF, false);
+            incl += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)incl, 0x112, 0xF, 0xF, false);
+            incl += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)incl, 0x114, 0xF, 0xF, false);
+            const uint32_t pre = incl - cnt, total = rl32(incl, 7);
+            const uint32_t p1 = rl32(pre, 1), p2 = rl32(pre, 2), p3 = rl32(pre, 3), p4 = rl32(pre, 4),
+                           p5 = rl32(pre, 5), p6 = rl32(pre, 6), p7 = rl32(pre, 7);
+            if (lane < WIN / 64) { L.asw[lane] = as; L.prew[lane] = pre; }     // looked up by word below
+            for (uint32_t base = 0; base < total; base += 64u) {
+                const uint32_t t = base + lane;
+                const bool on = t < total;
+                const uint32_t w = (uint32_t)(t >= p1) + (uint32_t)(t >= p2) + (uint32_t)(t >= p3) + (uint32_t)(t >= p4) +
+                                   (uint32_t)(t >= p5) + (uint32_t)(t >= p6) + (uint32_t)(t >= p7);
+                uint64_t x = L.asw[w];
+                uint32_t j = on ? t - L.prew[w] : 0u;
+                while (__ballot(j != 0u)) { if (j) { x &= x - 1ull; --j; } }
+                const uint32_t p = on ? 64u * w + (uint32_t)__builtin_ctzll(x | (1ull << 63)) : 0u;
+                acc_upd += score_small<EBWT>(L, T, qu, ms, a, lo, on, p);
+            }
+            }
+        } else {
+            // ---- count / emit: lane l walks the accepted heads among ITS 8 positions ---------------
+            const uint32_t w = lane >> 3, o = lane & 7u;
+            const uint64_t AHw = shfl64(c.ah, (int)w), Hw = shfl64(c.h, (int)w);
+            const uint32_t e_suf = __shfl(c.e_suf, (int)w);
+            uint32_t ahb = (uint32_t)(AHw >> (8u * o)) & 255u;
+            const uint32_t my_n = (uint32_t)__popc(ahb);
+            const uint32_t x = wave_incl_scan(my_n);
+            uint32_t rank = x - my_n;
+            const uint32_t win_cnt = rl32(x, 63);
+            if (MODE == 1 && lane == 0) a.tile_cnt[win] = win_cnt;
+            while (__ballot(ahb != 0u)) {
+                const bool act = ahb != 0u;
+                const uint32_t b = act ? (uint32_t)__builtin_ctz(ahb) : 0u;
+                ahb &= ahb - 1u;
+                const uint32_t bit = 8u * o + b, p = 64u * w + bit;
+                const uint64_t ha = (bit == 63u) ? 0ull : (Hw & (~0ull << (bit + 1u)));
+                const uint32_t e = ha ? 64u * w + (uint32_t)__builtin_ctzll(ha) : e_suf;
+                const uint32_t len = act ? e - p : 0u;
+                acc_max = len > acc_max ? len : acc_max;
+                if (MODE == 2 && act) {
+                    lime_cluster_t rec; rec.pStart = a.pos_base + lo + p; rec.len = len;
+                    a.out[a.tile_off[win] + rank] = rec; ++rank;
+                }
+            }
+            if (MODE == 2 && lane == 0) {
+                const CrossRec cr = a.cross[win];
+                if (cr.len) {
+                    lime_cluster_t rec; rec.pStart = a.pos_base + cr.start; rec.len = cr.len;
+                    a.out[a.tile_off[win] + win_cnt] = rec;
+                }
             }
         }
-        // ---- phase B: score the window's clusters ------------------------------------------------
-        if (MODE == 0 && a.ablate != 4) acc_upd += score_lists<EBWT>(L, a, nA);
         }
         }
         if (next >= n_win) break;
         if (a.ablate == 8) window_load<EBWT>(regs, a, (uint64_t)next * WIN);
         win = next;
     }
+    if (MODE == 0) { drain(qu, a); med_fill(a, ms); }
     if (MODE != 2) {
         const uint32_t tn = wave_sum(acc_n), tm = wave_max(acc_max), tu = wave_sum(acc_upd);
         if (lane == 0) {
@@ -620,6 +783,80 @@ __global__ __launch_bounds__(SCAN_WG) void k_score_list(ScanArgs a, const lime_c
         if (cA) L.listA[(uint32_t)__popcll(mA & lt)] = item;
         acc_upd += score_lists<EBWT>(L, a, (uint32_t)__popcll(mA));
     }
+    const uint32_t tu = wave_sum(acc_upd);
+    if (lane == 0 && tu) atomicAdd(&a.stats->n_updates, (unsigned long long)tu);
+}
+
+// =========================================================================================
+// k_score_med: the clusters the scan listed instead of scoring (5..SMALL_MAX symbols, or a
+// repeated document).  16 lanes per cluster, element i on sub-lane i, read straight from
+// global memory; XOR-ing the sub-lane with 1..15 shows every lane every other element.  With
+// all documents distinct each read lane scores each compatible genome it meets; a cluster with
+// a repeated document is staged in LDS and scored by the general routine.
+// =========================================================================================
+template <int EBWT>
+__global__ __launch_bounds__(SCAN_WG) void k_score_med(ScanArgs a)
+{
+    __shared__ WgTables T;
+    __shared__ uint32_t s_da[SCAN_WG / 64][64];
+    __shared__ uint8_t s_fl[SCAN_WG / 64][64];
+    __shared__ uint32_t s_qr[SCAN_WG / 64][QCAP], s_qg[SCAN_WG / 64][QCAP];
+    const uint32_t lane = lane_id(), wave = threadIdx.x >> 6, sub = lane & 15u, grp = lane >> 4;
+    tables_init(T);
+    UpdQueue qu; qu.qr = s_qr[wave]; qu.qg = s_qg[wave]; qu.n = 0;
+    const uint32_t n = a.stats->n_med < a.med_cap ? a.stats->n_med : a.med_cap;
+    const uint32_t n_it = (n + 3u) / 4u, stride = gridDim.x * (SCAN_WG / 64);
+    const uint64_t gm = 0xFFFFull << (lane & 48u);
+    uint32_t acc_upd = 0;
+    for (uint32_t it = blockIdx.x * (SCAN_WG / 64) + wave; it < n_it; it += stride) {
+        const uint32_t idx = it * 4u + grp;
+        const uint64_t rec = idx < n ? a.med[idx] : 0ull;          // 0: empty slot
+        const uint64_t ps = rec & 0xFFFFFFFFFFFFull;
+        const uint32_t len = rec ? (uint32_t)(rec >> 48) + 1u : 0u;
+        const bool have = sub < len;
+        const uint32_t d = have ? a.da[ps + sub] : 0u;
+        const uint32_t sy = (EBWT && have) ? T.symidx[a.ebwt[ps + sub]] : 0u;
+        const bool isr = have && d < a.n_reads;
+        const uint32_t f = have ? (sy | (isr ? F_READ : F_GEN)) : 0u;
+        const uint32_t cs = EBWT ? T.compat[sy] : 0xFFFFu;
+        uint32_t dup = 0, hits = 0, bad = 0;
+#pragma unroll 1
+        for (int r = 1; r < 16; ++r) {
+            const uint32_t pd = __shfl_xor(d, r), pf = __shfl_xor(f, r);
+            const bool both = f && pf;
+            dup |= (uint32_t)(both && pd == d);
+            const uint32_t g = pd - a.n_reads;
+            uint32_t ok = (uint32_t)(both && isr && (pf & F_GEN)) & ((cs >> (pf & F_SYM)) & 1u);
+            bad |= ok & (uint32_t)(g >= a.n_refs);
+            ok &= (uint32_t)(g < a.n_refs);
+            hits |= ok << r;
+        }
+        const bool gdup = (__ballot(dup != 0u) & gm) != 0ull;
+        if (__ballot(bad != 0u)) { if (bad && !gdup) atomicOr(&a.stats->flags, LIME_FLAG_DOCID); }
+        if (gdup) hits = 0u;
+        acc_upd += (uint32_t)__popc(hits);
+        // a lane can hit up to 15 times: to the queue in rounds of at most 4 per lane
+        while (__ballot(hits != 0u)) {
+            if (qu.n > QCAP - 256u) drain(qu, a);
+            uint32_t take = 0, hsel = 0;
+#pragma unroll 1
+            for (int r = 1; r < 16; ++r) if (((hits >> r) & 1u) && take < 4u) { hsel |= 1u << r; ++take; }
+            const uint32_t incl = wave_incl_scan(take);
+            uint32_t slot = qu.n + incl - take;
+#pragma unroll 1
+            for (int r = 1; r < 16; ++r) {
+                const uint32_t pd = __shfl_xor(d, r);
+                if ((hsel >> r) & 1u) { qu.qr[slot] = d; qu.qg[slot] = (pd - a.n_reads) | (1u << T_SHIFT); ++slot; }
+            }
+            qu.n += rl32(incl, 63);
+            hits &= ~hsel;
+        }
+        if (__ballot(gdup)) {                                      // repeated document: general routine from LDS
+            s_da[wave][lane] = d; s_fl[wave][lane] = (uint8_t)f;
+            acc_upd += cluster_general<EBWT>(s_da[wave], s_fl[wave], qu, a, gdup && sub == 0u, lane & 48u, len);
+        }
+    }
+    drain(qu, a);
     const uint32_t tu = wave_sum(acc_upd);
     if (lane == 0 && tu) atomicAdd(&a.stats->n_updates, (unsigned long long)tu);
 }
@@ -823,6 +1060,12 @@ void launch_score_list(int ebwt, const ScanArgs &a, const lime_cluster_t *list, 
 {
     if (ebwt) hipLaunchKernelGGL((k_score_list<1>), dim3(blocks), dim3(SCAN_WG), 0, st, a, list, count);
     else      hipLaunchKernelGGL((k_score_list<0>), dim3(blocks), dim3(SCAN_WG), 0, st, a, list, count);
+}
+
+void launch_score_med(int ebwt, const ScanArgs &a, uint32_t blocks, hipStream_t st)
+{
+    if (ebwt) hipLaunchKernelGGL((k_score_med<1>), dim3(blocks), dim3(SCAN_WG), 0, st, a);
+    else      hipLaunchKernelGGL((k_score_med<0>), dim3(blocks), dim3(SCAN_WG), 0, st, a);
 }
 
 void launch_score_big(int ebwt, const ScanArgs &a, uint32_t *scratch, hipStream_t st)

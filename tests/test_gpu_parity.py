@@ -278,3 +278,21 @@ def test_persistent_workgroups_walk_many_tiles(max_blocks, monkeypatch):
                 assert np.array_equal(sim, exp)
     finally:
         c.close()
+
+
+@pytest.mark.parametrize("period", [2, 3, 4, 5])
+@pytest.mark.parametrize("n", [250, 256, 300, 512, 1030, 5000])
+def test_dense_small_clusters(ctx, period, n):
+    """more than 64 small clusters per 512-position window (several hand-out rounds per window),
+    ends of data at every offset of a window"""
+    rng = np.random.default_rng(period * 10007 + n)
+    nr = ng = 3000
+    lcp = np.full(n, 20, np.uint32); lcp[::period] = 0
+    da = np.where(rng.random(n) < 0.5, rng.integers(0, nr, n), nr + rng.integers(0, ng, n)).astype(np.uint32)
+    eb = rng.choice(np.frombuffer(b"ACGTN", np.uint8), n).astype(np.uint8)
+    cl, nc, ml = O.detect(lcp, da, nr, 16)
+    for e in (eb, None):
+        exp = O.score(da, e, cl, nr, ng)
+        sim, gnc, gml = ctx.fused(lcp, da, e, nr, ng, 16)
+        assert (gnc, gml) == (nc, ml)
+        assert np.array_equal(sim, exp)
