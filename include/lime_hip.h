@@ -52,7 +52,8 @@ typedef struct {
     uint32_t n_cross;      /* clusters that crossed a tile edge (scored by the list kernel)  */
     uint32_t n_big;        /* clusters longer than the in-tile limit (scored by the big kernel) */
     uint32_t flags;        /* LIME_FLAG_* */
-    uint32_t n_med;        /* clusters of 5..16 symbols handed from the scan to the list kernel */
+    uint32_t n_med[2];     /* slots of the two lists (<= 8 / 9..16 symbols) the scan hands to k_score_med */
+    uint32_t reserved;
 } lime_stats_t;
 
 #define LIME_FLAG_MAXLEN 1u

@@ -23,7 +23,7 @@ class Cluster(C.Structure):
 
 class Stats(C.Structure):
     _fields_ = [("n_clusters", C.c_uint64), ("max_len", C.c_uint64), ("n_updates", C.c_uint64),
-                ("n_cross", C.c_uint32), ("n_big", C.c_uint32), ("flags", C.c_uint32), ("n_med", C.c_uint32)]
+                ("n_cross", C.c_uint32), ("n_big", C.c_uint32), ("flags", C.c_uint32), ("n_med", C.c_uint32 * 2), ("reserved", C.c_uint32)]
 
 
 class LimeError(RuntimeError):

@@ -140,7 +140,7 @@ static int ensure_scratch(lime_ctx *c, uint64_t n_avail, bool detect, bool score
         const uint64_t want_med = n_avail / 2u + 1048576u;
         if (want_med > c->med_cap) {
             if (want_med > 0xFFFFFFF0ull) return fail(LIME_ERR_ARG, "array too long for one shard: %llu", (unsigned long long)n_avail);
-            HIP_TRY(hipStreamSynchronize(st)); if ((rc = regrow(c->d_med, want_med))) return rc; c->med_cap = (uint32_t)want_med;
+            HIP_TRY(hipStreamSynchronize(st)); if ((rc = regrow(c->d_med, 2u * (size_t)want_med))) return rc; c->med_cap = (uint32_t)want_med;
         }
         if (!c->d_big_scratch) {
             const size_t words = (size_t)BIG_GRID * BIG_SCRATCH_WORDS;

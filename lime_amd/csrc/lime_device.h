@@ -93,24 +93,37 @@ LIME_HD void hist_set(uint32_t (&w)[4], uint32_t i, uint32_t v)
     w[3] = (k == 3u) ? ((w[3] & keep) | (v << sh)) : w[3];
 }
 
-// the general case (rare): rolled loops over packed leftovers, to keep the kernels small
+// the general case (rare).  t starts from the sum of minima (as above); the cross-match block
+// (:146-177) only ever touches the leftovers of the four bases and of IUPAC codes whose read and
+// genome counts differ, and an (i, a) step is a no-op when both leftovers of code a are zero --
+// leftovers of codes never grow -- so it is enough to walk, for each base i in order, the codes a
+// (ascending) that start with a non-zero leftover.  Same order of effects as the reference.
 LIME_HD uint32_t pair_score_iupac(const uint32_t (&cr)[4], const uint32_t (&cg)[4])
 {
-    uint32_t t = 0, rr[4] = {0u, 0u, 0u, 0u}, rg[4] = {0u, 0u, 0u, 0u};
-    for (uint32_t i = 0; i < 16u; i++) {         // :133-144
+    uint32_t t = (sad_u8(cr[0], 0u, sad_u8(cr[1], 0u, sad_u8(cr[2], 0u, sad_u8(cr[3], 0u, 0u)))) +
+                  sad_u8(cg[0], 0u, sad_u8(cg[1], 0u, sad_u8(cg[2], 0u, sad_u8(cg[3], 0u, 0u)))) -
+                  sad_u8(cr[0], cg[0], sad_u8(cr[1], cg[1], sad_u8(cr[2], cg[2], sad_u8(cr[3], cg[3], 0u))))) >> 1;
+    uint32_t rr[4] = {0u, 0u, 0u, 0u}, rg[4] = {0u, 0u, 0u, 0u};   // leftovers, packed like the histograms
+    uint32_t nz = 0;                                               // codes 4..14 with a non-zero leftover
+    for (uint32_t i = 0; i < 15u; i++) {
         const uint32_t a = hist_get(cr, i), b = hist_get(cg, i);
+        if (i >= 4u && a == b) continue;
         const uint32_t mn = a < b ? a : b;
-        t += mn; hist_set(rr, i, a - mn); hist_set(rg, i, b - mn);
+        hist_set(rr, i, a - mn); hist_set(rg, i, b - mn);
+        if (i >= 4u) nz |= 1u << i;
     }
     for (uint32_t i = 0; i < 4u; i++) {          // :146-177
-        for (uint32_t a = 4; a < 15u; a++) {
+        uint32_t m = nz;
+        while (m) {
+            const uint32_t a = (uint32_t)__builtin_ctz(m);
+            m &= m - 1u;
             if (!((CORR_PACKED >> (a * 4u + i)) & 1ull)) continue;
-            uint32_t ga = hist_get(rg, a), ri = hist_get(rr, i);
+            const uint32_t ga = hist_get(rg, a), ri = hist_get(rr, i);
             if (ga > 0u) {                       // :150-161 (as written: the zeroed side is "subtracted")
-                if (ga > ri) { t += ri; ri = 0u; hist_set(rr, i, 0u); }
+                if (ga > ri) { t += ri; hist_set(rr, i, 0u); }
                 else         { t += ga; hist_set(rg, a, 0u); }
             }
-            uint32_t ra = hist_get(rr, a), gi = hist_get(rg, i);
+            const uint32_t ra = hist_get(rr, a), gi = hist_get(rg, i);
             if (ra > 0u) {                       // :163-174
                 if (ra > gi) { t += gi; hist_set(rr, a, ra - gi); hist_set(rg, i, 0u); }
                 else         { t += ra; hist_set(rg, i, gi - ra); hist_set(rr, a, 0u); }

@@ -25,7 +25,7 @@ struct CrossRec { uint64_t start, len; };                          // len == 0: 
 
 struct DevStats {                            // same layout as lime_stats_t
     unsigned long long n_clusters, max_len, n_updates;
-    uint32_t n_cross, n_big, flags, n_med;
+    uint32_t n_cross, n_big, flags, n_med[2], reserved;
 };
 static_assert(sizeof(DevStats) == sizeof(lime_stats_t), "DevStats must mirror lime_stats_t");
 
@@ -39,7 +39,7 @@ struct ScanArgs {
     DevStats *stats;
     lime_cluster_t *small; uint32_t cross_cap;   // tile-crossing clusters <= SMALL_MAX
     lime_cluster_t *big; uint32_t big_cap;       // clusters > SMALL_MAX
-    uint64_t *med; uint32_t med_cap;             // clusters the scan lists for k_score_med: pStart | (len-1) << 48
+    uint64_t *med; uint32_t med_cap;             // 2 lists of med_cap records for k_score_med: pStart | (len-1) << 48
     uint32_t *tile_cnt; uint64_t *tile_off; CrossRec *cross; lime_cluster_t *out;   // detect only
     int ablate;                                  // timing experiments only (LIME_ABLATE): 0 = full kernel
 };

@@ -29,7 +29,7 @@ constexpr uint32_t F_READ = 0x20;
 constexpr uint32_t F_GEN = 0x40;
 
 constexpr uint32_t QCAP = 320;        // pending table updates per wave (a batch of 64 small clusters adds <= 256)
-constexpr uint32_t MED_CHUNK = 128;   // slots of the medium-cluster list a wave reserves at a time
+constexpr uint32_t MED_CHUNK = 64;    // slots of a medium-cluster list a wave reserves at a time
 constexpr uint32_t T_SHIFT = 27;      // queue entry: genome | t << 27 (t <= SMALL_MAX < 32)
 constexpr uint32_t CAP_A = 256;       // clusters (2..SMALL_MAX symbols) a window can own
 constexpr uint32_t CAP_D = 256;       // of those, clusters with a repeated document (general routine)
@@ -151,31 +151,39 @@ __device__ __forceinline__ uint32_t emit(UpdQueue &q, const ScanArgs &a, bool on
 // document): packed records pStart | (len-1) << 48.  Slots come from a chunk the wave reserved
 // with ONE atomic (a shared counter bumped per cluster would serialise the grid on one address);
 // the unused tail of a chunk is filled with empty (zero) records.
-struct MedState { uint32_t base, used; };
+struct MedState { uint32_t base[2], used[2]; };      // list 0: <= 8 symbols, list 1: 9..SMALL_MAX
 
-__device__ __forceinline__ void med_fill(const ScanArgs &a, const MedState &ms)
+__device__ __forceinline__ void med_fill(const ScanArgs &a, const MedState &ms, uint32_t which)
 {
-    for (uint32_t i = ms.used + lane_id(); i < MED_CHUNK; i += 64u)
-        if (ms.base + i < a.med_cap) a.med[ms.base + i] = 0ull;
+    for (uint32_t i = ms.used[which] + lane_id(); i < MED_CHUNK; i += 64u)
+        if (ms.base[which] + i < a.med_cap) a.med[(size_t)which * a.med_cap + ms.base[which] + i] = 0ull;
 }
 
-__device__ __forceinline__ void med_push(const ScanArgs &a, MedState &ms, bool on, uint64_t rec)
+__device__ __forceinline__ void med_push1(const ScanArgs &a, MedState &ms, uint32_t which, bool on, uint64_t rec)
 {
     const uint64_t m = __ballot(on);
     if (m == 0ull) return;
     const uint32_t cnt = (uint32_t)__popcll(m);
-    if (ms.used + cnt > MED_CHUNK) {
-        med_fill(a, ms);
+    if (ms.used[which] + cnt > MED_CHUNK) {
+        med_fill(a, ms, which);
         uint32_t b = 0;
-        if (lane_id() == 0) b = atomicAdd(&a.stats->n_med, MED_CHUNK);
-        ms.base = __builtin_amdgcn_readfirstlane(b); ms.used = 0;
+        if (lane_id() == 0) b = atomicAdd(&a.stats->n_med[which], MED_CHUNK);
+        ms.base[which] = __builtin_amdgcn_readfirstlane(b); ms.used[which] = 0;
     }
     if (on) {
-        const uint32_t slot = ms.base + ms.used + (uint32_t)__popcll(m & ((1ull << lane_id()) - 1ull));
-        if (slot < a.med_cap) a.med[slot] = rec;
+        const uint32_t slot = ms.base[which] + ms.used[which] + (uint32_t)__popcll(m & ((1ull << lane_id()) - 1ull));
+        if (slot < a.med_cap) a.med[(size_t)which * a.med_cap + slot] = rec;
         else atomicOr(&a.stats->flags, LIME_FLAG_OVERFLOW);
     }
-    ms.used += cnt;
+    ms.used[which] += cnt;
+}
+
+// len in 2..SMALL_MAX
+__device__ __forceinline__ void med_push(const ScanArgs &a, MedState &ms, bool on, uint64_t pos, uint32_t len)
+{
+    const uint64_t rec = pos | ((uint64_t)(len - 1u) << 48);
+    med_push1(a, ms, 0u, on && len <= 8u, rec);
+    if (__ballot(on && len > 8u)) med_push1(a, ms, 1u, on && len > 8u, rec);
 }
 
 // ---- cluster scoring ----------------------------------------------------------------------
@@ -328,7 +336,7 @@ __device__ __forceinline__ uint32_t score_small(LDS &L, const WgTables &T, UpdQu
     for (int i = 0; i < 4; ++i)
 #pragma unroll
         for (int j = i + 1; j < 4; ++j) dup |= (uint32_t)(d[i] == d[j]) & (uint32_t)((uint32_t)j < len);
-    med_push(a, ms, dup != 0u, (lo + p) | ((uint64_t)(len - 1u) << 48));
+    med_push1(a, ms, 0u, dup != 0u, (lo + p) | ((uint64_t)(len - 1u) << 48));
     uint32_t hits = 0, bad = 0;
     int pi = 0;
 #pragma unroll
@@ -463,7 +471,7 @@ __global__ __launch_bounds__(SCAN_WG) void k_scan(ScanArgs a)
     uint32_t win = blockIdx.x * (SCAN_WG / 64) + wave;
     if (win >= n_win) return;
     UpdQueue qu; qu.qr = L.q_read; qu.qg = L.q_gen; qu.n = 0;
-    MedState ms = {0u, MED_CHUNK};                         // no chunk reserved yet
+    MedState ms = {{0u, 0u}, {MED_CHUNK, MED_CHUNK}};      // no chunk reserved yet
     WinRegs regs;
     window_load<EBWT>(regs, a, (uint64_t)win * WIN);
     uint32_t acc_n = 0, acc_max = 0, acc_upd = 0;          // per-lane partial counters, reduced once at the end
@@ -574,7 +582,7 @@ __global__ __launch_bounds__(SCAN_WG) void k_scan(ScanArgs a)
                 const uint32_t e = ha ? 64u * lane + (uint32_t)__builtin_ctzll(ha) : c.e_suf;
                 const uint32_t len = act ? e - p : 0u;
                 acc_max = len > acc_max ? len : acc_max;
-                med_push(a, ms, act && len <= SMALL_MAX, (lo + p) | ((uint64_t)(len - 1u) << 48));
+                med_push(a, ms, act && len <= SMALL_MAX, lo + p, len);
                 const bool cD = act && len > SMALL_MAX;
                 if (__ballot(cD)) {                               // rare: one workgroup per such cluster later
                     if (cD) {
@@ -648,7 +656,7 @@ __global__ __launch_bounds__(SCAN_WG) void k_scan(ScanArgs a)
         if (a.ablate == 8) window_load<EBWT>(regs, a, (uint64_t)next * WIN);
         win = next;
     }
-    if (MODE == 0) { drain(qu, a); med_fill(a, ms); }
+    if (MODE == 0) { drain(qu, a); med_fill(a, ms, 0u); med_fill(a, ms, 1u); }
     if (MODE != 2) {
         const uint32_t tn = wave_sum(acc_n), tm = wave_max(acc_max), tu = wave_sum(acc_upd);
         if (lane == 0) {
@@ -789,39 +797,59 @@ __global__ __launch_bounds__(SCAN_WG) void k_score_list(ScanArgs a, const lime_c
 
 // =========================================================================================
 // k_score_med: the clusters the scan listed instead of scoring (5..SMALL_MAX symbols, or a
-// repeated document).  16 lanes per cluster, element i on sub-lane i, read straight from
-// global memory; XOR-ing the sub-lane with 1..15 shows every lane every other element.  With
-// all documents distinct each read lane scores each compatible genome it meets; a cluster with
-// a repeated document is staged in LDS and scored by the general routine.
+// repeated document).  G = 8 or 16 lanes per cluster (list 0: <= 8 symbols, list 1: longer),
+// element i on sub-lane i, read straight from global memory; XOR-ing the sub-lane with 1..G-1
+// shows every lane every other element of its cluster.  With all documents distinct each read
+// lane scores each compatible genome it meets; a cluster with a repeated document is staged in
+// LDS and scored by the general routine.
 // =========================================================================================
-template <int EBWT>
+template <int EBWT, int G>
 __global__ __launch_bounds__(SCAN_WG) void k_score_med(ScanArgs a)
 {
     __shared__ WgTables T;
-    __shared__ uint32_t s_da[SCAN_WG / 64][64];
-    __shared__ uint8_t s_fl[SCAN_WG / 64][64];
     __shared__ uint32_t s_qr[SCAN_WG / 64][QCAP], s_qg[SCAN_WG / 64][QCAP];
-    const uint32_t lane = lane_id(), wave = threadIdx.x >> 6, sub = lane & 15u, grp = lane >> 4;
+    constexpr uint32_t PER = 64u / G, WHICH = G == 8 ? 0u : 1u;
+    const uint32_t lane = lane_id(), wave = threadIdx.x >> 6, sub = lane & (G - 1u), grp = lane / G;
     tables_init(T);
     UpdQueue qu; qu.qr = s_qr[wave]; qu.qg = s_qg[wave]; qu.n = 0;
-    const uint32_t n = a.stats->n_med < a.med_cap ? a.stats->n_med : a.med_cap;
-    const uint32_t n_it = (n + 3u) / 4u, stride = gridDim.x * (SCAN_WG / 64);
-    const uint64_t gm = 0xFFFFull << (lane & 48u);
+    const uint64_t *med = a.med + (size_t)WHICH * a.med_cap;
+    const uint32_t n = a.stats->n_med[WHICH] < a.med_cap ? a.stats->n_med[WHICH] : a.med_cap;
+    const uint32_t n_it = (n + PER - 1u) / PER, stride = gridDim.x * (SCAN_WG / 64);
+    const uint64_t gm = (((1ull << (G - 1)) << 1) - 1ull) << (lane & ~(G - 1u));
     uint32_t acc_upd = 0;
-    for (uint32_t it = blockIdx.x * (SCAN_WG / 64) + wave; it < n_it; it += stride) {
-        const uint32_t idx = it * 4u + grp;
-        const uint64_t rec = idx < n ? a.med[idx] : 0ull;          // 0: empty slot
-        const uint64_t ps = rec & 0xFFFFFFFFFFFFull;
+    // software pipeline over the wave's iterations: the record of iteration i+2 and the elements
+    // of iteration i+1 are in flight while iteration i is scored
+    auto load_rec = [&](uint32_t it) -> uint64_t {
+        const uint32_t idx = it * PER + grp;
+        return (it < n_it && idx < n) ? med[idx] : 0ull;           // 0: empty slot
+    };
+    const uint32_t it0 = blockIdx.x * (SCAN_WG / 64) + wave;
+    uint64_t rec1 = load_rec(it0), rec2 = load_rec(it0 + stride);
+    uint32_t d1 = 0, b1 = 0;
+    {
+        const uint32_t l1 = rec1 ? (uint32_t)(rec1 >> 48) + 1u : 0u;
+        if (sub < l1) { const uint64_t q = (rec1 & 0xFFFFFFFFFFFFull) + sub; d1 = a.da[q]; if (EBWT) b1 = a.ebwt[q]; }
+    }
+    for (uint32_t it = it0; it < n_it; it += stride) {
+        const uint64_t rec = rec1;
+        const uint32_t d = d1, bb = b1;
+        rec1 = rec2;
+        rec2 = load_rec(it + 2u * stride);
+        d1 = 0; b1 = 0;
+        {
+            const uint32_t l1 = rec1 ? (uint32_t)(rec1 >> 48) + 1u : 0u;
+            if (sub < l1) { const uint64_t q = (rec1 & 0xFFFFFFFFFFFFull) + sub; d1 = a.da[q]; if (EBWT) b1 = a.ebwt[q]; }
+        }
+        if (__ballot(rec != 0ull) == 0ull || a.ablate == 6) continue;
         const uint32_t len = rec ? (uint32_t)(rec >> 48) + 1u : 0u;
         const bool have = sub < len;
-        const uint32_t d = have ? a.da[ps + sub] : 0u;
-        const uint32_t sy = (EBWT && have) ? T.symidx[a.ebwt[ps + sub]] : 0u;
+        const uint32_t sy = (EBWT && have) ? T.symidx[bb] : 0u;
         const bool isr = have && d < a.n_reads;
         const uint32_t f = have ? (sy | (isr ? F_READ : F_GEN)) : 0u;
         const uint32_t cs = EBWT ? T.compat[sy] : 0xFFFFu;
         uint32_t dup = 0, hits = 0, bad = 0;
-#pragma unroll 1
-        for (int r = 1; r < 16; ++r) {
+#pragma unroll
+        for (int r = 1; r < G; ++r) {
             const uint32_t pd = __shfl_xor(d, r), pf = __shfl_xor(f, r);
             const bool both = f && pf;
             dup |= (uint32_t)(both && pd == d);
@@ -835,25 +863,54 @@ __global__ __launch_bounds__(SCAN_WG) void k_score_med(ScanArgs a)
         if (__ballot(bad != 0u)) { if (bad && !gdup) atomicOr(&a.stats->flags, LIME_FLAG_DOCID); }
         if (gdup) hits = 0u;
         acc_upd += (uint32_t)__popc(hits);
-        // a lane can hit up to 15 times: to the queue in rounds of at most 4 per lane
+        // a lane can hit up to G-1 times: to the queue in rounds of at most 4 per lane
         while (__ballot(hits != 0u)) {
             if (qu.n > QCAP - 256u) drain(qu, a);
             uint32_t take = 0, hsel = 0;
-#pragma unroll 1
-            for (int r = 1; r < 16; ++r) if (((hits >> r) & 1u) && take < 4u) { hsel |= 1u << r; ++take; }
+#pragma unroll
+            for (int r = 1; r < G; ++r) { const uint32_t on = ((hits >> r) & 1u) & (uint32_t)(take < 4u); hsel |= on << r; take += on; }
             const uint32_t incl = wave_incl_scan(take);
             uint32_t slot = qu.n + incl - take;
-#pragma unroll 1
-            for (int r = 1; r < 16; ++r) {
+#pragma unroll
+            for (int r = 1; r < G; ++r) {
                 const uint32_t pd = __shfl_xor(d, r);
                 if ((hsel >> r) & 1u) { qu.qr[slot] = d; qu.qg[slot] = (pd - a.n_reads) | (1u << T_SHIFT); ++slot; }
             }
             qu.n += rl32(incl, 63);
             hits &= ~hsel;
         }
-        if (__ballot(gdup)) {                                      // repeated document: general routine from LDS
-            s_da[wave][lane] = d; s_fl[wave][lane] = (uint8_t)f;
-            acc_upd += cluster_general<EBWT>(s_da[wave], s_fl[wave], qu, a, gdup && sub == 0u, lane & 48u, len);
+        if (__ballot(gdup) && a.ablate != 7) {
+            // a repeated document somewhere in the group: the general score, still element-per-lane.
+            // Pass 1: is this element the first of its document, and the document's count / 16-bin
+            // histogram over the cluster (counts <= SMALL_MAX: no wrap, no saturation).  Pass 2: every
+            // first-occurrence read meets every first-occurrence genome once.
+            uint32_t earlier = 0, cnt = have ? 1u : 0u, hs[4] = {0u, 0u, 0u, 0u};
+            if (EBWT) hist_add(hs, sy, (uint32_t)have);
+#pragma unroll 1
+            for (int r = 1; r < G; ++r) {
+                const uint32_t pd = __shfl_xor(d, r), pf = __shfl_xor(f, r);
+                const uint32_t same = (uint32_t)(f && pf && pd == d);
+                earlier |= same & (uint32_t)((sub ^ (uint32_t)r) < sub);
+                cnt += same;
+                if (EBWT) hist_add(hs, pf & F_SYM, same);
+            }
+            const uint32_t lead = (uint32_t)(have && !earlier);
+#pragma unroll 1
+            for (int r = 1; r < G; ++r) {
+                const uint32_t pd = __shfl_xor(d, r), pf = __shfl_xor(f, r), pl = __shfl_xor(lead, r), pc = __shfl_xor(cnt, r);
+                uint32_t ph[4] = {0u, 0u, 0u, 0u};
+                if (EBWT) { ph[0] = __shfl_xor(hs[0], r); ph[1] = __shfl_xor(hs[1], r); ph[2] = __shfl_xor(hs[2], r); ph[3] = __shfl_xor(hs[3], r); }
+                const bool pair = gdup && lead && isr && pl && (pf & F_GEN);
+                if (__ballot(pair) == 0ull) continue;
+                uint32_t t = cnt < pc ? cnt : pc;
+                if (EBWT) {
+                    uint32_t h2[4], p2[4];           // only real pairs go through the (possibly slow) score
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) { h2[k] = pair ? hs[k] : 0u; p2[k] = pair ? ph[k] : 0u; }
+                    t = pair_score(h2, p2);
+                }
+                acc_upd += emit(qu, a, pair && t, d, pd, t);
+            }
         }
     }
     drain(qu, a);
@@ -1064,8 +1121,19 @@ void launch_score_list(int ebwt, const ScanArgs &a, const lime_cluster_t *list, 
 
 void launch_score_med(int ebwt, const ScanArgs &a, uint32_t blocks, hipStream_t st)
 {
-    if (ebwt) hipLaunchKernelGGL((k_score_med<1>), dim3(blocks), dim3(SCAN_WG), 0, st, a);
-    else      hipLaunchKernelGGL((k_score_med<0>), dim3(blocks), dim3(SCAN_WG), 0, st, a);
+    static uint32_t res[4] = {0, 0, 0, 0};           // workgroups that fit the device at once, per instantiation
+    if (!res[0]) {
+        res[0] = resident_blocks(k_score_med<1, 8>, SCAN_WG); res[1] = resident_blocks(k_score_med<1, 16>, SCAN_WG);
+        res[2] = resident_blocks(k_score_med<0, 8>, SCAN_WG); res[3] = resident_blocks(k_score_med<0, 16>, SCAN_WG);
+    }
+    (void)blocks;
+    if (ebwt) {
+        hipLaunchKernelGGL((k_score_med<1, 8>), dim3(res[0]), dim3(SCAN_WG), 0, st, a);
+        hipLaunchKernelGGL((k_score_med<1, 16>), dim3(res[1]), dim3(SCAN_WG), 0, st, a);
+    } else {
+        hipLaunchKernelGGL((k_score_med<0, 8>), dim3(res[2]), dim3(SCAN_WG), 0, st, a);
+        hipLaunchKernelGGL((k_score_med<0, 16>), dim3(res[3]), dim3(SCAN_WG), 0, st, a);
+    }
 }
 
 void launch_score_big(int ebwt, const ScanArgs &a, uint32_t *scratch, hipStream_t st)

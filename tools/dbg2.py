@@ -12,7 +12,7 @@ def run(name, lcp, da, eb, nr, ng):
             sim, gnc, gml = ctx.fused(lcp, da, e, nr, ng, 16)
             s, _ = ctx.stats()
             bad = int((sim != exp).sum())
-            print(f"{name} {tag}: clusters {nc} maxlen {ml} n_med {s.n_med} n_big {s.n_big} diffcells {bad} sum_gpu {int(sim.astype(np.int64).sum())} sum_exp {int(exp.astype(np.int64).sum())}")
+            print(f"{name} {tag}: clusters {nc} maxlen {ml} n_med {list(s.n_med)} n_big {s.n_big} diffcells {bad} sum_gpu {int(sim.astype(np.int64).sum())} sum_exp {int(exp.astype(np.int64).sum())}")
         except Exception as ex:
             print(name, tag, "ERR", ex)
 def mk(n, nr, ng, p_run, p_read, syms=b"ACGT"):

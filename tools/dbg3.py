@@ -15,7 +15,7 @@ for n in (192, 250, 256, 258, 300, 320, 384, 448, 576, 640):
     exp = O.score(da, None, cl, nr, ng)
     sim, gnc, gml = ctx.fused(lcp, da, None, nr, ng, 16)
     st, _ = ctx.stats()
-    print('   n_med', st.n_med, 'n_upd', st.n_updates, 'exp upd', int((exp>0).sum()))
+    print('   n_med', list(st.n_med), 'n_upd', st.n_updates, 'exp upd', int((exp>0).sum()))
     miss = []
     for ps, ln in cl:
         seg = da[ps:ps+ln]; r = seg[seg < nr][0]; g = seg[seg >= nr][0] - nr
