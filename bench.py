@@ -164,7 +164,7 @@ def main():
                        "symbols_total": n_total, "sharding": f"position ranges x{world}", "n_clusters": int(n_clusters),
                        "max_cluster_len": int(max_len), "table_updates": int(s.n_updates)},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "kernel": "k_tile<EBWT=1,score>",
+                         "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "kernel": "lime::k_scan<1, 0>",
                          "kernel_ms_avg": scan_ms, "launches_timed": launches,
                          "algorithmic_bytes_per_launch": BYTES_PER_SYMBOL * n_own},
         }
