@@ -135,7 +135,7 @@ __device__ __forceinline__ uint32_t emit(UpdQueue &q, const ScanArgs &a, bool on
 {
     if (q.n > QCAP - 64u) drain(q, a);
     const uint32_t g = gdoc - a.n_reads;
-    const bool bad = on && g >= a.n_refs;
+    const bool bad = on && (g >= a.n_refs || rdoc >= a.n_reads);
     if (__ballot(bad)) { if (bad) atomicOr(&a.stats->flags, LIME_FLAG_DOCID); }
     on = on && !bad;
     const uint64_t m = __ballot(on);
@@ -178,12 +178,10 @@ __device__ __forceinline__ void med_push1(const ScanArgs &a, MedState &ms, uint3
     ms.used[which] += cnt;
 }
 
-// len in 2..SMALL_MAX
+// record of list 0: pStart | (len-1) << 40   (len in 2..SMALL_MAX, pStart < 2^40)
 __device__ __forceinline__ void med_push(const ScanArgs &a, MedState &ms, bool on, uint64_t pos, uint32_t len)
 {
-    const uint64_t rec = pos | ((uint64_t)(len - 1u) << 48);
-    med_push1(a, ms, 0u, on && len <= 8u, rec);
-    if (__ballot(on && len > 8u)) med_push1(a, ms, 1u, on && len > 8u, rec);
+    med_push1(a, ms, 0u, on, pos | ((uint64_t)(len - 1u) << 40));
 }
 
 // ---- cluster scoring ----------------------------------------------------------------------
@@ -336,7 +334,7 @@ __device__ __forceinline__ uint32_t score_small(LDS &L, const WgTables &T, UpdQu
     for (int i = 0; i < 4; ++i)
 #pragma unroll
         for (int j = i + 1; j < 4; ++j) dup |= (uint32_t)(d[i] == d[j]) & (uint32_t)((uint32_t)j < len);
-    med_push1(a, ms, 0u, dup != 0u, (lo + p) | ((uint64_t)(len - 1u) << 48));
+    med_push(a, ms, dup != 0u, lo + p, len);
     uint32_t hits = 0, bad = 0;
     int pi = 0;
 #pragma unroll
@@ -567,7 +565,9 @@ __global__ __launch_bounds__(SCAN_WG) void k_scan(ScanArgs a)
         if (MODE == 0) {
             // ---- accepted heads by cluster length, still lane = word: the next head after an
             // accepted head b is at b+2, b+3 or b+4 for clusters of 2, 3, 4 symbols -------------
-            const uint64_t hn = shfl64(c.h, (int)(lane < 63u ? lane + 1u : lane));
+            uint64_t hn = 0ull;                                   // head mask of the next word, from the staged bytes
+            if (lane < WIN / 64) hn = *reinterpret_cast<const uint64_t *>(&L.hb[8u * lane + 8u]);
+            if (lane == WIN / 64 - 1u) hn &= 0xFFFFull;
             const uint64_t n2 = (c.h >> 2) | (hn << 62), n3 = (c.h >> 3) | (hn << 61), n4 = (c.h >> 4) | (hn << 60);
             const uint64_t as = c.ah & (n2 | n3 | n4);         // 2..4 symbols: scored here, one lane per cluster
             uint64_t al = c.ah & ~(n2 | n3 | n4);              // longer: measured below, scored by other kernels
@@ -656,7 +656,7 @@ __global__ __launch_bounds__(SCAN_WG) void k_scan(ScanArgs a)
         if (a.ablate == 8) window_load<EBWT>(regs, a, (uint64_t)next * WIN);
         win = next;
     }
-    if (MODE == 0) { drain(qu, a); med_fill(a, ms, 0u); med_fill(a, ms, 1u); }
+    if (MODE == 0) { drain(qu, a); med_fill(a, ms, 0u); }
     if (MODE != 2) {
         const uint32_t tn = wave_sum(acc_n), tm = wave_max(acc_max), tu = wave_sum(acc_upd);
         if (lane == 0) {
@@ -791,6 +791,131 @@ __global__ __launch_bounds__(SCAN_WG) void k_score_list(ScanArgs a, const lime_c
         if (cA) L.listA[(uint32_t)__popcll(mA & lt)] = item;
         acc_upd += score_lists<EBWT>(L, a, (uint32_t)__popcll(mA));
     }
+    const uint32_t tu = wave_sum(acc_upd);
+    if (lane == 0 && tu) atomicAdd(&a.stats->n_updates, (unsigned long long)tu);
+}
+
+// =========================================================================================
+// k_score_exp: the clusters the scan listed instead of scoring (5..SMALL_MAX symbols, or 2..4 with
+// a repeated document), with all documents distinct in the common case.  Load-balanced PAIR
+// EXPANSION: a wave takes 64 records (lane = cluster), stages their elements in LDS (one lane per
+// element), then gives every position pair i<j of every cluster to one lane: same kind -> the two
+// documents must differ (else the cluster is marked repeated); read x genome -> score 1 if the
+// symbols are compatible.  Task -> cluster search: clusters flag the slot of their first task in a
+// 64-task chunk, a ballot turns the flags into a mask, a popcount below the lane gives the
+// cluster.  Clusters with a repeated document go to list 1 for the general kernel.
+// =========================================================================================
+constexpr uint32_t EXP_ELEMS = 64u * SMALL_MAX;
+
+struct alignas(16) ExpLds {
+    uint32_t e_da[EXP_ELEMS];
+    uint8_t e_sy[EXP_ELEMS];
+    uint32_t c_eoff[64], c_tstart[64], c_meta[64];      // per compacted cluster: element offset, first task, length
+    uint32_t c_pslo[64], c_pshi[64];
+    uint8_t flag[64], dupf[64];
+    uint32_t q_read[QCAP], q_gen[QCAP];
+};
+
+// position pair (i < j) number t of a cluster of L symbols, rows i = 0.. of lengths L-1-i
+__host__ __device__ __forceinline__ void tri_decode(uint32_t t, uint32_t L, uint32_t &i, uint32_t &j)
+{
+    const float b = (float)(2u * L - 1u);
+    uint32_t r = (uint32_t)((b - sqrtf(b * b - 8.0f * (float)t)) * 0.5f);
+    // exact for L <= 16: fix the possible off-by-one of the float root
+    for (int k = 0; k < 3 && r > 0u && r * (2u * L - 1u - r) / 2u > t; ++k) --r;
+    for (int k = 0; k < 3 && r + 2u < L && (r + 1u) * (2u * L - 2u - r) / 2u <= t; ++k) ++r;
+    i = r; j = t - r * (2u * L - 1u - r) / 2u + r + 1u;
+}
+
+template <int EBWT>
+__global__ __launch_bounds__(SCAN_WG) void k_score_exp(ScanArgs a)
+{
+    __shared__ ExpLds lds[SCAN_WG / 64];
+    __shared__ WgTables T;
+    const uint32_t lane = lane_id(), wave = threadIdx.x >> 6;
+    ExpLds &L = lds[wave];
+    tables_init(T);
+    UpdQueue qu; qu.qr = L.q_read; qu.qg = L.q_gen; qu.n = 0;
+    const uint32_t n = a.stats->n_med[0] < a.med_cap ? a.stats->n_med[0] : a.med_cap;
+    const uint32_t n_b = (n + 63u) / 64u, stride = gridDim.x * (SCAN_WG / 64);
+    const uint64_t lt = (1ull << lane) - 1ull, le = lt | (1ull << lane);
+    uint32_t acc_upd = 0;
+    const uint32_t b0 = blockIdx.x * (SCAN_WG / 64) + wave;
+    uint64_t rec_next = (b0 < n_b && b0 * 64u + lane < n) ? a.med[b0 * 64u + lane] : 0ull;
+    for (uint32_t b = b0; b < n_b; b += stride) {
+        const uint64_t rec = rec_next;
+        { const uint32_t nb = b + stride; rec_next = (nb < n_b && nb * 64u + lane < n) ? a.med[nb * 64u + lane] : 0ull; }
+        const bool valid = rec != 0ull;
+        const uint64_t vm = __ballot(valid);
+        if (vm == 0ull) continue;
+        const uint32_t nc = (uint32_t)__popcll(vm), ci = (uint32_t)__popcll(vm & lt);    // compacted index
+        const uint64_t ps = rec & 0xFFFFFFFFFFull;
+        const uint32_t len = valid ? (uint32_t)((rec >> 40) & 15u) + 1u : 0u;
+        const uint32_t ntask = len * (len - 1u) / 2u;
+        const uint32_t eincl = wave_incl_scan(len), tincl = wave_incl_scan(ntask);
+        const uint32_t etotal = rl32(eincl, 63), ttotal = rl32(tincl, 63);
+        const uint32_t eoff = eincl - len, tstart = tincl - ntask;
+        if (valid) {
+            L.c_eoff[ci] = eoff; L.c_tstart[ci] = tstart; L.c_meta[ci] = len;
+            L.c_pslo[ci] = (uint32_t)ps; L.c_pshi[ci] = (uint32_t)(ps >> 32);
+        }
+        volatile uint8_t *dupf = L.dupf;                  // same remark as for `flag` below
+        dupf[lane] = 0;
+        // ---- stage the elements: one lane per element -------------------------------------------
+        // (lanes talk through `flag` with no barrier in between: volatile, or the compiler forwards a
+        //  lane's own store of 0 to its load and never sees the other lanes' stores)
+        volatile uint8_t *flag = L.flag;
+        for (uint32_t base = 0; base < etotal; base += 64u) {
+            flag[lane] = 0;
+            if (valid && eoff >= base && eoff < base + 64u) flag[eoff - base] = 1;
+            const uint64_t M = __ballot(flag[lane] != 0);
+            const uint32_t cb = (uint32_t)__popcll(__ballot(valid && eoff < base));
+            const uint32_t e = base + lane;
+            const uint32_t c = cb + (uint32_t)__popcll(M & le) - 1u;
+            if (e < etotal) {
+                const uint32_t k = e - L.c_eoff[c];
+                const uint64_t g = (((uint64_t)L.c_pshi[c] << 32) | L.c_pslo[c]) + k;
+                L.e_da[e] = a.da[g];
+                if (EBWT) L.e_sy[e] = T.symidx[a.ebwt[g]];
+            }
+        }
+        // ---- position pairs: pass 0 looks for a repeated document, pass 1 scores ------------------
+#pragma unroll 1
+        for (int pass = 0; pass < 2; ++pass) {
+            for (uint32_t base = 0; base < ttotal; base += 64u) {
+                flag[lane] = 0;
+                if (valid && ntask && tstart >= base && tstart < base + 64u) flag[tstart - base] = 1;
+                const uint64_t M = __ballot(flag[lane] != 0);
+                const uint32_t cb = (uint32_t)__popcll(__ballot(valid && tstart < base));
+                const uint32_t t = base + lane;
+                const bool on = t < ttotal;
+                const uint32_t c = on ? cb + (uint32_t)__popcll(M & le) - 1u : 0u;
+                const uint32_t cl = L.c_meta[c], eo = L.c_eoff[c];
+                uint32_t i = 0, j = 1;
+                if (on) tri_decode(t - L.c_tstart[c], cl, i, j);
+                const uint32_t di = L.e_da[eo + i], dj = L.e_da[eo + j];
+                const uint32_t ri = (uint32_t)(di < a.n_reads), rj = (uint32_t)(dj < a.n_reads);
+                if (pass == 0) {
+                    if (on && ri == rj && di == dj) dupf[c] = 1;
+                } else {
+                    uint32_t t1 = 1u;
+                    if (EBWT) t1 = (T.compat[L.e_sy[eo + i]] >> L.e_sy[eo + j]) & 1u;
+                    const bool hit = on && ri != rj && t1 && !dupf[c];
+                    acc_upd += emit(qu, a, hit, ri ? di : dj, ri ? dj : di, 1u);
+                }
+            }
+        }
+        // ---- clusters with a repeated document: to list 1 (general kernel) -------------------------
+        const bool rep = valid && dupf[ci] != 0;
+        if (__ballot(rep)) {
+            if (rep) {
+                const uint32_t k = atomicAdd(&a.stats->n_med[1], 1u);
+                if (k < a.med_cap) a.med[(size_t)a.med_cap + k] = ps | ((uint64_t)(len - 1u) << 48);
+                else atomicOr(&a.stats->flags, LIME_FLAG_OVERFLOW);
+            }
+        }
+    }
+    drain(qu, a);
     const uint32_t tu = wave_sum(acc_upd);
     if (lane == 0 && tu) atomicAdd(&a.stats->n_updates, (unsigned long long)tu);
 }
@@ -1123,15 +1248,15 @@ void launch_score_med(int ebwt, const ScanArgs &a, uint32_t blocks, hipStream_t 
 {
     static uint32_t res[4] = {0, 0, 0, 0};           // workgroups that fit the device at once, per instantiation
     if (!res[0]) {
-        res[0] = resident_blocks(k_score_med<1, 8>, SCAN_WG); res[1] = resident_blocks(k_score_med<1, 16>, SCAN_WG);
-        res[2] = resident_blocks(k_score_med<0, 8>, SCAN_WG); res[3] = resident_blocks(k_score_med<0, 16>, SCAN_WG);
+        res[0] = resident_blocks(k_score_exp<1>, SCAN_WG); res[1] = resident_blocks(k_score_med<1, 16>, SCAN_WG);
+        res[2] = resident_blocks(k_score_exp<0>, SCAN_WG); res[3] = resident_blocks(k_score_med<0, 16>, SCAN_WG);
     }
     (void)blocks;
     if (ebwt) {
-        hipLaunchKernelGGL((k_score_med<1, 8>), dim3(res[0]), dim3(SCAN_WG), 0, st, a);
+        hipLaunchKernelGGL((k_score_exp<1>), dim3(res[0]), dim3(SCAN_WG), 0, st, a);
         hipLaunchKernelGGL((k_score_med<1, 16>), dim3(res[1]), dim3(SCAN_WG), 0, st, a);
     } else {
-        hipLaunchKernelGGL((k_score_med<0, 8>), dim3(res[2]), dim3(SCAN_WG), 0, st, a);
+        hipLaunchKernelGGL((k_score_exp<0>), dim3(res[2]), dim3(SCAN_WG), 0, st, a);
         hipLaunchKernelGGL((k_score_med<0, 16>), dim3(res[3]), dim3(SCAN_WG), 0, st, a);
     }
 }
