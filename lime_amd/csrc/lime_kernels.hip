@@ -29,7 +29,7 @@ constexpr uint32_t F_READ = 0x20;
 constexpr uint32_t F_GEN = 0x40;
 
 constexpr uint32_t QCAP = 320;        // pending table updates per wave (a batch of 64 small clusters adds <= 256)
-constexpr uint32_t MED_CHUNK = 64;    // slots of a medium-cluster list a wave reserves at a time
+constexpr uint32_t MED_CHUNK = 8;     // slots of the repeated-document list a wave reserves at a time
 constexpr uint32_t T_SHIFT = 27;      // queue entry: genome | t << 27 (t <= SMALL_MAX < 32)
 constexpr uint32_t CAP_A = 256;       // clusters (2..SMALL_MAX symbols) a window can own
 constexpr uint32_t CAP_D = 256;       // of those, clusters with a repeated document (general routine)
@@ -41,6 +41,9 @@ struct alignas(16) WaveLds {
     uint8_t fl[NPOS];
     uint8_t hb[72];                   // head bit of every staged position of the scan (bytes 64..66: read-ahead)
     uint8_t rb[NPOS / 8 + 8];         // read bit of every staged position (byte k = positions 8k..8k+7)
+    uint16_t listM[104];              // scan: this window's clusters of 5..SMALL_MAX symbols (start | (len-1) << 12)
+    uint32_t m_tstart[64];            //       first pair-task of each of them
+    uint8_t m_flag[64], m_dup[64];
     uint64_t asw[8];                  // scan: per mask word, heads of the clusters scored in the window
     uint32_t prew[8];                 //       and how many such heads the words before hold
     uint16_t listA[CAP_A], listD[CAP_D];   // entry: start | (len-1) << 12
@@ -151,11 +154,11 @@ __device__ __forceinline__ uint32_t emit(UpdQueue &q, const ScanArgs &a, bool on
 // document): packed records pStart | (len-1) << 48.  Slots come from a chunk the wave reserved
 // with ONE atomic (a shared counter bumped per cluster would serialise the grid on one address);
 // the unused tail of a chunk is filled with empty (zero) records.
-struct MedState { uint32_t base[2], used[2]; };      // list 0: <= 8 symbols, list 1: 9..SMALL_MAX
+struct MedState { uint32_t base[2], used[2], cap[2]; };   // per list: the wave's reserved chunk, slots used, chunk size
 
 __device__ __forceinline__ void med_fill(const ScanArgs &a, const MedState &ms, uint32_t which)
 {
-    for (uint32_t i = ms.used[which] + lane_id(); i < MED_CHUNK; i += 64u)
+    for (uint32_t i = ms.used[which] + lane_id(); i < ms.cap[which]; i += 64u)
         if (ms.base[which] + i < a.med_cap) a.med[(size_t)which * a.med_cap + ms.base[which] + i] = 0ull;
 }
 
@@ -164,11 +167,12 @@ __device__ __forceinline__ void med_push1(const ScanArgs &a, MedState &ms, uint3
     const uint64_t m = __ballot(on);
     if (m == 0ull) return;
     const uint32_t cnt = (uint32_t)__popcll(m);
-    if (ms.used[which] + cnt > MED_CHUNK) {
+    if (ms.used[which] + cnt > ms.cap[which]) {
         med_fill(a, ms, which);
+        const uint32_t want = cnt > MED_CHUNK ? cnt : MED_CHUNK;
         uint32_t b = 0;
-        if (lane_id() == 0) b = atomicAdd(&a.stats->n_med[which], MED_CHUNK);
-        ms.base[which] = __builtin_amdgcn_readfirstlane(b); ms.used[which] = 0;
+        if (lane_id() == 0) b = atomicAdd(&a.stats->n_med[which], want);
+        ms.base[which] = __builtin_amdgcn_readfirstlane(b); ms.used[which] = 0; ms.cap[which] = want;
     }
     if (on) {
         const uint32_t slot = ms.base[which] + ms.used[which] + (uint32_t)__popcll(m & ((1ull << lane_id()) - 1ull));
@@ -178,10 +182,10 @@ __device__ __forceinline__ void med_push1(const ScanArgs &a, MedState &ms, uint3
     ms.used[which] += cnt;
 }
 
-// record of list 0: pStart | (len-1) << 40   (len in 2..SMALL_MAX, pStart < 2^40)
+// clusters with a repeated document: list 1, record pStart | (len-1) << 48   (len in 2..SMALL_MAX)
 __device__ __forceinline__ void med_push(const ScanArgs &a, MedState &ms, bool on, uint64_t pos, uint32_t len)
 {
-    med_push1(a, ms, 0u, on, pos | ((uint64_t)(len - 1u) << 40));
+    med_push1(a, ms, 1u, on, pos | ((uint64_t)(len - 1u) << 48));
 }
 
 // ---- cluster scoring ----------------------------------------------------------------------
@@ -368,6 +372,69 @@ __device__ __forceinline__ uint32_t score_small(LDS &L, const WgTables &T, UpdQu
     return nh;
 }
 
+// position pair (i < j) number t of a cluster of L symbols, rows i = 0.. of lengths L-1-i (L <= 16)
+__host__ __device__ __forceinline__ void tri_decode(uint32_t t, uint32_t L, uint32_t &i, uint32_t &j)
+{
+    const float b = (float)(2u * L - 1u);
+    uint32_t r = (uint32_t)((b - sqrtf(b * b - 8.0f * (float)t)) * 0.5f);
+    for (int k = 0; k < 3 && r > 0u && r * (2u * L - 1u - r) / 2u > t; ++k) --r;       // float root: off by one at most
+    for (int k = 0; k < 3 && r + 2u < L && (r + 1u) * (2u * L - 2u - r) / 2u <= t; ++k) ++r;
+    i = r; j = t - r * (2u * L - 1u - r) / 2u + r + 1u;
+}
+
+// Clusters of 5..SMALL_MAX symbols of the window (a few per window), scored by load-balanced PAIR
+// EXPANSION: every position pair i<j of every listed cluster goes to one lane.  Pass 0: a pair of
+// the same kind with equal documents marks the cluster as repeated (-> list for the general
+// kernel); pass 1: a read x genome pair of an unmarked cluster scores 1 if the two symbols are
+// compatible.  Task -> cluster: clusters flag the slot of their first task in the 64-task chunk, a
+// ballot turns the flags into a mask, the popcount below the lane gives the cluster.
+template <int EBWT, typename LDS>
+__device__ __forceinline__ uint32_t score_medium(LDS &L, const WgTables &T, UpdQueue &qu, MedState &ms, const ScanArgs &a,
+                                                 uint64_t lo, uint32_t nM)
+{
+    const uint32_t lane = lane_id();
+    const uint64_t lt = (1ull << lane) - 1ull, le = lt | (1ull << lane);
+    // lanes talk through these LDS bytes with no barrier in between: volatile, or the compiler
+    // forwards a lane's own store to its later load and never sees the other lanes' stores
+    volatile uint8_t *flag = L.m_flag, *dupf = L.m_dup;
+    uint32_t nupd = 0;
+    for (uint32_t c0 = 0; c0 < nM; c0 += 64u) {
+        const bool valid = c0 + lane < nM;
+        const uint32_t item = valid ? L.listM[c0 + lane] : 0u;
+        const uint32_t len = valid ? (item >> 12) + 1u : 0u;
+        const uint32_t ntask = len * (len - 1u) / 2u;
+        const uint32_t tincl = wave_incl_scan(ntask), tstart = tincl - ntask, ttotal = rl32(tincl, 63);
+        L.m_tstart[lane] = tstart;
+        dupf[lane] = 0;
+#pragma unroll 1
+        for (int pass = 0; pass < 2; ++pass) {
+            for (uint32_t base = 0; base < ttotal; base += 64u) {
+                flag[lane] = 0;
+                if (valid && tstart >= base && tstart < base + 64u) flag[tstart - base] = 1;
+                const uint64_t M = __ballot(flag[lane] != 0);
+                const uint32_t cb = (uint32_t)__popcll(__ballot(valid && tstart < base));
+                const uint32_t t = base + lane;
+                const bool on = t < ttotal;
+                const uint32_t c = on ? cb + (uint32_t)__popcll(M & le) - 1u : 0u;
+                const uint32_t it = L.listM[c0 + c], p = it & 0xFFFu, cl = (it >> 12) + 1u;
+                uint32_t i = 0, j = 1;
+                if (on) tri_decode(t - L.m_tstart[c], cl, i, j);
+                const uint32_t di = L.da[p + i], dj = L.da[p + j];
+                const uint32_t ri = (uint32_t)(di < a.n_reads), rj = (uint32_t)(dj < a.n_reads);
+                if (pass == 0) {
+                    if (on && ri == rj && di == dj) dupf[c] = 1;
+                } else {
+                    uint32_t t1 = 1u;
+                    if (EBWT) t1 = (T.compat[T.symidx[L.fl[p + i]]] >> T.symidx[L.fl[p + j]]) & 1u;
+                    nupd += emit(qu, a, on && ri != rj && t1 && !dupf[c], ri ? di : dj, ri ? dj : di, 1u);
+                }
+            }
+        }
+        med_push(a, ms, valid && dupf[lane] != 0, lo + (item & 0xFFFu), len);
+    }
+    return nupd;
+}
+
 // ---- window context, lane = 64-bit mask word (words 0..7 owned, word 8 = read-ahead) --------
 // Which heads open an accepted cluster.  Segments wholly inside a word are decided by
 // carry-ripple arithmetic on that word's masks; the segment headed at a word's LAST head may
@@ -469,7 +536,7 @@ __global__ __launch_bounds__(SCAN_WG) void k_scan(ScanArgs a)
     uint32_t win = blockIdx.x * (SCAN_WG / 64) + wave;
     if (win >= n_win) return;
     UpdQueue qu; qu.qr = L.q_read; qu.qg = L.q_gen; qu.n = 0;
-    MedState ms = {{0u, 0u}, {MED_CHUNK, MED_CHUNK}};      // no chunk reserved yet
+    MedState ms = {{0u, 0u}, {0u, 0u}, {0u, 0u}};          // no chunk reserved yet
     WinRegs regs;
     window_load<EBWT>(regs, a, (uint64_t)win * WIN);
     uint32_t acc_n = 0, acc_max = 0, acc_upd = 0;          // per-lane partial counters, reduced once at the end
@@ -570,7 +637,8 @@ __global__ __launch_bounds__(SCAN_WG) void k_scan(ScanArgs a)
             if (lane == WIN / 64 - 1u) hn &= 0xFFFFull;
             const uint64_t n2 = (c.h >> 2) | (hn << 62), n3 = (c.h >> 3) | (hn << 61), n4 = (c.h >> 4) | (hn << 60);
             const uint64_t as = c.ah & (n2 | n3 | n4);         // 2..4 symbols: scored here, one lane per cluster
-            uint64_t al = c.ah & ~(n2 | n3 | n4);              // longer: measured below, scored by other kernels
+            uint64_t al = c.ah & ~(n2 | n3 | n4);              // longer: measured below
+            uint32_t nM = 0;
             const uint32_t small_max = (c.ah & ~n2 & ~n3 & n4) ? 4u : ((c.ah & ~n2 & n3) ? 3u : ((c.ah & n2) ? 2u : 0u));
             acc_max = small_max > acc_max ? small_max : acc_max;
             while (__ballot(al != 0ull)) {
@@ -582,7 +650,10 @@ __global__ __launch_bounds__(SCAN_WG) void k_scan(ScanArgs a)
                 const uint32_t e = ha ? 64u * lane + (uint32_t)__builtin_ctzll(ha) : c.e_suf;
                 const uint32_t len = act ? e - p : 0u;
                 acc_max = len > acc_max ? len : acc_max;
-                med_push(a, ms, act && len <= SMALL_MAX, lo + p, len);
+                const bool cM = act && len <= SMALL_MAX;
+                const uint64_t mM = __ballot(cM);
+                if (cM) L.listM[nM + (uint32_t)__popcll(mM & lt)] = (uint16_t)(p | ((len - 1u) << 12));
+                nM += (uint32_t)__popcll(mM);
                 const bool cD = act && len > SMALL_MAX;
                 if (__ballot(cD)) {                               // rare: one workgroup per such cluster later
                     if (cD) {
@@ -616,6 +687,7 @@ __global__ __launch_bounds__(SCAN_WG) void k_scan(ScanArgs a)
                 const uint32_t p = on ? 64u * w + (uint32_t)__builtin_ctzll(x | (1ull << 63)) : 0u;
                 acc_upd += score_small<EBWT>(L, T, qu, ms, a, lo, on, p);
             }
+            if (nM) acc_upd += score_medium<EBWT>(L, T, qu, ms, a, lo, nM);
             }
         } else {
             // ---- count / emit: lane l walks the accepted heads among ITS 8 positions ---------------
@@ -656,7 +728,7 @@ __global__ __launch_bounds__(SCAN_WG) void k_scan(ScanArgs a)
         if (a.ablate == 8) window_load<EBWT>(regs, a, (uint64_t)next * WIN);
         win = next;
     }
-    if (MODE == 0) { drain(qu, a); med_fill(a, ms, 0u); }
+    if (MODE == 0) { drain(qu, a); med_fill(a, ms, 1u); }
     if (MODE != 2) {
         const uint32_t tn = wave_sum(acc_n), tm = wave_max(acc_max), tu = wave_sum(acc_upd);
         if (lane == 0) {
@@ -791,131 +863,6 @@ __global__ __launch_bounds__(SCAN_WG) void k_score_list(ScanArgs a, const lime_c
         if (cA) L.listA[(uint32_t)__popcll(mA & lt)] = item;
         acc_upd += score_lists<EBWT>(L, a, (uint32_t)__popcll(mA));
     }
-    const uint32_t tu = wave_sum(acc_upd);
-    if (lane == 0 && tu) atomicAdd(&a.stats->n_updates, (unsigned long long)tu);
-}
-
-// =========================================================================================
-// k_score_exp: the clusters the scan listed instead of scoring (5..SMALL_MAX symbols, or 2..4 with
-// a repeated document), with all documents distinct in the common case.  Load-balanced PAIR
-// EXPANSION: a wave takes 64 records (lane = cluster), stages their elements in LDS (one lane per
-// element), then gives every position pair i<j of every cluster to one lane: same kind -> the two
-// documents must differ (else the cluster is marked repeated); read x genome -> score 1 if the
-// symbols are compatible.  Task -> cluster search: clusters flag the slot of their first task in a
-// 64-task chunk, a ballot turns the flags into a mask, a popcount below the lane gives the
-// cluster.  Clusters with a repeated document go to list 1 for the general kernel.
-// =========================================================================================
-constexpr uint32_t EXP_ELEMS = 64u * SMALL_MAX;
-
-struct alignas(16) ExpLds {
-    uint32_t e_da[EXP_ELEMS];
-    uint8_t e_sy[EXP_ELEMS];
-    uint32_t c_eoff[64], c_tstart[64], c_meta[64];      // per compacted cluster: element offset, first task, length
-    uint32_t c_pslo[64], c_pshi[64];
-    uint8_t flag[64], dupf[64];
-    uint32_t q_read[QCAP], q_gen[QCAP];
-};
-
-// position pair (i < j) number t of a cluster of L symbols, rows i = 0.. of lengths L-1-i
-__host__ __device__ __forceinline__ void tri_decode(uint32_t t, uint32_t L, uint32_t &i, uint32_t &j)
-{
-    const float b = (float)(2u * L - 1u);
-    uint32_t r = (uint32_t)((b - sqrtf(b * b - 8.0f * (float)t)) * 0.5f);
-    // exact for L <= 16: fix the possible off-by-one of the float root
-    for (int k = 0; k < 3 && r > 0u && r * (2u * L - 1u - r) / 2u > t; ++k) --r;
-    for (int k = 0; k < 3 && r + 2u < L && (r + 1u) * (2u * L - 2u - r) / 2u <= t; ++k) ++r;
-    i = r; j = t - r * (2u * L - 1u - r) / 2u + r + 1u;
-}
-
-template <int EBWT>
-__global__ __launch_bounds__(SCAN_WG) void k_score_exp(ScanArgs a)
-{
-    __shared__ ExpLds lds[SCAN_WG / 64];
-    __shared__ WgTables T;
-    const uint32_t lane = lane_id(), wave = threadIdx.x >> 6;
-    ExpLds &L = lds[wave];
-    tables_init(T);
-    UpdQueue qu; qu.qr = L.q_read; qu.qg = L.q_gen; qu.n = 0;
-    const uint32_t n = a.stats->n_med[0] < a.med_cap ? a.stats->n_med[0] : a.med_cap;
-    const uint32_t n_b = (n + 63u) / 64u, stride = gridDim.x * (SCAN_WG / 64);
-    const uint64_t lt = (1ull << lane) - 1ull, le = lt | (1ull << lane);
-    uint32_t acc_upd = 0;
-    const uint32_t b0 = blockIdx.x * (SCAN_WG / 64) + wave;
-    uint64_t rec_next = (b0 < n_b && b0 * 64u + lane < n) ? a.med[b0 * 64u + lane] : 0ull;
-    for (uint32_t b = b0; b < n_b; b += stride) {
-        const uint64_t rec = rec_next;
-        { const uint32_t nb = b + stride; rec_next = (nb < n_b && nb * 64u + lane < n) ? a.med[nb * 64u + lane] : 0ull; }
-        const bool valid = rec != 0ull;
-        const uint64_t vm = __ballot(valid);
-        if (vm == 0ull) continue;
-        const uint32_t nc = (uint32_t)__popcll(vm), ci = (uint32_t)__popcll(vm & lt);    // compacted index
-        const uint64_t ps = rec & 0xFFFFFFFFFFull;
-        const uint32_t len = valid ? (uint32_t)((rec >> 40) & 15u) + 1u : 0u;
-        const uint32_t ntask = len * (len - 1u) / 2u;
-        const uint32_t eincl = wave_incl_scan(len), tincl = wave_incl_scan(ntask);
-        const uint32_t etotal = rl32(eincl, 63), ttotal = rl32(tincl, 63);
-        const uint32_t eoff = eincl - len, tstart = tincl - ntask;
-        if (valid) {
-            L.c_eoff[ci] = eoff; L.c_tstart[ci] = tstart; L.c_meta[ci] = len;
-            L.c_pslo[ci] = (uint32_t)ps; L.c_pshi[ci] = (uint32_t)(ps >> 32);
-        }
-        volatile uint8_t *dupf = L.dupf;                  // same remark as for `flag` below
-        dupf[lane] = 0;
-        // ---- stage the elements: one lane per element -------------------------------------------
-        // (lanes talk through `flag` with no barrier in between: volatile, or the compiler forwards a
-        //  lane's own store of 0 to its load and never sees the other lanes' stores)
-        volatile uint8_t *flag = L.flag;
-        for (uint32_t base = 0; base < etotal; base += 64u) {
-            flag[lane] = 0;
-            if (valid && eoff >= base && eoff < base + 64u) flag[eoff - base] = 1;
-            const uint64_t M = __ballot(flag[lane] != 0);
-            const uint32_t cb = (uint32_t)__popcll(__ballot(valid && eoff < base));
-            const uint32_t e = base + lane;
-            const uint32_t c = cb + (uint32_t)__popcll(M & le) - 1u;
-            if (e < etotal) {
-                const uint32_t k = e - L.c_eoff[c];
-                const uint64_t g = (((uint64_t)L.c_pshi[c] << 32) | L.c_pslo[c]) + k;
-                L.e_da[e] = a.da[g];
-                if (EBWT) L.e_sy[e] = T.symidx[a.ebwt[g]];
-            }
-        }
-        // ---- position pairs: pass 0 looks for a repeated document, pass 1 scores ------------------
-#pragma unroll 1
-        for (int pass = 0; pass < 2; ++pass) {
-            for (uint32_t base = 0; base < ttotal; base += 64u) {
-                flag[lane] = 0;
-                if (valid && ntask && tstart >= base && tstart < base + 64u) flag[tstart - base] = 1;
-                const uint64_t M = __ballot(flag[lane] != 0);
-                const uint32_t cb = (uint32_t)__popcll(__ballot(valid && tstart < base));
-                const uint32_t t = base + lane;
-                const bool on = t < ttotal;
-                const uint32_t c = on ? cb + (uint32_t)__popcll(M & le) - 1u : 0u;
-                const uint32_t cl = L.c_meta[c], eo = L.c_eoff[c];
-                uint32_t i = 0, j = 1;
-                if (on) tri_decode(t - L.c_tstart[c], cl, i, j);
-                const uint32_t di = L.e_da[eo + i], dj = L.e_da[eo + j];
-                const uint32_t ri = (uint32_t)(di < a.n_reads), rj = (uint32_t)(dj < a.n_reads);
-                if (pass == 0) {
-                    if (on && ri == rj && di == dj) dupf[c] = 1;
-                } else {
-                    uint32_t t1 = 1u;
-                    if (EBWT) t1 = (T.compat[L.e_sy[eo + i]] >> L.e_sy[eo + j]) & 1u;
-                    const bool hit = on && ri != rj && t1 && !dupf[c];
-                    acc_upd += emit(qu, a, hit, ri ? di : dj, ri ? dj : di, 1u);
-                }
-            }
-        }
-        // ---- clusters with a repeated document: to list 1 (general kernel) -------------------------
-        const bool rep = valid && dupf[ci] != 0;
-        if (__ballot(rep)) {
-            if (rep) {
-                const uint32_t k = atomicAdd(&a.stats->n_med[1], 1u);
-                if (k < a.med_cap) a.med[(size_t)a.med_cap + k] = ps | ((uint64_t)(len - 1u) << 48);
-                else atomicOr(&a.stats->flags, LIME_FLAG_OVERFLOW);
-            }
-        }
-    }
-    drain(qu, a);
     const uint32_t tu = wave_sum(acc_upd);
     if (lane == 0 && tu) atomicAdd(&a.stats->n_updates, (unsigned long long)tu);
 }
@@ -1246,19 +1193,11 @@ void launch_score_list(int ebwt, const ScanArgs &a, const lime_cluster_t *list, 
 
 void launch_score_med(int ebwt, const ScanArgs &a, uint32_t blocks, hipStream_t st)
 {
-    static uint32_t res[4] = {0, 0, 0, 0};           // workgroups that fit the device at once, per instantiation
-    if (!res[0]) {
-        res[0] = resident_blocks(k_score_exp<1>, SCAN_WG); res[1] = resident_blocks(k_score_med<1, 16>, SCAN_WG);
-        res[2] = resident_blocks(k_score_exp<0>, SCAN_WG); res[3] = resident_blocks(k_score_med<0, 16>, SCAN_WG);
-    }
+    static uint32_t res[2] = {0, 0};                 // workgroups that fit the device at once, per instantiation
+    if (!res[0]) { res[0] = resident_blocks(k_score_med<1, 16>, SCAN_WG); res[1] = resident_blocks(k_score_med<0, 16>, SCAN_WG); }
     (void)blocks;
-    if (ebwt) {
-        hipLaunchKernelGGL((k_score_exp<1>), dim3(res[0]), dim3(SCAN_WG), 0, st, a);
-        hipLaunchKernelGGL((k_score_med<1, 16>), dim3(res[1]), dim3(SCAN_WG), 0, st, a);
-    } else {
-        hipLaunchKernelGGL((k_score_exp<0>), dim3(res[2]), dim3(SCAN_WG), 0, st, a);
-        hipLaunchKernelGGL((k_score_med<0, 16>), dim3(res[3]), dim3(SCAN_WG), 0, st, a);
-    }
+    if (ebwt) hipLaunchKernelGGL((k_score_med<1, 16>), dim3(res[0]), dim3(SCAN_WG), 0, st, a);
+    else      hipLaunchKernelGGL((k_score_med<0, 16>), dim3(res[1]), dim3(SCAN_WG), 0, st, a);
 }
 
 void launch_score_big(int ebwt, const ScanArgs &a, uint32_t *scratch, hipStream_t st)
