@@ -317,14 +317,11 @@ __device__ __forceinline__ uint32_t score_lists(LDS &L, const ScanArgs &a, uint3
 // Hits go straight into the update queue at slots from one wave prefix sum.
 template <int EBWT, typename LDS>
 __device__ __forceinline__ uint32_t score_small(LDS &L, const WgTables &T, UpdQueue &qu, MedState &ms, const ScanArgs &a,
-                                                uint64_t lo, bool on, uint32_t p)
+                                                uint64_t lo, bool on, uint32_t p, uint32_t len)
 {
     if (qu.n > QCAP - 256u) drain(qu, a);
     const uint32_t kb = p >> 3, sh = p & 7u;
-    const uint32_t hbits = (uint32_t)L.hb[kb] | ((uint32_t)L.hb[kb + 1u] << 8) | ((uint32_t)L.hb[kb + 2u] << 16);
-    const uint32_t rbits = (uint32_t)L.rb[kb] | ((uint32_t)L.rb[kb + 1u] << 8) | ((uint32_t)L.rb[kb + 2u] << 16);
-    const uint32_t after = (hbits >> (sh + 1u)) | 0x8u;            // next head at distance <= 4 for this class
-    const uint32_t len = on ? (uint32_t)__builtin_ctz(after) + 1u : 0u;
+    const uint32_t rbits = (uint32_t)L.rb[kb] | ((uint32_t)L.rb[kb + 1u] << 8);
     const uint32_t rmask = (rbits >> sh) & ((1u << len) - 1u);
     uint32_t d[4], sy[4], cs[4];
 #pragma unroll
@@ -588,30 +585,21 @@ __global__ __launch_bounds__(SCAN_WG) void k_scan(ScanArgs a)
 
         // ---- window summary for the segment that is still open after the read-ahead ------------
         {
-            const uint64_t oh = lane < WIN / 64 ? c.h : 0ull, orr = lane < WIN / 64 ? c.r : 0ull, og = lane < WIN / 64 ? c.g : 0ull;
-            const uint64_t hw = __ballot(oh != 0ull);
+            const bool ow = lane < WIN / 64;
+            const uint64_t hw = __ballot(ow && c.h != 0ull), rw = __ballot(ow && c.r != 0ull), gw = __ballot(ow && c.g != 0ull);
             TileSummary sm;
-            sm.first_head = NONE32; sm.last_head = NONE32; sm.pre = 0; sm.suf = 0;
-            uint32_t fw = 64u, lw = 0u;
-            if (hw) {
-                fw = (uint32_t)__builtin_ctzll(hw);
-                lw = 63u - (uint32_t)__clzll((long long)hw);
-                const uint64_t hf0 = rl64(oh, fw), hl0 = rl64(oh, lw);
-                sm.first_head = fw * 64u + (uint32_t)__builtin_ctzll(hf0);
-                sm.last_head = lw * 64u + 63u - (uint32_t)__clzll((long long)hl0);
+            sm.first_head = NONE32; sm.last_head = NONE32;
+            uint32_t pre = (rw ? 1u : 0u) | (gw ? 2u : 0u), suf = 0u;       // no head: the whole window is "prefix"
+            if (hw) {                                                       // wave-uniform: scalar arithmetic
+                const uint32_t fw = (uint32_t)__builtin_ctzll(hw), lw = 63u - (uint32_t)__clzll((long long)hw);
+                const uint64_t hf0 = rl64(c.h, fw), hl0 = rl64(c.h, lw);
+                const uint32_t fb = (uint32_t)__builtin_ctzll(hf0), lb = 63u - (uint32_t)__clzll((long long)hl0);
+                sm.first_head = fw * 64u + fb; sm.last_head = lw * 64u + lb;
+                const uint64_t below = fb ? (~0ull >> (64u - fb)) : 0ull, from = ~0ull << lb;
+                const uint64_t wlow = (1ull << fw) - 1ull, whigh = (lw == 63u) ? 0ull : (~0ull << (lw + 1u));
+                pre = (((rw & wlow) || (rl64(c.r, fw) & below)) ? 1u : 0u) | (((gw & wlow) || (rl64(c.g, fw) & below)) ? 2u : 0u);
+                suf = (((rw & whigh) || (rl64(c.r, lw) & from)) ? 1u : 0u) | (((gw & whigh) || (rl64(c.g, lw) & from)) ? 2u : 0u);
             }
-            uint64_t pr = orr, pg = og, sr = 0ull, sg = 0ull;       // prefix [0, first_head); suffix [last_head, WIN)
-            if (hw) {
-                const uint32_t fb = sm.first_head & 63u, lb = sm.last_head & 63u;
-                const uint64_t below = fb ? (~0ull >> (64u - fb)) : 0ull;
-                const uint64_t from = ~0ull << lb;
-                pr = (lane < fw) ? orr : (lane == fw ? (orr & below) : 0ull);
-                pg = (lane < fw) ? og : (lane == fw ? (og & below) : 0ull);
-                sr = (lane > lw) ? orr : (lane == lw ? (orr & from) : 0ull);
-                sg = (lane > lw) ? og : (lane == lw ? (og & from) : 0ull);
-            }
-            const uint32_t pre = (__ballot(pr != 0ull) ? 1u : 0u) | (__ballot(pg != 0ull) ? 2u : 0u);
-            const uint32_t suf = (__ballot(sr != 0ull) ? 1u : 0u) | (__ballot(sg != 0ull) ? 2u : 0u);
             if (lane == 0 && MODE != 2) { sm.pre = pre; sm.suf = suf; a.summ[win] = sm; }
             // a run closed by padding instead of data while more data exists beyond the shard's
             // halo: the last data head in sight is owned and nothing but padding follows it
@@ -630,44 +618,9 @@ __global__ __launch_bounds__(SCAN_WG) void k_scan(ScanArgs a)
         if (a.ablate != 3) {
         acc_n += (uint32_t)__popcll(c.ah);
         if (MODE == 0) {
-            // ---- accepted heads by cluster length, still lane = word: the next head after an
-            // accepted head b is at b+2, b+3 or b+4 for clusters of 2, 3, 4 symbols -------------
-            uint64_t hn = 0ull;                                   // head mask of the next word, from the staged bytes
-            if (lane < WIN / 64) hn = *reinterpret_cast<const uint64_t *>(&L.hb[8u * lane + 8u]);
-            if (lane == WIN / 64 - 1u) hn &= 0xFFFFull;
-            const uint64_t n2 = (c.h >> 2) | (hn << 62), n3 = (c.h >> 3) | (hn << 61), n4 = (c.h >> 4) | (hn << 60);
-            const uint64_t as = c.ah & (n2 | n3 | n4);         // 2..4 symbols: scored here, one lane per cluster
-            uint64_t al = c.ah & ~(n2 | n3 | n4);              // longer: measured below
-            uint32_t nM = 0;
-            const uint32_t small_max = (c.ah & ~n2 & ~n3 & n4) ? 4u : ((c.ah & ~n2 & n3) ? 3u : ((c.ah & n2) ? 2u : 0u));
-            acc_max = small_max > acc_max ? small_max : acc_max;
-            while (__ballot(al != 0ull)) {
-                const bool act = al != 0ull;
-                const uint32_t b = act ? (uint32_t)__builtin_ctzll(al) : 0u;
-                al &= al - 1ull;
-                const uint32_t p = 64u * lane + b;
-                const uint64_t ha = (b == 63u) ? 0ull : (c.h & (~0ull << (b + 1u)));
-                const uint32_t e = ha ? 64u * lane + (uint32_t)__builtin_ctzll(ha) : c.e_suf;
-                const uint32_t len = act ? e - p : 0u;
-                acc_max = len > acc_max ? len : acc_max;
-                const bool cM = act && len <= SMALL_MAX;
-                const uint64_t mM = __ballot(cM);
-                if (cM) L.listM[nM + (uint32_t)__popcll(mM & lt)] = (uint16_t)(p | ((len - 1u) << 12));
-                nM += (uint32_t)__popcll(mM);
-                const bool cD = act && len > SMALL_MAX;
-                if (__ballot(cD)) {                               // rare: one workgroup per such cluster later
-                    if (cD) {
-                        if (len > LIME_MAX_CLUSTER) atomicOr(&a.stats->flags, LIME_FLAG_MAXLEN);
-                        else {
-                            const uint32_t k = atomicAdd(&a.stats->n_big, 1u);
-                            if (k < a.big_cap) { a.big[k].pStart = lo + p; a.big[k].len = len; }
-                        }
-                    }
-                }
-            }
-            // ---- hand the small clusters to lanes: lane t takes the t-th set bit of `as` -------
+            // ---- hand the accepted heads to lanes: lane t takes the t-th set bit of `ah` ------------
             if (a.ablate != 4) {
-            const uint32_t cnt = (uint32_t)__popcll(as);
+            const uint32_t cnt = (uint32_t)__popcll(c.ah);
             uint32_t incl = cnt;
             incl += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)incl, 0x111, 0xF, 0xF, false);
             incl += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)incl, 0x112, 0xF, 0xF, false);
@@ -675,7 +628,8 @@ __global__ __launch_bounds__(SCAN_WG) void k_scan(ScanArgs a)
             const uint32_t pre = incl - cnt, total = rl32(incl, 7);
             const uint32_t p1 = rl32(pre, 1), p2 = rl32(pre, 2), p3 = rl32(pre, 3), p4 = rl32(pre, 4),
                            p5 = rl32(pre, 5), p6 = rl32(pre, 6), p7 = rl32(pre, 7);
-            if (lane < WIN / 64) { L.asw[lane] = as; L.prew[lane] = pre; }     // looked up by word below
+            if (lane < WIN / 64) { L.asw[lane] = c.ah; L.prew[lane] = pre; }   // looked up by word below
+            uint32_t nM = 0;
             for (uint32_t base = 0; base < total; base += 64u) {
                 const uint32_t t = base + lane;
                 const bool on = t < total;
@@ -685,9 +639,38 @@ __global__ __launch_bounds__(SCAN_WG) void k_scan(ScanArgs a)
                 uint32_t j = on ? t - L.prew[w] : 0u;
                 while (__ballot(j != 0u)) { if (j) { x &= x - 1ull; --j; } }
                 const uint32_t p = on ? 64u * w + (uint32_t)__builtin_ctzll(x | (1ull << 63)) : 0u;
-                acc_upd += score_small<EBWT>(L, T, qu, ms, a, lo, on, p);
+                // cluster length: distance to the next head, from the staged head bytes
+                const uint32_t kb = p >> 3, sh = p & 7u;
+                const uint32_t hbits = (uint32_t)L.hb[kb] | ((uint32_t)L.hb[kb + 1u] << 8) | ((uint32_t)L.hb[kb + 2u] << 16);
+                const uint32_t near = (hbits >> (sh + 1u)) & 0xFFFFu;
+                uint32_t len = on ? (uint32_t)__builtin_ctz(near | 0x10000u) + 1u : 0u;    // 17: farther than 16
+                if (__ballot(len > SMALL_MAX)) {                      // rare: walk the head bytes to the end of the run
+                    if (len > SMALL_MAX) {
+                        uint32_t q = p + 17u, e = WPOS;               // an accepted cluster closes before WPOS
+                        while (q < WPOS) {
+                            const uint32_t hbq = (uint32_t)L.hb[q >> 3] >> (q & 7u);
+                            if (hbq) { e = q + (uint32_t)__builtin_ctz(hbq); break; }
+                            q = (q | 7u) + 1u;
+                        }
+                        len = e - p;
+                        if (len > LIME_MAX_CLUSTER) atomicOr(&a.stats->flags, LIME_FLAG_MAXLEN);   // cannot happen inside a window
+                        else {
+                            const uint32_t k = atomicAdd(&a.stats->n_big, 1u);      // one workgroup per such cluster later
+                            if (k < a.big_cap) { a.big[k].pStart = lo + p; a.big[k].len = len; }
+                        }
+                    }
+                }
+                acc_max = len > acc_max ? len : acc_max;
+                const bool cM = on && len > 4u && len <= SMALL_MAX;
+                const uint64_t mM = __ballot(cM);
+                if (mM) {
+                    if (cM) L.listM[nM + (uint32_t)__popcll(mM & lt)] = (uint16_t)(p | ((len - 1u) << 12));
+                    nM += (uint32_t)__popcll(mM);
+                }
+                const bool sm4 = on && len <= 4u;
+                if (a.ablate != 10) acc_upd += score_small<EBWT>(L, T, qu, ms, a, lo, sm4, sm4 ? p : 0u, sm4 ? len : 0u);
             }
-            if (nM) acc_upd += score_medium<EBWT>(L, T, qu, ms, a, lo, nM);
+            if (nM && a.ablate != 10 && a.ablate != 11) acc_upd += score_medium<EBWT>(L, T, qu, ms, a, lo, nM);
             }
         } else {
             // ---- count / emit: lane l walks the accepted heads among ITS 8 positions ---------------
