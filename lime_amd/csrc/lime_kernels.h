@@ -7,7 +7,9 @@
 
 namespace lime {
 
-constexpr uint32_t WIN = 512;                // positions a wave owns per window (8 per lane)
+constexpr uint32_t WIN = 1024;               // positions a wave owns per window
+constexpr uint32_t PPL = WIN / 64;           // consecutive positions per lane (16)
+constexpr uint32_t NW = WIN / 64;            // 64-bit mask words per window
 constexpr uint32_t HALO = 16;                // read-ahead positions behind a window (>= SMALL_MAX)
 constexpr uint32_t WPOS = WIN + HALO;
 constexpr int SCAN_WG = 256;                 // 4 independent waves per workgroup of the scan kernels

@@ -34,18 +34,24 @@ constexpr uint32_t T_SHIFT = 27;      // queue entry: genome | t << 27 (t <= SMA
 constexpr uint32_t CAP_A = 256;       // clusters (2..SMALL_MAX symbols) a window can own
 constexpr uint32_t CAP_D = 256;       // of those, clusters with a repeated document (general routine)
 
+// LDS is written and read through differently typed pointers (bytes as u16/u64, words as uint4):
+// these may_alias types keep the compiler from reordering such accesses under type-based aliasing.
+typedef uint16_t __attribute__((may_alias)) u16a;
+typedef uint64_t __attribute__((may_alias)) u64a;
+typedef uint4 __attribute__((may_alias)) u4a;
+
 // LDS of ONE wave: the staged window and its work lists.  `da`/`fl` are sized by the kernel.
 template <uint32_t NPOS>
 struct alignas(16) WaveLds {
     uint32_t da[NPOS];
     uint8_t fl[NPOS];
-    uint8_t hb[72];                   // head bit of every staged position of the scan (bytes 64..66: read-ahead)
-    uint8_t rb[NPOS / 8 + 8];         // read bit of every staged position (byte k = positions 8k..8k+7)
-    uint16_t listM[104];              // scan: this window's clusters of 5..SMALL_MAX symbols (start | (len-1) << 12)
+    alignas(8) uint8_t hb[NPOS / 8 + 8];   // head bit of every staged position of the scan, same layout as rb (read as 64-bit words)
+    alignas(8) uint8_t rb[NPOS / 8 + 8];   // read bit of every staged position (byte k = positions 8k..8k+7)
+    uint16_t listM[WIN / 5 + 4];      // scan: this window's clusters of 5..SMALL_MAX symbols (start | (len-1) << 12)
     uint32_t m_tstart[64];            //       first pair-task of each of them
     uint8_t m_flag[64], m_dup[64];
-    uint64_t asw[8];                  // scan: per mask word, heads of the clusters scored in the window
-    uint32_t prew[8];                 //       and how many such heads the words before hold
+    alignas(8) uint64_t asw[NW];                 // scan: per mask word, heads of the clusters scored in the window
+    uint32_t prew[NW];                 //       and how many such heads the words before hold
     uint16_t listA[CAP_A], listD[CAP_D];   // entry: start | (len-1) << 12
     uint32_t q_read[QCAP], q_gen[QCAP];
 };
@@ -482,31 +488,39 @@ __device__ __forceinline__ WinCtx window_context(uint64_t h, uint64_t r, uint64_
     return c;
 }
 
-// ---- window loads: lane l holds positions [8l, 8l+8) of the window (2 x 16 B lcp, 2 x 16 B da,
-// 8 B ebwt) and position WIN + l of the read-ahead (lanes < HALO) ------------------------------
-struct WinRegs { uint32_t lv[8], dv[8], bv[2], hl, hd, hb; };
+// ---- window loads: lane l holds positions [PPL*l, PPL*l+PPL) of the window (PPL/4 x 16 B lcp, the
+// same of da, PPL bytes of ebwt) and position WIN + l of the read-ahead (lanes < HALO) ---------------
+struct WinRegs { uint32_t lv[PPL], dv[PPL], bv[PPL / 4], hl, hd, hb; };
 
 template <int EBWT>
 __device__ __forceinline__ void window_load(WinRegs &t, const ScanArgs &a, uint64_t lo)
 {
     const uint32_t lane = lane_id();
-    const uint64_t g = lo + 8u * lane;
-    t.bv[0] = 0u; t.bv[1] = 0u;
-    if (g + 8u <= a.n_avail) {
-        const uint4 l0 = *reinterpret_cast<const uint4 *>(a.lcp + g), l1 = *reinterpret_cast<const uint4 *>(a.lcp + g + 4);
-        const uint4 d0 = *reinterpret_cast<const uint4 *>(a.da + g), d1 = *reinterpret_cast<const uint4 *>(a.da + g + 4);
-        t.lv[0] = l0.x; t.lv[1] = l0.y; t.lv[2] = l0.z; t.lv[3] = l0.w; t.lv[4] = l1.x; t.lv[5] = l1.y; t.lv[6] = l1.z; t.lv[7] = l1.w;
-        t.dv[0] = d0.x; t.dv[1] = d0.y; t.dv[2] = d0.z; t.dv[3] = d0.w; t.dv[4] = d1.x; t.dv[5] = d1.y; t.dv[6] = d1.z; t.dv[7] = d1.w;
-        if (EBWT) { const uint2 b = *reinterpret_cast<const uint2 *>(a.ebwt + g); t.bv[0] = b.x; t.bv[1] = b.y; }
+    const uint64_t g = lo + PPL * lane;
+#pragma unroll
+    for (int k = 0; k < (int)PPL / 4; ++k) t.bv[k] = 0u;
+    if (g + PPL <= a.n_avail) {
+#pragma unroll
+        for (int k = 0; k < (int)PPL / 4; ++k) {
+            const uint4 l4 = *reinterpret_cast<const uint4 *>(a.lcp + g + 4 * k);
+            const uint4 d4 = *reinterpret_cast<const uint4 *>(a.da + g + 4 * k);
+            t.lv[4 * k] = l4.x; t.lv[4 * k + 1] = l4.y; t.lv[4 * k + 2] = l4.z; t.lv[4 * k + 3] = l4.w;
+            t.dv[4 * k] = d4.x; t.dv[4 * k + 1] = d4.y; t.dv[4 * k + 2] = d4.z; t.dv[4 * k + 3] = d4.w;
+        }
+        if (EBWT) {
+            const uint4 b = *reinterpret_cast<const uint4 *>(a.ebwt + g);
+            t.bv[0] = b.x; t.bv[1] = b.y; t.bv[2] = b.z; t.bv[3] = b.w;
+        }
     } else {
 #pragma unroll 1
-        for (int j = 0; j < 8; ++j) {
+        for (int j = 0; j < (int)PPL; ++j) {
             const bool ok = g + j < a.n_avail;
             const uint32_t l = ok ? a.lcp[g + j] : 0u, d = ok ? a.da[g + j] : 0u;
             const uint32_t b = (EBWT && ok) ? a.ebwt[g + j] : 0u;
 #pragma unroll
-            for (int k = 0; k < 8; ++k) if (k == j) { t.lv[k] = l; t.dv[k] = d; }
-            if (j < 4) t.bv[0] |= b << (8 * j); else t.bv[1] |= b << (8 * (j - 4));
+            for (int k = 0; k < (int)PPL; ++k) if (k == j) { t.lv[k] = l; t.dv[k] = d; }
+#pragma unroll
+            for (int k = 0; k < (int)PPL / 4; ++k) if (k == (j >> 2)) t.bv[k] |= b << (8 * (j & 3));
         }
     }
     const uint64_t hp = lo + WIN + lane;
@@ -542,30 +556,32 @@ __global__ __launch_bounds__(SCAN_WG) void k_scan(ScanArgs a)
         const uint64_t lo = (uint64_t)win * WIN;
         const uint64_t own_lim = a.n_own > lo ? (a.n_own - lo < WIN ? a.n_own - lo : (uint64_t)WIN) : 0ull;
         const uint64_t lim = a.n_avail - lo;               // valid positions of the window + read-ahead: [0, lim)
-        // ---- stage the window in LDS: documents, raw ebwt bytes, and per lane one byte each of
-        // head bits (lcp < alpha) and read bits (da < n_reads) of its 8 positions -------------------
+        // ---- stage the window in LDS: documents, raw ebwt bytes, and per lane PPL bits each of
+        // head bits (lcp < alpha) and read bits (da < n_reads) of its positions ---------------------
         {
             uint32_t hb = 0, rb = 0;
 #pragma unroll
-            for (int j = 0; j < 8; ++j) {
+            for (int j = 0; j < (int)PPL; ++j) {
                 hb |= (uint32_t)(regs.lv[j] < a.alpha) << j;
                 rb |= (uint32_t)(regs.dv[j] < a.n_reads) << j;
             }
             uint32_t hh = (uint32_t)(lane < HALO && regs.hl < a.alpha), hr = (uint32_t)(lane < HALO && regs.hd < a.n_reads);
             if (lim < WPOS) {                              // the end of the data: padding closes runs, is nobody's
-                const uint32_t v0 = 8u * lane;
-                const uint32_t vb = lim >= v0 + 8u ? 255u : (lim <= v0 ? 0u : ((1u << (lim - v0)) - 1u));
-                hb |= ~vb & 255u; rb &= vb;
+                const uint32_t v0 = PPL * lane;
+                const uint32_t vb = lim >= v0 + PPL ? ((1u << PPL) - 1u) : (lim <= v0 ? 0u : ((1u << (lim - v0)) - 1u));
+                hb |= ~vb & ((1u << PPL) - 1u); rb &= vb;
                 const bool hv = WIN + lane < lim;
                 hh = (uint32_t)(lane < HALO && (!hv || regs.hl < a.alpha)); hr = hr & (uint32_t)hv;
             }
-            *reinterpret_cast<uint4 *>(&L.da[8u * lane]) = make_uint4(regs.dv[0], regs.dv[1], regs.dv[2], regs.dv[3]);
-            *reinterpret_cast<uint4 *>(&L.da[8u * lane + 4u]) = make_uint4(regs.dv[4], regs.dv[5], regs.dv[6], regs.dv[7]);
-            if (EBWT) *reinterpret_cast<uint2 *>(&L.fl[8u * lane]) = make_uint2(regs.bv[0], regs.bv[1]);
-            L.hb[lane] = (uint8_t)hb; L.rb[lane] = (uint8_t)rb;
+#pragma unroll
+            for (int k = 0; k < (int)PPL / 4; ++k)
+                *reinterpret_cast<u4a *>(&L.da[PPL * lane + 4 * k]) = make_uint4(regs.dv[4 * k], regs.dv[4 * k + 1], regs.dv[4 * k + 2], regs.dv[4 * k + 3]);
+            if (EBWT) *reinterpret_cast<u4a *>(&L.fl[PPL * lane]) = make_uint4(regs.bv[0], regs.bv[1], regs.bv[2], regs.bv[3]);
+            *reinterpret_cast<u16a *>(&L.hb[2u * lane]) = (uint16_t)hb;
+            *reinterpret_cast<u16a *>(&L.rb[2u * lane]) = (uint16_t)rb;
             if (lane < HALO) { L.da[WIN + lane] = regs.hd; if (EBWT) L.fl[WIN + lane] = (uint8_t)regs.hb; }
             const uint64_t H8 = __ballot(hh != 0u), R8 = __ballot(hr != 0u);
-            if (lane < 3u) { L.hb[64u + lane] = (uint8_t)(H8 >> (8u * lane)); L.rb[64u + lane] = (uint8_t)(R8 >> (8u * lane)); }
+            if (lane < 3u) { L.hb[WIN / 8 + lane] = (uint8_t)(H8 >> (8u * lane)); L.rb[WIN / 8 + lane] = (uint8_t)(R8 >> (8u * lane)); }
         }
         // ---- the next window's loads go out now and land while this one is processed ----------
         const uint32_t next = win + stride;
@@ -574,8 +590,8 @@ __global__ __launch_bounds__(SCAN_WG) void k_scan(ScanArgs a)
         // ---- masks with lane = word: bytes of 8 lanes make one 64-bit word (word 8: read-ahead) --
         uint64_t h = 0ull, r = 0ull, g = 0ull;
         if (lane <= WIN / 64) {
-            h = *reinterpret_cast<const uint64_t *>(&L.hb[8u * lane]);
-            r = *reinterpret_cast<const uint64_t *>(&L.rb[8u * lane]);
+            h = *reinterpret_cast<const u64a *>(&L.hb[8u * lane]);
+            r = *reinterpret_cast<const u64a *>(&L.rb[8u * lane]);
             const uint64_t wl = 64ull * lane;
             const uint64_t v = lim >= wl + 64u ? ~0ull : (lim <= wl ? 0ull : ((1ull << (lim - wl)) - 1ull));
             g = v & ~r;
@@ -625,16 +641,19 @@ __global__ __launch_bounds__(SCAN_WG) void k_scan(ScanArgs a)
             incl += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)incl, 0x111, 0xF, 0xF, false);
             incl += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)incl, 0x112, 0xF, 0xF, false);
             incl += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)incl, 0x114, 0xF, 0xF, false);
-            const uint32_t pre = incl - cnt, total = rl32(incl, 7);
-            const uint32_t p1 = rl32(pre, 1), p2 = rl32(pre, 2), p3 = rl32(pre, 3), p4 = rl32(pre, 4),
-                           p5 = rl32(pre, 5), p6 = rl32(pre, 6), p7 = rl32(pre, 7);
-            if (lane < WIN / 64) { L.asw[lane] = c.ah; L.prew[lane] = pre; }   // looked up by word below
+            incl += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)incl, 0x118, 0xF, 0xF, false);
+            const uint32_t pre = incl - cnt, total = rl32(incl, NW - 1);
+            uint32_t pk[NW];                                   // clusters before each word (wave-uniform)
+#pragma unroll
+            for (int k = 1; k < (int)NW; ++k) pk[k] = rl32(pre, k);
+            if (lane < NW) { L.asw[lane] = c.ah; L.prew[lane] = pre; }         // looked up by word below
             uint32_t nM = 0;
             for (uint32_t base = 0; base < total; base += 64u) {
                 const uint32_t t = base + lane;
                 const bool on = t < total;
-                const uint32_t w = (uint32_t)(t >= p1) + (uint32_t)(t >= p2) + (uint32_t)(t >= p3) + (uint32_t)(t >= p4) +
-                                   (uint32_t)(t >= p5) + (uint32_t)(t >= p6) + (uint32_t)(t >= p7);
+                uint32_t w = 0;
+#pragma unroll
+                for (int k = 1; k < (int)NW; ++k) w += (uint32_t)(t >= pk[k]);
                 uint64_t x = L.asw[w];
                 uint32_t j = on ? t - L.prew[w] : 0u;
                 while (__ballot(j != 0u)) { if (j) { x &= x - 1ull; --j; } }
@@ -674,10 +693,10 @@ __global__ __launch_bounds__(SCAN_WG) void k_scan(ScanArgs a)
             }
         } else {
             // ---- count / emit: lane l walks the accepted heads among ITS 8 positions ---------------
-            const uint32_t w = lane >> 3, o = lane & 7u;
+            const uint32_t w = (PPL * lane) >> 6, o = (PPL * lane) & 63u;
             const uint64_t AHw = shfl64(c.ah, (int)w), Hw = shfl64(c.h, (int)w);
             const uint32_t e_suf = __shfl(c.e_suf, (int)w);
-            uint32_t ahb = (uint32_t)(AHw >> (8u * o)) & 255u;
+            uint32_t ahb = (uint32_t)(AHw >> o) & ((1u << PPL) - 1u);
             const uint32_t my_n = (uint32_t)__popc(ahb);
             const uint32_t x = wave_incl_scan(my_n);
             uint32_t rank = x - my_n;
@@ -687,7 +706,7 @@ __global__ __launch_bounds__(SCAN_WG) void k_scan(ScanArgs a)
                 const bool act = ahb != 0u;
                 const uint32_t b = act ? (uint32_t)__builtin_ctz(ahb) : 0u;
                 ahb &= ahb - 1u;
-                const uint32_t bit = 8u * o + b, p = 64u * w + bit;
+                const uint32_t bit = o + b, p = 64u * w + bit;
                 const uint64_t ha = (bit == 63u) ? 0ull : (Hw & (~0ull << (bit + 1u)));
                 const uint32_t e = ha ? 64u * w + (uint32_t)__builtin_ctzll(ha) : e_suf;
                 const uint32_t len = act ? e - p : 0u;
@@ -838,7 +857,7 @@ __global__ __launch_bounds__(SCAN_WG) void k_score_list(ScanArgs a, const lime_c
             f |= (d < a.n_reads) ? F_READ : F_GEN;
             L.da[i] = d; L.fl[i] = (uint8_t)f;
             const uint64_t rm = __ballot(d < a.n_reads && i0 + lane < total);
-            if (lane == 0) *reinterpret_cast<uint64_t *>(&L.rb[i0 >> 3]) = rm;
+            if (lane == 0) *reinterpret_cast<u64a *>(&L.rb[i0 >> 3]) = rm;
         }
         const bool cA = len32 >= 2u;
         const uint16_t item = (uint16_t)(my_off | ((len32 - 1u) << 12));
