@@ -152,7 +152,7 @@ def main():
         tfile = os.path.join(ROOT, "profiles", "traffic.json")     # rocprofv3 --pmc result, see DESIGN.md
         if os.path.exists(tfile) and args.n == N_PER_GPU and args.mode == 0:
             try:
-                traffic = json.load(open(tfile)).get("k_tile_hbm_bytes_per_launch")
+                traffic = json.load(open(tfile)).get("hbm_bytes_per_launch")
             except Exception:
                 traffic = None
         out = {

@@ -56,6 +56,39 @@ struct alignas(16) WaveLds {
     uint32_t q_read[QCAP], q_gen[QCAP];
 };
 
+#ifdef LIME_PHASE_TIMING     // debug build: per-wave cycle counts of the scan's phases, printed by a few waves
+#define PT_DECL uint64_t pt_t = __builtin_readcyclecounter(), pt_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0}, pt_m[4] = {0, 0, 0, 0}; uint32_t pt_nwin = 0;
+#define PT(i) { const uint64_t n_ = __builtin_readcyclecounter(); pt_acc[i] += n_ - pt_t; pt_t = n_; }
+#define PT_WAITVM asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#else
+#define PT_DECL
+#define PT(i)
+#define PT_WAITVM
+#endif
+
+// LDS of one wave of k_scan (kept small: it bounds the waves a CU holds)
+#ifndef LIME_SCANK_WG
+#define LIME_SCANK_WG 256
+#endif
+#ifndef LIME_SCAN_WAVES
+#define LIME_SCAN_WAVES 3
+#endif
+constexpr int SCANK_WG = LIME_SCANK_WG;   // threads per workgroup of k_scan; its waves work independently
+constexpr uint32_t QCAP_SCAN = 256;   // >= the 256 hits one batch of 64 clusters of <= 4 symbols can add
+struct alignas(16) ScanLds {
+    uint32_t da[WPOS];
+    uint8_t fl[WPOS];
+    alignas(8) uint8_t hb[WPOS / 8 + 8];
+    alignas(8) uint8_t rb[WPOS / 8 + 8];
+    uint16_t listM[WIN / 5 + 4];
+    uint16_t m_tstart[64];            // < 64 clusters x 120 pairs
+    uint8_t m_flag[64], m_dup[64];
+    alignas(8) uint64_t asw[NW];
+    uint32_t prew[NW];
+    uint32_t q_read[QCAP_SCAN], q_gen[QCAP_SCAN];
+    uint32_t f_read[256], f_gen[256];   // entries whose compare-and-swap is in flight
+};
+
 __device__ __forceinline__ uint32_t lane_id() { return threadIdx.x & 63u; }
 __device__ __forceinline__ uint64_t brev64(uint64_t x) { return __builtin_bitreverse64(x); }
 __device__ __forceinline__ uint32_t rl32(uint32_t v, uint32_t l) { return (uint32_t)__builtin_amdgcn_readlane((int)v, (int)l); }
@@ -99,7 +132,7 @@ struct WgTables { uint8_t symidx[256]; uint16_t compat[16]; };
 __device__ __forceinline__ void tables_init(WgTables &T)
 {
     const uint32_t t = threadIdx.x;
-    if (t < 256u) T.symidx[t] = (uint8_t)sym_index(t);
+    for (uint32_t b = t; b < 256u; b += blockDim.x) T.symidx[b] = (uint8_t)sym_index(b);
     if (t < 16u) {
         uint32_t m = 0;
         for (uint32_t b = 0; b < 16u; ++b) m |= iupac_match(t, b) << b;
@@ -127,22 +160,107 @@ __device__ __forceinline__ void sim_add(uint8_t *sim, uint64_t cell, uint32_t t)
 
 // ---- table updates of a wave: queued in its LDS ring, applied together so that the round
 // trips of the compare-and-swaps overlap instead of following one another -----------------
-struct UpdQueue { uint32_t *qr, *qg; uint32_t n; };
+struct UpdQueue { uint32_t *qr, *qg; uint32_t n, cap;
+    // split-phase mode (k_scan): the compare-and-swaps of a drain are only ISSUED; their results
+    // are looked at by the next drain, so a wave never waits for the round trip to the table.
+    // Lane l owns in-flight slots 64 j + l (j < 4): entry kept in fr/fg, value the CAS expected
+    // and value it returned in registers.
+    bool async = false;
+    uint32_t *fr = nullptr, *fg = nullptr;
+    uint32_t f_old[4], f_exp[4], f_pend = 0;
+#ifdef LIME_PHASE_TIMING
+    uint64_t t_drain = 0; uint32_t n_drain = 0;
+#endif
+};
+
+// Split-phase drain: (1) settle the slots issued last time: a CAS that found the expected word is
+// done, one that lost keeps its slot with the word it saw; (2) free slots take entries from the
+// queue's tail; (3) every occupied slot issues its CAS.  Entries that found no free slot stay
+// queued (q.n > 0 afterwards): callers loop while they need more room.
+__device__ __forceinline__ void drain_async(UpdQueue &q, const ScanArgs &a)
+{
+    const uint32_t lane = lane_id();
+    const uint64_t lt = (1ull << lane) - 1ull;
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+        if ((q.f_pend >> j) & 1u) {
+            if (q.f_old[j] == q.f_exp[j]) q.f_pend &= ~(1u << j);
+            else q.f_exp[j] = q.f_old[j];
+        }
+    uint32_t n = q.n;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const bool fre = !((q.f_pend >> j) & 1u);
+        const uint64_t m = __ballot(fre);
+        const uint32_t r = (uint32_t)__popcll(m & lt), c = (uint32_t)__popcll(m);
+        if (fre && r < n) {
+            const uint32_t k = n - 1u - r;
+            q.fr[64u * (uint32_t)j + lane] = q.qr[k]; q.fg[64u * (uint32_t)j + lane] = q.qg[k];
+            q.f_exp[j] = 0u; q.f_pend |= 1u << j;
+        }
+        n -= c < n ? c : n;
+    }
+    q.n = n;
+    if (a.ablate == 5) { q.f_pend = 0; return; }
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+        if ((q.f_pend >> j) & 1u) {
+            const uint32_t gt = q.fg[64u * (uint32_t)j + lane];
+            const uint64_t cell = (uint64_t)q.fr[64u * (uint32_t)j + lane] * a.n_refs + (gt & ((1u << T_SHIFT) - 1u));
+            const uint32_t sh = (uint32_t)(cell & 3ull) * 8u, e = q.f_exp[j];
+            const uint32_t b = ((e >> sh) + (gt >> T_SHIFT)) & 255u;
+            q.f_old[j] = atomicCAS(reinterpret_cast<uint32_t *>(a.sim + (cell & ~3ull)), e, (e & ~(255u << sh)) | (b << sh));
+        }
+}
 
 __device__ __forceinline__ void drain(UpdQueue &q, const ScanArgs &a)
 {
+    if (q.async) { drain_async(q, a); return; }
+#ifdef LIME_PHASE_TIMING
+    const uint64_t t0 = __builtin_readcyclecounter();
+#endif
+    // four queue entries per lane and round: their compare-and-swaps are issued together (first
+    // try: word still zero, tables are sparse) and only the ones that lost are tried again
     if (a.ablate != 5)
-        for (uint32_t k = lane_id(); k < q.n; k += 64u) {
-            const uint32_t gt = q.qg[k];
-            sim_add(a.sim, (uint64_t)q.qr[k] * a.n_refs + (gt & ((1u << T_SHIFT) - 1u)), gt >> T_SHIFT);
+        for (uint32_t k0 = 0; k0 < q.n; k0 += 256u) {
+            uint32_t *w[4], sh[4], t[4], expect[4], pend = 0;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const uint32_t k = k0 + 64u * (uint32_t)j + lane_id();
+                const bool on = k < q.n;
+                const uint32_t gt = q.qg[on ? k : 0u];
+                const uint64_t cell = (uint64_t)q.qr[on ? k : 0u] * a.n_refs + (gt & ((1u << T_SHIFT) - 1u));
+                w[j] = reinterpret_cast<uint32_t *>(a.sim + (cell & ~3ull));
+                sh[j] = (uint32_t)(cell & 3ull) * 8u; t[j] = gt >> T_SHIFT; expect[j] = 0u;
+                pend |= (uint32_t)on << j;
+            }
+            while (__ballot(pend != 0u)) {
+                uint32_t old[4];
+#pragma unroll
+                for (int j = 0; j < 4; ++j)
+                    if ((pend >> j) & 1u) {
+                        const uint32_t b = ((expect[j] >> sh[j]) + t[j]) & 255u;
+                        old[j] = atomicCAS(w[j], expect[j], (expect[j] & ~(255u << sh[j])) | (b << sh[j]));
+                    }
+#pragma unroll
+                for (int j = 0; j < 4; ++j)
+                    if ((pend >> j) & 1u) {
+                        if (old[j] == expect[j]) pend &= ~(1u << j);
+                        else expect[j] = old[j];
+                    }
+            }
         }
     q.n = 0;
+#ifdef LIME_PHASE_TIMING
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    q.t_drain += __builtin_readcyclecounter() - t0; ++q.n_drain;
+#endif
 }
 
 // every active lane may add one update; all 64 lanes must call (wave ballots inside)
 __device__ __forceinline__ uint32_t emit(UpdQueue &q, const ScanArgs &a, bool on, uint32_t rdoc, uint32_t gdoc, uint32_t t)
 {
-    if (q.n > QCAP - 64u) drain(q, a);
+    while (q.n + 64u > q.cap) drain(q, a);
     const uint32_t g = gdoc - a.n_reads;
     const bool bad = on && (g >= a.n_refs || rdoc >= a.n_reads);
     if (__ballot(bad)) { if (bad) atomicOr(&a.stats->flags, LIME_FLAG_DOCID); }
@@ -303,7 +421,7 @@ __device__ __forceinline__ uint32_t cluster_general(const uint32_t *da, const ui
 template <int EBWT, typename LDS>
 __device__ __forceinline__ uint32_t score_lists(LDS &L, const ScanArgs &a, uint32_t nA)
 {
-    UpdQueue qu; qu.qr = L.q_read; qu.qg = L.q_gen; qu.n = 0;
+    UpdQueue qu; qu.qr = L.q_read; qu.qg = L.q_gen; qu.n = 0; qu.cap = QCAP;
     uint32_t nupd = 0, nD = 0;
     for (uint32_t k0 = 0; k0 < nA; k0 += 64u) nupd += cluster_pairs<EBWT>(L, qu, a, L.listA, nA, k0, nD);
     for (uint32_t k0 = 0; k0 < nD; k0 += 64u) {
@@ -325,7 +443,6 @@ template <int EBWT, typename LDS>
 __device__ __forceinline__ uint32_t score_small(LDS &L, const WgTables &T, UpdQueue &qu, MedState &ms, const ScanArgs &a,
                                                 uint64_t lo, bool on, uint32_t p, uint32_t len)
 {
-    if (qu.n > QCAP - 256u) drain(qu, a);
     const uint32_t kb = p >> 3, sh = p & 7u;
     const uint32_t rbits = (uint32_t)L.rb[kb] | ((uint32_t)L.rb[kb + 1u] << 8);
     const uint32_t rmask = (rbits >> sh) & ((1u << len) - 1u);
@@ -357,7 +474,8 @@ __device__ __forceinline__ uint32_t score_small(LDS &L, const WgTables &T, UpdQu
         }
     if (__ballot(bad != 0u)) { if (bad) atomicOr(&a.stats->flags, LIME_FLAG_DOCID); }
     const uint32_t nh = (uint32_t)__popc(hits);
-    const uint32_t incl = wave_incl_scan(nh);
+    const uint32_t incl = wave_incl_scan(nh), total = rl32(incl, 63);
+    while (qu.n + total > qu.cap) drain(qu, a);              // total <= 4 per lane = 256 <= cap
     uint32_t slot = qu.n + incl - nh;
     pi = 0;
 #pragma unroll
@@ -371,7 +489,7 @@ __device__ __forceinline__ uint32_t score_small(LDS &L, const WgTables &T, UpdQu
                 ++slot;
             }
         }
-    qu.n += rl32(incl, 63);
+    qu.n += total;
     return nh;
 }
 
@@ -385,16 +503,21 @@ __host__ __device__ __forceinline__ void tri_decode(uint32_t t, uint32_t L, uint
     i = r; j = t - r * (2u * L - 1u - r) / 2u + r + 1u;
 }
 
-// Clusters of 5..SMALL_MAX symbols of the window (a few per window), scored by load-balanced PAIR
-// EXPANSION: every position pair i<j of every listed cluster goes to one lane.  Pass 0: a pair of
-// the same kind with equal documents marks the cluster as repeated (-> list for the general
-// kernel); pass 1: a read x genome pair of an unmarked cluster scores 1 if the two symbols are
-// compatible.  Task -> cluster: clusters flag the slot of their first task in the 64-task chunk, a
-// ballot turns the flags into a mask, the popcount below the lane gives the cluster.
+// Clusters of 5..SMALL_MAX symbols of the window (a few per window), scored by ROWS: every position
+// i of a listed cluster except its last goes to one lane, which compares it with the positions
+// j > i of the cluster (<= 15, all loads issued together).  Equal documents in a row mark the
+// cluster as repeated (-> list for the general kernel); otherwise a read x genome pair scores 1
+// if the two symbols are compatible.  Row -> cluster: clusters flag the slot of their first row
+// in the 64-row chunk, a ballot turns the flags into a mask, the popcount below the lane gives the
+// cluster.  A chunk normally holds all rows of the window: one pass; else a first pass over all
+// chunks settles the repeated-document marks before hits are emitted.
 template <int EBWT, typename LDS>
 __device__ __forceinline__ uint32_t score_medium(LDS &L, const WgTables &T, UpdQueue &qu, MedState &ms, const ScanArgs &a,
-                                                 uint64_t lo, uint32_t nM)
+                                                 uint64_t lo, uint32_t nM, uint64_t *ptm = nullptr)
 {
+#ifdef LIME_PHASE_TIMING
+    uint64_t pt_t = __builtin_readcyclecounter(); uint64_t *pt_acc = ptm;
+#endif
     const uint32_t lane = lane_id();
     const uint64_t lt = (1ull << lane) - 1ull, le = lt | (1ull << lane);
     // lanes talk through these LDS bytes with no barrier in between: volatile, or the compiler
@@ -405,12 +528,13 @@ __device__ __forceinline__ uint32_t score_medium(LDS &L, const WgTables &T, UpdQ
         const bool valid = c0 + lane < nM;
         const uint32_t item = valid ? L.listM[c0 + lane] : 0u;
         const uint32_t len = valid ? (item >> 12) + 1u : 0u;
-        const uint32_t ntask = len * (len - 1u) / 2u;
-        const uint32_t tincl = wave_incl_scan(ntask), tstart = tincl - ntask, ttotal = rl32(tincl, 63);
-        L.m_tstart[lane] = tstart;
+        const uint32_t nrow = valid ? len - 1u : 0u;
+        const uint32_t tincl = wave_incl_scan(nrow), tstart = tincl - nrow, ttotal = rl32(tincl, 63);
+        L.m_tstart[lane] = (uint16_t)tstart;
         dupf[lane] = 0;
 #pragma unroll 1
-        for (int pass = 0; pass < 2; ++pass) {
+        for (int pass = ttotal <= 64u ? 1 : 0; pass < 2; ++pass) {
+#pragma unroll 1
             for (uint32_t base = 0; base < ttotal; base += 64u) {
                 flag[lane] = 0;
                 if (valid && tstart >= base && tstart < base + 64u) flag[tstart - base] = 1;
@@ -420,20 +544,43 @@ __device__ __forceinline__ uint32_t score_medium(LDS &L, const WgTables &T, UpdQ
                 const bool on = t < ttotal;
                 const uint32_t c = on ? cb + (uint32_t)__popcll(M & le) - 1u : 0u;
                 const uint32_t it = L.listM[c0 + c], p = it & 0xFFFu, cl = (it >> 12) + 1u;
-                uint32_t i = 0, j = 1;
-                if (on) tri_decode(t - L.m_tstart[c], cl, i, j);
-                const uint32_t di = L.da[p + i], dj = L.da[p + j];
-                const uint32_t ri = (uint32_t)(di < a.n_reads), rj = (uint32_t)(dj < a.n_reads);
-                if (pass == 0) {
-                    if (on && ri == rj && di == dj) dupf[c] = 1;
-                } else {
-                    uint32_t t1 = 1u;
-                    if (EBWT) t1 = (T.compat[T.symidx[L.fl[p + i]]] >> T.symidx[L.fl[p + j]]) & 1u;
-                    nupd += emit(qu, a, on && ri != rj && t1 && !dupf[c], ri ? di : dj, ri ? dj : di, 1u);
+                const uint32_t i = on ? t - L.m_tstart[c] : 0u, q = p + i;
+                PT(0)
+                const uint32_t rem = on ? cl - 1u - i : 0u;                 // positions after i in the cluster
+                const uint32_t di = L.da[q], ri = (uint32_t)(di < a.n_reads);
+                const uint32_t ci = EBWT ? T.compat[T.symidx[L.fl[q]]] : 0xFFFFu;
+                uint32_t dup = 0, hits = 0;
+#pragma unroll
+                for (int k0 = 1; k0 < (int)SMALL_MAX; k0 += 4) {
+                    if (__ballot(rem >= (uint32_t)k0)) {              // wave-uniform
+#pragma unroll
+                        for (int k = k0; k < k0 + 4 && k < (int)SMALL_MAX; ++k) {
+                            const uint32_t act = (uint32_t)((uint32_t)k <= rem);
+                            const uint32_t qj = act ? q + (uint32_t)k : q;
+                            const uint32_t dj = L.da[qj];
+                            const uint32_t sj = EBWT ? T.symidx[L.fl[qj]] : 0u;
+                            dup |= act & (uint32_t)(dj == di);
+                            hits |= (act & (ri ^ (uint32_t)(dj < a.n_reads)) & ((ci >> sj) & 1u)) << k;
+                        }
+                    }
                 }
+                if (on && dup) dupf[c] = 1;
+                PT(1)
+                if (pass == 1) {
+                    if (!on || dupf[c]) hits = 0u;
+                    while (__ballot(hits != 0u)) {
+                        const bool has = hits != 0u;
+                        const uint32_t k = has ? (uint32_t)__builtin_ctz(hits) : 0u;
+                        hits &= hits - 1u;
+                        const uint32_t dj = L.da[q + k];
+                        nupd += emit(qu, a, has, ri ? di : dj, ri ? dj : di, 1u);
+                    }
+                }
+                PT(2)
             }
         }
         med_push(a, ms, valid && dupf[lane] != 0, lo + (item & 0xFFFu), len);
+        PT(3)
     }
     return nupd;
 }
@@ -536,23 +683,26 @@ __device__ __forceinline__ void window_load(WinRegs &t, const ScanArgs &a, uint6
 // MODE: 0 detect + score, 1 count clusters per window, 2 emit cluster records in order.
 // =========================================================================================
 template <int EBWT, int MODE>
-__global__ __launch_bounds__(SCAN_WG) void k_scan(ScanArgs a)
+__global__ __launch_bounds__(SCANK_WG) __attribute__((amdgpu_waves_per_eu(LIME_SCAN_WAVES, LIME_SCAN_WAVES))) void k_scan(ScanArgs a)
 {
-    __shared__ WaveLds<WPOS> lds[SCAN_WG / 64];
+    __shared__ ScanLds lds[SCANK_WG / 64];
     __shared__ WgTables T;
     const uint32_t lane = lane_id(), wave = threadIdx.x >> 6;
-    WaveLds<WPOS> &L = lds[wave];
+    ScanLds &L = lds[wave];
     tables_init(T);                                        // the only workgroup barrier of the kernel
-    const uint32_t n_win = a.n_tiles, stride = gridDim.x * (SCAN_WG / 64);
-    uint32_t win = blockIdx.x * (SCAN_WG / 64) + wave;
+    const uint32_t n_win = a.n_tiles, stride = gridDim.x * (SCANK_WG / 64);
+    uint32_t win = blockIdx.x * (SCANK_WG / 64) + wave;
     if (win >= n_win) return;
-    UpdQueue qu; qu.qr = L.q_read; qu.qg = L.q_gen; qu.n = 0;
+    UpdQueue qu; qu.qr = L.q_read; qu.qg = L.q_gen; qu.n = 0; qu.cap = QCAP_SCAN;
+    qu.async = true; qu.fr = L.f_read; qu.fg = L.f_gen;
     MedState ms = {{0u, 0u}, {0u, 0u}, {0u, 0u}};          // no chunk reserved yet
     WinRegs regs;
     window_load<EBWT>(regs, a, (uint64_t)win * WIN);
     uint32_t acc_n = 0, acc_max = 0, acc_upd = 0;          // per-lane partial counters, reduced once at the end
     const uint64_t lt = (1ull << lane) - 1ull;
+    PT_DECL
     for (;;) {
+        PT_WAITVM PT(0)
         const uint64_t lo = (uint64_t)win * WIN;
         const uint64_t own_lim = a.n_own > lo ? (a.n_own - lo < WIN ? a.n_own - lo : (uint64_t)WIN) : 0ull;
         const uint64_t lim = a.n_avail - lo;               // valid positions of the window + read-ahead: [0, lim)
@@ -586,6 +736,7 @@ __global__ __launch_bounds__(SCAN_WG) void k_scan(ScanArgs a)
         // ---- the next window's loads go out now and land while this one is processed ----------
         const uint32_t next = win + stride;
         if (next < n_win && a.ablate != 8) window_load<EBWT>(regs, a, (uint64_t)next * WIN);
+        PT(1)
         if (a.ablate != 1) {
         // ---- masks with lane = word: bytes of 8 lanes make one 64-bit word (word 8: read-ahead) --
         uint64_t h = 0ull, r = 0ull, g = 0ull;
@@ -631,6 +782,7 @@ __global__ __launch_bounds__(SCAN_WG) void k_scan(ScanArgs a)
                 }
             }
         }
+        PT(2)
         if (a.ablate != 3) {
         acc_n += (uint32_t)__popcll(c.ah);
         if (MODE == 0) {
@@ -648,6 +800,7 @@ __global__ __launch_bounds__(SCAN_WG) void k_scan(ScanArgs a)
             for (int k = 1; k < (int)NW; ++k) pk[k] = rl32(pre, k);
             if (lane < NW) { L.asw[lane] = c.ah; L.prew[lane] = pre; }         // looked up by word below
             uint32_t nM = 0;
+            PT(3)
             for (uint32_t base = 0; base < total; base += 64u) {
                 const uint32_t t = base + lane;
                 const bool on = t < total;
@@ -687,9 +840,18 @@ __global__ __launch_bounds__(SCAN_WG) void k_scan(ScanArgs a)
                     nM += (uint32_t)__popcll(mM);
                 }
                 const bool sm4 = on && len <= 4u;
+                PT(4)
                 if (a.ablate != 10) acc_upd += score_small<EBWT>(L, T, qu, ms, a, lo, sm4, sm4 ? p : 0u, sm4 ? len : 0u);
+                PT(5)
             }
-            if (nM && a.ablate != 10 && a.ablate != 11) acc_upd += score_medium<EBWT>(L, T, qu, ms, a, lo, nM);
+            if (nM && a.ablate != 10 && a.ablate != 11) {
+#ifdef LIME_PHASE_TIMING
+                acc_upd += score_medium<EBWT>(L, T, qu, ms, a, lo, nM, pt_m); ++pt_nwin;
+#else
+                acc_upd += score_medium<EBWT>(L, T, qu, ms, a, lo, nM);
+#endif
+            }
+            PT(6)
             }
         } else {
             // ---- count / emit: lane l walks the accepted heads among ITS 8 positions ---------------
@@ -730,7 +892,18 @@ __global__ __launch_bounds__(SCAN_WG) void k_scan(ScanArgs a)
         if (a.ablate == 8) window_load<EBWT>(regs, a, (uint64_t)next * WIN);
         win = next;
     }
-    if (MODE == 0) { drain(qu, a); med_fill(a, ms, 1u); }
+    if (MODE == 0) {
+        do drain(qu, a); while (qu.n != 0u || __ballot(qu.f_pend != 0u));      // until every update has landed
+        med_fill(a, ms, 1u);
+    }
+#ifdef LIME_PHASE_TIMING
+    PT(7)
+    if (MODE == 0 && lane == 0 && wave == 0 && blockIdx.x % 181u == 0u)
+        printf("blk %u: wait %llu stage %llu ctx %llu prefix %llu enum %llu small %llu medium %llu tail %llu | med calls %u map %llu rows %llu emit %llu push %llu | drains %u cycles %llu\n", blockIdx.x,
+               (unsigned long long)pt_acc[0], (unsigned long long)pt_acc[1], (unsigned long long)pt_acc[2], (unsigned long long)pt_acc[3],
+               (unsigned long long)pt_acc[4], (unsigned long long)pt_acc[5], (unsigned long long)pt_acc[6], (unsigned long long)pt_acc[7],
+               pt_nwin, (unsigned long long)pt_m[0], (unsigned long long)pt_m[1], (unsigned long long)pt_m[2], (unsigned long long)pt_m[3], qu.n_drain, (unsigned long long)qu.t_drain);
+#endif
     if (MODE != 2) {
         const uint32_t tn = wave_sum(acc_n), tm = wave_max(acc_max), tu = wave_sum(acc_upd);
         if (lane == 0) {
@@ -885,7 +1058,7 @@ __global__ __launch_bounds__(SCAN_WG) void k_score_med(ScanArgs a)
     constexpr uint32_t PER = 64u / G, WHICH = G == 8 ? 0u : 1u;
     const uint32_t lane = lane_id(), wave = threadIdx.x >> 6, sub = lane & (G - 1u), grp = lane / G;
     tables_init(T);
-    UpdQueue qu; qu.qr = s_qr[wave]; qu.qg = s_qg[wave]; qu.n = 0;
+    UpdQueue qu; qu.qr = s_qr[wave]; qu.qg = s_qg[wave]; qu.n = 0; qu.cap = QCAP;
     const uint64_t *med = a.med + (size_t)WHICH * a.med_cap;
     const uint32_t n = a.stats->n_med[WHICH] < a.med_cap ? a.stats->n_med[WHICH] : a.med_cap;
     const uint32_t n_it = (n + PER - 1u) / PER, stride = gridDim.x * (SCAN_WG / 64);
@@ -1159,11 +1332,11 @@ template <typename K> static uint32_t resident_blocks(K kernel, int block)
 template <typename K> static void launch_scan_kernel(K kernel, const ScanArgs &a, uint32_t max_blocks, hipStream_t st)
 {
     static uint32_t resident = 0;                 // per instantiation: blocks that fit the device at once
-    if (!resident) resident = resident_blocks(kernel, SCAN_WG);
-    uint32_t want = (a.n_tiles + SCAN_WG / 64 - 1) / (SCAN_WG / 64);
+    if (!resident) resident = resident_blocks(kernel, SCANK_WG);
+    uint32_t want = (a.n_tiles + SCANK_WG / 64 - 1) / (SCANK_WG / 64);
     uint32_t cap = max_blocks ? max_blocks : resident;
     uint32_t grid = want < cap ? want : cap;
-    hipLaunchKernelGGL(kernel, dim3(grid ? grid : 1u), dim3(SCAN_WG), 0, st, a);
+    hipLaunchKernelGGL(kernel, dim3(grid ? grid : 1u), dim3(SCANK_WG), 0, st, a);
 }
 
 void launch_tile(int ebwt, int mode, const ScanArgs &a, uint32_t max_blocks, hipStream_t st)

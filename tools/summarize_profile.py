@@ -1,0 +1,74 @@
+#!/usr/bin/env python3
+"""tools/summarize_profile.py TAG -- turn the rocprofv3 output of tools/profile.sh TAG
+(gpurun_out/prof_TAG/{trace,pmc1..pmc4}) into the summaries kept under profiles/:
+
+  profiles/TAG_kernel_stats.csv   the --kernel-trace --stats table (lime:: kernels and fills)
+  profiles/TAG_pmc_summary.json   per kernel, every counter averaged over its launches
+  profiles/traffic.json           HBM bytes per launch of the dominant kernel, read by bench.py
+
+HBM bytes follow /opt/skills/guides/MI355X_MICROARCH.md: FETCH_SIZE and WRITE_SIZE are in KiB,
+and gfx950 counts 128-byte fetch requests as 64 bytes, so fetch bytes = 2 x FETCH_SIZE x 1024.
+"""
+import csv
+import glob
+import json
+import os
+import re
+import sys
+from collections import defaultdict
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def short(name):
+    name = re.sub(r"^void ", "", name)
+    return re.sub(r"\(.*$", "", name)
+
+
+def main():
+    tag = sys.argv[1] if len(sys.argv) > 1 else "r01"
+    src = os.path.join(ROOT, "gpurun_out", "prof_" + tag)
+    dst = os.path.join(ROOT, "profiles")
+    stats = glob.glob(os.path.join(src, "trace", "**", "*kernel_stats.csv"), recursive=True)
+    if not stats:
+        sys.exit("no kernel_stats.csv under " + src)
+    with open(stats[0]) as f, open(os.path.join(dst, tag + "_kernel_stats.csv"), "w") as g:
+        g.write(f.read())
+    acc = defaultdict(lambda: defaultdict(list))
+    for path in glob.glob(os.path.join(src, "pmc*", "**", "*counter_collection.csv"), recursive=True):
+        per_dispatch = defaultdict(float)
+        names = {}
+        with open(path) as f:
+            for row in csv.DictReader(f):
+                key = (row["Dispatch_Id"], row["Counter_Name"])
+                per_dispatch[key] += float(row["Counter_Value"])
+                names[row["Dispatch_Id"]] = short(row["Kernel_Name"])
+        for (disp, ctr), v in per_dispatch.items():
+            acc[names[disp]][ctr].append(v)
+    summary = {k: {c: sum(v) / len(v) for c, v in sorted(ctrs.items())} | {"launches": max(len(v) for v in ctrs.values())}
+               for k, ctrs in sorted(acc.items()) if k.startswith("lime::")}
+    with open(os.path.join(dst, tag + "_pmc_summary.json"), "w") as g:
+        json.dump(summary, g, indent=1)
+    dom = max((k for k in summary if "k_scan" in k), key=lambda k: summary[k].get("FETCH_SIZE", 0.0), default=None)
+    if dom and "FETCH_SIZE" in summary[dom] and "WRITE_SIZE" in summary[dom]:
+        s = summary[dom]
+        traffic = {
+            "kernel": dom,
+            "hbm_bytes_per_launch": int(2 * s["FETCH_SIZE"] * 1024 + s["WRITE_SIZE"] * 1024),
+            "FETCH_SIZE_KiB": s["FETCH_SIZE"], "WRITE_SIZE_KiB": s["WRITE_SIZE"],
+            "TCC_EA0_ATOMIC_sum": s.get("TCC_EA0_ATOMIC_sum"),
+            "correction": "HBM bytes = 2 x FETCH_SIZE x 1024 (gfx950 counts 128-B requests at 64 B) + WRITE_SIZE x 1024; "
+                          "separate --pmc passes (tools/profile.sh %s), bench.py --steps 5 --warmup 2 --no-cpu, "
+                          "averages over %d launches" % (tag, s["launches"]),
+            "algorithmic_bytes_per_launch": 900000000,
+            "profile": tag,
+        }
+        with open(os.path.join(dst, "traffic.json"), "w") as g:
+            json.dump(traffic, g, indent=1)
+        print(json.dumps(traffic))
+    for k, s in summary.items():
+        print(k, {c: round(v) for c, v in s.items()})
+
+
+if __name__ == "__main__":
+    main()
