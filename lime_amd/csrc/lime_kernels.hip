@@ -92,6 +92,12 @@ struct alignas(16) ScanLds {
 __device__ __forceinline__ uint32_t lane_id() { return threadIdx.x & 63u; }
 __device__ __forceinline__ uint64_t brev64(uint64_t x) { return __builtin_bitreverse64(x); }
 __device__ __forceinline__ uint32_t rl32(uint32_t v, uint32_t l) { return (uint32_t)__builtin_amdgcn_readlane((int)v, (int)l); }
+// v with lane L replaced by the wave-uniform value s
+template <int L> __device__ __forceinline__ uint32_t write_lane(uint32_t v, uint32_t s)
+{
+    asm("v_writelane_b32 %0, %1, %2" : "+v"(v) : "s"(s), "n"(L));
+    return v;
+}
 __device__ __forceinline__ uint64_t rl64(uint64_t v, uint32_t l)
 {
     return ((uint64_t)rl32((uint32_t)(v >> 32), l) << 32) | rl32((uint32_t)v, l);
@@ -635,39 +641,44 @@ __device__ __forceinline__ WinCtx window_context(uint64_t h, uint64_t r, uint64_
     return c;
 }
 
-// ---- window loads: lane l holds positions [PPL*l, PPL*l+PPL) of the window (PPL/4 x 16 B lcp, the
-// same of da, PPL bytes of ebwt) and position WIN + l of the read-ahead (lanes < HALO) ---------------
+// ---- window loads: lane l holds positions 64 j + l (j < PPL) of the window -- every load
+// instruction reads 64 consecutive elements, and the wave ballot of a comparison on register j IS
+// mask word j -- the ebwt bytes 256 k + 4 l .. + 3 (k < PPL/4), and position WIN + l of the
+// read-ahead (lanes < HALO).  Elements at or beyond n_avail read as 0.
 struct WinRegs { uint32_t lv[PPL], dv[PPL], bv[PPL / 4], hl, hd, hb; };
+typedef uint32_t __attribute__((may_alias, aligned(1))) u32u;    // ebwt words: any byte alignment
 
 template <int EBWT>
 __device__ __forceinline__ void window_load(WinRegs &t, const ScanArgs &a, uint64_t lo)
 {
     const uint32_t lane = lane_id();
-    const uint64_t g = lo + PPL * lane;
+    const uint32_t *lp = a.lcp + lo + lane, *dp = a.da + lo + lane;
+    if (lo + WIN <= a.n_avail) {                           // wave-uniform: the whole window is data
 #pragma unroll
-    for (int k = 0; k < (int)PPL / 4; ++k) t.bv[k] = 0u;
-    if (g + PPL <= a.n_avail) {
+        for (int j = 0; j < (int)PPL; ++j) { t.lv[j] = lp[64 * j]; t.dv[j] = dp[64 * j]; }
+#pragma unroll
+        for (int k = 0; k < (int)PPL / 4; ++k)
+            t.bv[k] = EBWT ? *reinterpret_cast<const u32u *>(a.ebwt + lo + 256u * (uint32_t)k + 4u * lane) : 0u;
+    } else {
+        // the last window of the data: addresses clamped to the last element (what the padding
+        // positions read is never used: the masks mark them), ebwt byte by byte
+        const uint64_t left = a.n_avail > lo ? a.n_avail - lo : 0ull;      // valid positions of the window (> 0)
+        const uint32_t last = (uint32_t)left - 1u;
+#pragma unroll
+        for (int j = 0; j < (int)PPL; ++j) {
+            const uint32_t p = 64u * (uint32_t)j + lane, q = p < last ? p : last;
+            t.lv[j] = a.lcp[lo + q]; t.dv[j] = a.da[lo + q];
+        }
 #pragma unroll
         for (int k = 0; k < (int)PPL / 4; ++k) {
-            const uint4 l4 = *reinterpret_cast<const uint4 *>(a.lcp + g + 4 * k);
-            const uint4 d4 = *reinterpret_cast<const uint4 *>(a.da + g + 4 * k);
-            t.lv[4 * k] = l4.x; t.lv[4 * k + 1] = l4.y; t.lv[4 * k + 2] = l4.z; t.lv[4 * k + 3] = l4.w;
-            t.dv[4 * k] = d4.x; t.dv[4 * k + 1] = d4.y; t.dv[4 * k + 2] = d4.z; t.dv[4 * k + 3] = d4.w;
-        }
-        if (EBWT) {
-            const uint4 b = *reinterpret_cast<const uint4 *>(a.ebwt + g);
-            t.bv[0] = b.x; t.bv[1] = b.y; t.bv[2] = b.z; t.bv[3] = b.w;
-        }
-    } else {
-#pragma unroll 1
-        for (int j = 0; j < (int)PPL; ++j) {
-            const bool ok = g + j < a.n_avail;
-            const uint32_t l = ok ? a.lcp[g + j] : 0u, d = ok ? a.da[g + j] : 0u;
-            const uint32_t b = (EBWT && ok) ? a.ebwt[g + j] : 0u;
+            uint32_t w = 0;
+            if (EBWT)
 #pragma unroll
-            for (int k = 0; k < (int)PPL; ++k) if (k == j) { t.lv[k] = l; t.dv[k] = d; }
-#pragma unroll
-            for (int k = 0; k < (int)PPL / 4; ++k) if (k == (j >> 2)) t.bv[k] |= b << (8 * (j & 3));
+                for (int b = 0; b < 4; ++b) {
+                    const uint32_t p = 256u * (uint32_t)k + 4u * lane + (uint32_t)b;
+                    w |= (uint32_t)a.ebwt[lo + (p < last ? p : last)] << (8 * b);
+                }
+            t.bv[k] = w;
         }
     }
     const uint64_t hp = lo + WIN + lane;
@@ -706,48 +717,43 @@ __global__ __launch_bounds__(SCANK_WG) __attribute__((amdgpu_waves_per_eu(LIME_S
         const uint64_t lo = (uint64_t)win * WIN;
         const uint64_t own_lim = a.n_own > lo ? (a.n_own - lo < WIN ? a.n_own - lo : (uint64_t)WIN) : 0ull;
         const uint64_t lim = a.n_avail - lo;               // valid positions of the window + read-ahead: [0, lim)
-        // ---- stage the window in LDS: documents, raw ebwt bytes, and per lane PPL bits each of
-        // head bits (lcp < alpha) and read bits (da < n_reads) of its positions ---------------------
+        // ---- stage the window in LDS (documents, raw ebwt bytes) and build the masks with lane =
+        // word: word j of the head mask (lcp < alpha) / read mask (da < n_reads) is the ballot of the
+        // comparison on register j, written into lane j; word WIN/64 holds the read-ahead ------------
+        uint64_t h = 0ull, r = 0ull, g = 0ull;
         {
-            uint32_t hb = 0, rb = 0;
+            uint32_t hlo = 0, hhi = 0, rlo = 0, rhi = 0;
+            static_assert(PPL == 16 && WIN / 64 == 16, "mask words are written lane by lane below");
+#define LIME_WORD(J) { const uint64_t bh = __ballot(regs.lv[J] < a.alpha), br = __ballot(regs.dv[J] < a.n_reads); \
+                       hlo = write_lane<J>(hlo, (uint32_t)bh); hhi = write_lane<J>(hhi, (uint32_t)(bh >> 32)); \
+                       rlo = write_lane<J>(rlo, (uint32_t)br); rhi = write_lane<J>(rhi, (uint32_t)(br >> 32)); }
+            LIME_WORD(0) LIME_WORD(1) LIME_WORD(2) LIME_WORD(3) LIME_WORD(4) LIME_WORD(5) LIME_WORD(6) LIME_WORD(7)
+            LIME_WORD(8) LIME_WORD(9) LIME_WORD(10) LIME_WORD(11) LIME_WORD(12) LIME_WORD(13) LIME_WORD(14) LIME_WORD(15)
+#undef LIME_WORD
+            const uint64_t bh = __ballot(lane < HALO && regs.hl < a.alpha), br = __ballot(lane < HALO && regs.hd < a.n_reads);
+            hlo = write_lane<16>(hlo, (uint32_t)bh); rlo = write_lane<16>(rlo, (uint32_t)br);
+            h = ((uint64_t)hhi << 32) | hlo; r = ((uint64_t)rhi << 32) | rlo;
+            const uint64_t wl = 64ull * lane;                 // the end of the data: padding closes runs, is nobody's
+            const uint64_t v = lim >= wl + 64u ? ~0ull : (lim <= wl ? 0ull : ((1ull << (lim - wl)) - 1ull));
+            h |= ~v; r &= v; g = v & ~r;
+            if (lane == WIN / 64) { h &= 0xFFFFull; g &= 0xFFFFull; }
+            if (lane > WIN / 64) { h = 0ull; g = 0ull; }
 #pragma unroll
-            for (int j = 0; j < (int)PPL; ++j) {
-                hb |= (uint32_t)(regs.lv[j] < a.alpha) << j;
-                rb |= (uint32_t)(regs.dv[j] < a.n_reads) << j;
-            }
-            uint32_t hh = (uint32_t)(lane < HALO && regs.hl < a.alpha), hr = (uint32_t)(lane < HALO && regs.hd < a.n_reads);
-            if (lim < WPOS) {                              // the end of the data: padding closes runs, is nobody's
-                const uint32_t v0 = PPL * lane;
-                const uint32_t vb = lim >= v0 + PPL ? ((1u << PPL) - 1u) : (lim <= v0 ? 0u : ((1u << (lim - v0)) - 1u));
-                hb |= ~vb & ((1u << PPL) - 1u); rb &= vb;
-                const bool hv = WIN + lane < lim;
-                hh = (uint32_t)(lane < HALO && (!hv || regs.hl < a.alpha)); hr = hr & (uint32_t)hv;
-            }
+            for (int j = 0; j < (int)PPL; ++j) L.da[64 * j + (int)lane] = regs.dv[j];
+            if (EBWT)
 #pragma unroll
-            for (int k = 0; k < (int)PPL / 4; ++k)
-                *reinterpret_cast<u4a *>(&L.da[PPL * lane + 4 * k]) = make_uint4(regs.dv[4 * k], regs.dv[4 * k + 1], regs.dv[4 * k + 2], regs.dv[4 * k + 3]);
-            if (EBWT) *reinterpret_cast<u4a *>(&L.fl[PPL * lane]) = make_uint4(regs.bv[0], regs.bv[1], regs.bv[2], regs.bv[3]);
-            *reinterpret_cast<u16a *>(&L.hb[2u * lane]) = (uint16_t)hb;
-            *reinterpret_cast<u16a *>(&L.rb[2u * lane]) = (uint16_t)rb;
+                for (int k = 0; k < (int)PPL / 4; ++k) reinterpret_cast<u32u *>(L.fl)[64 * k + (int)lane] = regs.bv[k];
             if (lane < HALO) { L.da[WIN + lane] = regs.hd; if (EBWT) L.fl[WIN + lane] = (uint8_t)regs.hb; }
-            const uint64_t H8 = __ballot(hh != 0u), R8 = __ballot(hr != 0u);
-            if (lane < 3u) { L.hb[WIN / 8 + lane] = (uint8_t)(H8 >> (8u * lane)); L.rb[WIN / 8 + lane] = (uint8_t)(R8 >> (8u * lane)); }
+            if (lane <= WIN / 64) {
+                *reinterpret_cast<u64a *>(&L.hb[8u * lane]) = h;
+                *reinterpret_cast<u64a *>(&L.rb[8u * lane]) = r;
+            }
         }
         // ---- the next window's loads go out now and land while this one is processed ----------
         const uint32_t next = win + stride;
         if (next < n_win && a.ablate != 8) window_load<EBWT>(regs, a, (uint64_t)next * WIN);
         PT(1)
         if (a.ablate != 1) {
-        // ---- masks with lane = word: bytes of 8 lanes make one 64-bit word (word 8: read-ahead) --
-        uint64_t h = 0ull, r = 0ull, g = 0ull;
-        if (lane <= WIN / 64) {
-            h = *reinterpret_cast<const u64a *>(&L.hb[8u * lane]);
-            r = *reinterpret_cast<const u64a *>(&L.rb[8u * lane]);
-            const uint64_t wl = 64ull * lane;
-            const uint64_t v = lim >= wl + 64u ? ~0ull : (lim <= wl ? 0ull : ((1ull << (lim - wl)) - 1ull));
-            g = v & ~r;
-            if (lane == WIN / 64) { h &= 0xFFFFull; g &= 0xFFFFull; }
-        }
         const WinCtx c = window_context(h, r, g, own_lim);
 
         // ---- window summary for the segment that is still open after the read-ahead ------------
