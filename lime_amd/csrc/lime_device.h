@@ -98,18 +98,33 @@ LIME_HD void hist_set(uint32_t (&w)[4], uint32_t i, uint32_t v)
 // genome counts differ, and an (i, a) step is a no-op when both leftovers of code a are zero --
 // leftovers of codes never grow -- so it is enough to walk, for each base i in order, the codes a
 // (ascending) that start with a non-zero leftover.  Same order of effects as the reference.
+// The leftovers live in two 64-bit halves (bins 0..7, 8..15) read and written with shifts: plain
+// scalars, so that the compiler has no array to move into scratch memory.
+LIME_HD uint32_t h64_get(uint64_t lo, uint64_t hi, uint32_t i)
+{
+    return (uint32_t)(((i & 8u) ? hi : lo) >> ((i & 7u) * 8u)) & 255u;
+}
+LIME_HD void h64_set(uint64_t &lo, uint64_t &hi, uint32_t i, uint32_t v)
+{
+    const uint32_t sh = (i & 7u) * 8u;
+    const uint64_t keep = ~(255ull << sh), put = (uint64_t)v << sh;
+    if (i & 8u) hi = (hi & keep) | put; else lo = (lo & keep) | put;
+}
+
 LIME_HD uint32_t pair_score_iupac(const uint32_t (&cr)[4], const uint32_t (&cg)[4])
 {
     uint32_t t = (sad_u8(cr[0], 0u, sad_u8(cr[1], 0u, sad_u8(cr[2], 0u, sad_u8(cr[3], 0u, 0u)))) +
                   sad_u8(cg[0], 0u, sad_u8(cg[1], 0u, sad_u8(cg[2], 0u, sad_u8(cg[3], 0u, 0u)))) -
                   sad_u8(cr[0], cg[0], sad_u8(cr[1], cg[1], sad_u8(cr[2], cg[2], sad_u8(cr[3], cg[3], 0u))))) >> 1;
-    uint32_t rr[4] = {0u, 0u, 0u, 0u}, rg[4] = {0u, 0u, 0u, 0u};   // leftovers, packed like the histograms
+    const uint64_t crl = cr[0] | ((uint64_t)cr[1] << 32), crh = cr[2] | ((uint64_t)cr[3] << 32);
+    const uint64_t cgl = cg[0] | ((uint64_t)cg[1] << 32), cgh = cg[2] | ((uint64_t)cg[3] << 32);
+    uint64_t rrl = 0, rrh = 0, rgl = 0, rgh = 0;                   // leftovers, packed like the histograms
     uint32_t nz = 0;                                               // codes 4..14 with a non-zero leftover
     for (uint32_t i = 0; i < 15u; i++) {
-        const uint32_t a = hist_get(cr, i), b = hist_get(cg, i);
+        const uint32_t a = h64_get(crl, crh, i), b = h64_get(cgl, cgh, i);
         if (i >= 4u && a == b) continue;
         const uint32_t mn = a < b ? a : b;
-        hist_set(rr, i, a - mn); hist_set(rg, i, b - mn);
+        h64_set(rrl, rrh, i, a - mn); h64_set(rgl, rgh, i, b - mn);
         if (i >= 4u) nz |= 1u << i;
     }
     for (uint32_t i = 0; i < 4u; i++) {          // :146-177
@@ -118,15 +133,15 @@ LIME_HD uint32_t pair_score_iupac(const uint32_t (&cr)[4], const uint32_t (&cg)[
             const uint32_t a = (uint32_t)__builtin_ctz(m);
             m &= m - 1u;
             if (!((CORR_PACKED >> (a * 4u + i)) & 1ull)) continue;
-            const uint32_t ga = hist_get(rg, a), ri = hist_get(rr, i);
+            const uint32_t ga = h64_get(rgl, rgh, a), ri = h64_get(rrl, rrh, i);
             if (ga > 0u) {                       // :150-161 (as written: the zeroed side is "subtracted")
-                if (ga > ri) { t += ri; hist_set(rr, i, 0u); }
-                else         { t += ga; hist_set(rg, a, 0u); }
+                if (ga > ri) { t += ri; h64_set(rrl, rrh, i, 0u); }
+                else         { t += ga; h64_set(rgl, rgh, a, 0u); }
             }
-            const uint32_t ra = hist_get(rr, a), gi = hist_get(rg, i);
+            const uint32_t ra = h64_get(rrl, rrh, a), gi = h64_get(rgl, rgh, i);
             if (ra > 0u) {                       // :163-174
-                if (ra > gi) { t += gi; hist_set(rr, a, ra - gi); hist_set(rg, i, 0u); }
-                else         { t += ra; hist_set(rg, i, gi - ra); hist_set(rr, a, 0u); }
+                if (ra > gi) { t += gi; h64_set(rrl, rrh, a, ra - gi); h64_set(rgl, rgh, i, 0u); }
+                else         { t += ra; h64_set(rgl, rgh, i, gi - ra); h64_set(rrl, rrh, a, 0u); }
             }
         }
     }

@@ -28,6 +28,7 @@ constexpr uint32_t F_HEAD = 0x10;
 constexpr uint32_t F_READ = 0x20;
 constexpr uint32_t F_GEN = 0x40;
 
+constexpr uint32_t MID_MAX = 64;      // clusters of SMALL_MAX+1 .. MID_MAX symbols: one 64-lane group each (k_score_med)
 constexpr uint32_t QCAP = 320;        // pending table updates per wave (a batch of 64 small clusters adds <= 256)
 constexpr uint32_t MED_CHUNK = 8;     // slots of the repeated-document list a wave reserves at a time
 constexpr uint32_t T_SHIFT = 27;      // queue entry: genome | t << 27 (t <= SMALL_MAX < 32)
@@ -36,6 +37,7 @@ constexpr uint32_t CAP_D = 256;       // of those, clusters with a repeated docu
 
 // LDS is written and read through differently typed pointers (bytes as u16/u64, words as uint4):
 // these may_alias types keep the compiler from reordering such accesses under type-based aliasing.
+typedef volatile uint8_t __attribute__((address_space(3))) lds_vu8;
 typedef uint16_t __attribute__((may_alias)) u16a;
 typedef uint64_t __attribute__((may_alias)) u64a;
 typedef uint4 __attribute__((may_alias)) u4a;
@@ -74,10 +76,11 @@ struct alignas(16) WaveLds {
 #define LIME_SCAN_WAVES 3
 #endif
 constexpr int SCANK_WG = LIME_SCANK_WG;   // threads per workgroup of k_scan; its waves work independently
+constexpr uint32_t DUP_SLOTS = 16;    // clusters with a repeated document a wave of k_scan holds before scoring them
 constexpr uint32_t QCAP_SCAN = 256;   // >= the 256 hits one batch of 64 clusters of <= 4 symbols can add
 struct alignas(16) ScanLds {
-    uint32_t da[WPOS];
-    uint8_t fl[WPOS];
+    uint32_t da[WPOS + SMALL_MAX];    // padded: rows of score_medium read up to SMALL_MAX-1 past a position
+    uint8_t fl[WPOS + SMALL_MAX];
     alignas(8) uint8_t hb[WPOS / 8 + 8];
     alignas(8) uint8_t rb[WPOS / 8 + 8];
     uint16_t listM[WIN / 5 + 4];
@@ -87,6 +90,8 @@ struct alignas(16) ScanLds {
     uint32_t prew[NW];
     uint32_t q_read[QCAP_SCAN], q_gen[QCAP_SCAN];
     uint32_t f_read[256], f_gen[256];   // entries whose compare-and-swap is in flight
+    uint32_t g_doc[DUP_SLOTS][SMALL_MAX];   // clusters with a repeated document waiting for dup_flush
+    uint8_t g_sym[DUP_SLOTS][SMALL_MAX], g_len[DUP_SLOTS];
 };
 
 __device__ __forceinline__ uint32_t lane_id() { return threadIdx.x & 63u; }
@@ -318,6 +323,96 @@ __device__ __forceinline__ void med_push(const ScanArgs &a, MedState &ms, bool o
     med_push1(a, ms, 1u, on, pos | ((uint64_t)(len - 1u) << 48));
 }
 
+// ---- general score of short clusters by lane groups ------------------------------------------
+// G lanes per cluster, element i on sub-lane i; XOR-ing the sub-lane with 1..R (R + 1 = the power
+// of two covering the longest cluster of the wave) shows every lane every other element of its
+// cluster.  Pass 1: is this element the first of its document, and the document's count / 16-bin
+// histogram over the cluster (counts <= 64: no wrap, no saturation).  Pass 2: every
+// first-occurrence read meets every first-occurrence genome once (pair_score;
+// ClusterBWT_DA.cpp:107-190 / :192-252).
+// the clusters of one wave iteration: element `sub` of the lane's group holds document d and ebwt
+// byte bb (sub < len; len = 0: no cluster in this group)
+template <int EBWT, int G>
+__device__ __forceinline__ uint32_t group_score(const ScanArgs &a, const WgTables &T, UpdQueue &qu,
+                                                uint32_t d, uint32_t bb, uint32_t len)
+{
+    const uint32_t sub = lane_id() & (G - 1u);
+    uint32_t acc_upd = 0;
+    // rounds: sub-lane ^ r stays inside the first R+1 sub-lanes, which hold the whole cluster
+    uint32_t R = 1u;
+#pragma unroll
+    for (uint32_t p2 = 2u; p2 < (uint32_t)G; p2 <<= 1) if (__ballot(len > p2)) R = 2u * p2 - 1u;
+    const bool have = sub < len;
+    const uint32_t sy = (EBWT && have) ? T.symidx[bb] : 0u;
+    const bool isr = have && d < a.n_reads;
+    const uint32_t f = have ? (sy | (isr ? F_READ : F_GEN)) : 0u;
+    uint32_t earlier = 0, cnt = have ? 1u : 0u, hs[4] = {0u, 0u, 0u, 0u};
+    if (EBWT) hist_add(hs, sy, (uint32_t)have);
+#pragma unroll 1
+    for (uint32_t r = 1; r <= R; ++r) {
+        const uint32_t pd = __shfl_xor(d, (int)r), pf = __shfl_xor(f, (int)r);
+        const uint32_t same = (uint32_t)(f && pf && pd == d);
+        earlier |= same & (uint32_t)((sub ^ r) < sub);
+        cnt += same;
+        if (EBWT) hist_add(hs, pf & F_SYM, same);
+    }
+    const uint32_t lead = (uint32_t)(have && !earlier);
+#pragma unroll 1
+    for (uint32_t r = 1; r <= R; ++r) {
+        const uint32_t pd = __shfl_xor(d, (int)r), pf = __shfl_xor(f, (int)r), pl = __shfl_xor(lead, (int)r), pc = __shfl_xor(cnt, (int)r);
+        uint32_t ph[4] = {0u, 0u, 0u, 0u};
+        if (EBWT) { ph[0] = __shfl_xor(hs[0], (int)r); ph[1] = __shfl_xor(hs[1], (int)r); ph[2] = __shfl_xor(hs[2], (int)r); ph[3] = __shfl_xor(hs[3], (int)r); }
+        const bool pair = lead && isr && pl && (pf & F_GEN);
+        if (__ballot(pair) == 0ull) continue;
+        uint32_t t = cnt < pc ? cnt : pc;
+        if (EBWT) {
+            uint32_t h2[4], p2[4];           // only real pairs go through the (possibly slow) score
+#pragma unroll
+            for (int k = 0; k < 4; ++k) { h2[k] = pair ? hs[k] : 0u; p2[k] = pair ? ph[k] : 0u; }
+            t = pair_score(h2, p2);
+        }
+        acc_upd += emit(qu, a, pair && t, d, pd, t);
+    }
+    return acc_upd;
+}
+
+
+// ---- clusters with a repeated document, kept by the wave that found them: copies of up to
+// DUP_SLOTS clusters (<= SMALL_MAX elements each) in LDS, scored four at a time by 16-lane groups
+// when enough have gathered (and at the end).  A batch that does not fit goes to global list 1
+// for k_score_med instead.
+template <int EBWT, typename LDS>
+__device__ __forceinline__ void dup_push(LDS &L, uint32_t &n_dup, const ScanArgs &a, MedState &ms,
+                                         bool on, uint64_t lo, uint32_t p, uint32_t len)
+{
+    const uint64_t m = __ballot(on);
+    if (m == 0ull) return;
+    const uint32_t cnt = (uint32_t)__popcll(m);
+    if (n_dup + cnt > DUP_SLOTS) { med_push(a, ms, on, lo + p, len); return; }
+    if (on) {
+        const uint32_t slot = n_dup + (uint32_t)__popcll(m & ((1ull << lane_id()) - 1ull));
+        for (uint32_t k = 0; k < len; ++k) { L.g_doc[slot][k] = L.da[p + k]; if (EBWT) L.g_sym[slot][k] = L.fl[p + k]; }
+        L.g_len[slot] = (uint8_t)len;
+    }
+    n_dup += cnt;
+}
+
+template <int EBWT, typename LDS>
+__device__ __forceinline__ uint32_t dup_flush(LDS &L, uint32_t &n_dup, const ScanArgs &a, const WgTables &T, UpdQueue &qu)
+{
+    const uint32_t lane = lane_id(), grp = lane >> 4, sub = lane & 15u;
+    uint32_t nupd = 0;
+#pragma unroll 1
+    for (uint32_t c0 = 0; c0 < n_dup; c0 += 4u) {
+        const uint32_t c = c0 + grp;
+        const uint32_t len = c < n_dup ? L.g_len[c] : 0u;
+        const uint32_t cc = c < n_dup ? c : 0u;
+        nupd += group_score<EBWT, 16>(a, T, qu, L.g_doc[cc][sub], EBWT ? L.g_sym[cc][sub] : 0u, len);
+    }
+    n_dup = 0;
+    return nupd;
+}
+
 // ---- cluster scoring ----------------------------------------------------------------------
 // One lane per cluster of the list (<= SMALL_MAX symbols, staged at L.da/L.fl[s..s+len)).  The
 // cluster's read and genome positions are bit masks cut out of the window's mask bytes; the
@@ -446,7 +541,7 @@ __device__ __forceinline__ uint32_t score_lists(LDS &L, const ScanArgs &a, uint3
 // 6 position pairs that joins a read with a genome scores 1 if their symbols are compatible.
 // Hits go straight into the update queue at slots from one wave prefix sum.
 template <int EBWT, typename LDS>
-__device__ __forceinline__ uint32_t score_small(LDS &L, const WgTables &T, UpdQueue &qu, MedState &ms, const ScanArgs &a,
+__device__ __forceinline__ uint32_t score_small(LDS &L, const WgTables &T, UpdQueue &qu, MedState &ms, uint32_t &n_dup, const ScanArgs &a,
                                                 uint64_t lo, bool on, uint32_t p, uint32_t len)
 {
     const uint32_t kb = p >> 3, sh = p & 7u;
@@ -464,7 +559,7 @@ __device__ __forceinline__ uint32_t score_small(LDS &L, const WgTables &T, UpdQu
     for (int i = 0; i < 4; ++i)
 #pragma unroll
         for (int j = i + 1; j < 4; ++j) dup |= (uint32_t)(d[i] == d[j]) & (uint32_t)((uint32_t)j < len);
-    med_push(a, ms, dup != 0u, lo + p, len);
+    dup_push<EBWT>(L, n_dup, a, ms, dup != 0u, lo, p, len);
     uint32_t hits = 0, bad = 0;
     int pi = 0;
 #pragma unroll
@@ -518,7 +613,7 @@ __host__ __device__ __forceinline__ void tri_decode(uint32_t t, uint32_t L, uint
 // cluster.  A chunk normally holds all rows of the window: one pass; else a first pass over all
 // chunks settles the repeated-document marks before hits are emitted.
 template <int EBWT, typename LDS>
-__device__ __forceinline__ uint32_t score_medium(LDS &L, const WgTables &T, UpdQueue &qu, MedState &ms, const ScanArgs &a,
+__device__ __forceinline__ uint32_t score_medium(LDS &L, const WgTables &T, UpdQueue &qu, MedState &ms, uint32_t &n_dup, const ScanArgs &a,
                                                  uint64_t lo, uint32_t nM, uint64_t *ptm = nullptr)
 {
 #ifdef LIME_PHASE_TIMING
@@ -527,8 +622,9 @@ __device__ __forceinline__ uint32_t score_medium(LDS &L, const WgTables &T, UpdQ
     const uint32_t lane = lane_id();
     const uint64_t lt = (1ull << lane) - 1ull, le = lt | (1ull << lane);
     // lanes talk through these LDS bytes with no barrier in between: volatile, or the compiler
+    // (LDS address space: a volatile GENERIC pointer turns into flat accesses that wait for vmcnt)
     // forwards a lane's own store to its later load and never sees the other lanes' stores
-    volatile uint8_t *flag = L.m_flag, *dupf = L.m_dup;
+    lds_vu8 *flag = (lds_vu8 *)L.m_flag, *dupf = (lds_vu8 *)L.m_dup;
     uint32_t nupd = 0;
     for (uint32_t c0 = 0; c0 < nM; c0 += 64u) {
         const bool valid = c0 + lane < nM;
@@ -553,39 +649,56 @@ __device__ __forceinline__ uint32_t score_medium(LDS &L, const WgTables &T, UpdQ
                 const uint32_t i = on ? t - L.m_tstart[c] : 0u, q = p + i;
                 PT(0)
                 const uint32_t rem = on ? cl - 1u - i : 0u;                 // positions after i in the cluster
-                const uint32_t di = L.da[q], ri = (uint32_t)(di < a.n_reads);
+                const uint32_t di = L.da[q];
                 const uint32_t ci = EBWT ? T.compat[T.symidx[L.fl[q]]] : 0xFFFFu;
-                uint32_t dup = 0, hits = 0;
+                // read bits of q .. q+15 from the staged mask bytes
+                const uint32_t kb = q >> 3;
+                const uint32_t rb16 = ((uint32_t)L.rb[kb] | ((uint32_t)L.rb[kb + 1u] << 8) | ((uint32_t)L.rb[kb + 2u] << 16)) >> (q & 7u);
+                const uint32_t ri = rb16 & 1u;
+                // bit k: position q+k holds the same document / a compatible symbol.  Positions past
+                // the cluster are read too (the arrays are padded) and masked afterwards.
+                uint32_t dupb = 0, cb16 = EBWT ? 0u : 0xFFFFu;
 #pragma unroll
                 for (int k0 = 1; k0 < (int)SMALL_MAX; k0 += 4) {
                     if (__ballot(rem >= (uint32_t)k0)) {              // wave-uniform
 #pragma unroll
                         for (int k = k0; k < k0 + 4 && k < (int)SMALL_MAX; ++k) {
-                            const uint32_t act = (uint32_t)((uint32_t)k <= rem);
-                            const uint32_t qj = act ? q + (uint32_t)k : q;
-                            const uint32_t dj = L.da[qj];
-                            const uint32_t sj = EBWT ? T.symidx[L.fl[qj]] : 0u;
-                            dup |= act & (uint32_t)(dj == di);
-                            hits |= (act & (ri ^ (uint32_t)(dj < a.n_reads)) & ((ci >> sj) & 1u)) << k;
+                            dupb |= (uint32_t)(L.da[q + (uint32_t)k] == di) << k;
+                            if (EBWT) cb16 |= ((ci >> T.symidx[L.fl[q + (uint32_t)k]]) & 1u) << k;
                         }
                     }
                 }
-                if (on && dup) dupf[c] = 1;
+                const uint32_t vmask = (2u << rem) - 2u;                    // bits 1..rem
+                uint32_t hits = (ri ? ~rb16 : rb16) & cb16 & vmask;
+                if (on && (dupb & vmask)) dupf[c] = 1;
                 PT(1)
                 if (pass == 1) {
                     if (!on || dupf[c]) hits = 0u;
+                    // hits -> update queue, at most 4 per lane and round, slots from one prefix sum
                     while (__ballot(hits != 0u)) {
-                        const bool has = hits != 0u;
-                        const uint32_t k = has ? (uint32_t)__builtin_ctz(hits) : 0u;
-                        hits &= hits - 1u;
-                        const uint32_t dj = L.da[q + k];
-                        nupd += emit(qu, a, has, ri ? di : dj, ri ? dj : di, 1u);
+                        const uint32_t nh = (uint32_t)__popc(hits), take = nh < 4u ? nh : 4u;
+                        const uint32_t incl = wave_incl_scan(take), tot = rl32(incl, 63);
+                        while (qu.n + tot > qu.cap) drain(qu, a);
+                        uint32_t slot = qu.n + incl - take, bad = 0;
+#pragma unroll
+                        for (int e = 0; e < 4; ++e)
+                            if ((uint32_t)e < take) {
+                                const uint32_t k = (uint32_t)__builtin_ctz(hits);
+                                hits &= hits - 1u;
+                                const uint32_t dj = L.da[q + k];
+                                uint32_t gd = (ri ? dj : di) - a.n_reads;
+                                if (gd >= a.n_refs) { bad = 1u; gd = 0u; }   // reported below; the result is void anyway
+                                qu.qr[slot] = ri ? di : dj; qu.qg[slot] = gd | (1u << T_SHIFT);
+                                ++slot;
+                            }
+                        if (__ballot(bad != 0u)) { if (bad) atomicOr(&a.stats->flags, LIME_FLAG_DOCID); }
+                        qu.n += tot; nupd += take;
                     }
                 }
                 PT(2)
             }
         }
-        med_push(a, ms, valid && dupf[lane] != 0, lo + (item & 0xFFFu), len);
+        dup_push<EBWT>(L, n_dup, a, ms, valid && dupf[lane] != 0, lo, item & 0xFFFu, len);
         PT(3)
     }
     return nupd;
@@ -710,6 +823,7 @@ __global__ __launch_bounds__(SCANK_WG) __attribute__((amdgpu_waves_per_eu(LIME_S
     WinRegs regs;
     window_load<EBWT>(regs, a, (uint64_t)win * WIN);
     uint32_t acc_n = 0, acc_max = 0, acc_upd = 0;          // per-lane partial counters, reduced once at the end
+    uint32_t n_dup = 0;                                    // clusters waiting in the wave's dup store
     const uint64_t lt = (1ull << lane) - 1ull;
     PT_DECL
     for (;;) {
@@ -831,11 +945,20 @@ __global__ __launch_bounds__(SCANK_WG) __attribute__((amdgpu_waves_per_eu(LIME_S
                             q = (q | 7u) + 1u;
                         }
                         len = e - p;
-                        if (len > LIME_MAX_CLUSTER) atomicOr(&a.stats->flags, LIME_FLAG_MAXLEN);   // cannot happen inside a window
-                        else {
-                            const uint32_t k = atomicAdd(&a.stats->n_big, 1u);      // one workgroup per such cluster later
+                        if (len > MID_MAX) {                          // one workgroup per such cluster later
+                            const uint32_t k = atomicAdd(&a.stats->n_big, 1u);
                             if (k < a.big_cap) { a.big[k].pStart = lo + p; a.big[k].len = len; }
                         }
+                    }
+                    // SMALL_MAX+1 .. MID_MAX symbols: scored at once, the whole wave one lane group on the
+                    // staged window (such a cluster closes inside the window + read-ahead)
+                    uint64_t mm = __ballot(len > SMALL_MAX && len <= MID_MAX);
+                    while (mm) {
+                        const uint32_t l0 = (uint32_t)__builtin_ctzll(mm);
+                        mm &= mm - 1ull;
+                        const uint32_t p0 = rl32(p, l0), len0 = rl32(len, l0);
+                        const bool hv = lane < len0;
+                        acc_upd += group_score<EBWT, 64>(a, T, qu, hv ? L.da[p0 + lane] : 0u, (EBWT && hv) ? L.fl[p0 + lane] : 0u, len0);
                     }
                 }
                 acc_max = len > acc_max ? len : acc_max;
@@ -847,16 +970,17 @@ __global__ __launch_bounds__(SCANK_WG) __attribute__((amdgpu_waves_per_eu(LIME_S
                 }
                 const bool sm4 = on && len <= 4u;
                 PT(4)
-                if (a.ablate != 10) acc_upd += score_small<EBWT>(L, T, qu, ms, a, lo, sm4, sm4 ? p : 0u, sm4 ? len : 0u);
+                if (a.ablate != 10) acc_upd += score_small<EBWT>(L, T, qu, ms, n_dup, a, lo, sm4, sm4 ? p : 0u, sm4 ? len : 0u);
                 PT(5)
             }
             if (nM && a.ablate != 10 && a.ablate != 11) {
 #ifdef LIME_PHASE_TIMING
-                acc_upd += score_medium<EBWT>(L, T, qu, ms, a, lo, nM, pt_m); ++pt_nwin;
+                acc_upd += score_medium<EBWT>(L, T, qu, ms, n_dup, a, lo, nM, pt_m); ++pt_nwin;
 #else
-                acc_upd += score_medium<EBWT>(L, T, qu, ms, a, lo, nM);
+                acc_upd += score_medium<EBWT>(L, T, qu, ms, n_dup, a, lo, nM);
 #endif
             }
+            if (n_dup >= DUP_SLOTS / 2u) acc_upd += dup_flush<EBWT>(L, n_dup, a, T, qu);
             PT(6)
             }
         } else {
@@ -899,8 +1023,9 @@ __global__ __launch_bounds__(SCANK_WG) __attribute__((amdgpu_waves_per_eu(LIME_S
         win = next;
     }
     if (MODE == 0) {
+        if (n_dup) acc_upd += dup_flush<EBWT>(L, n_dup, a, T, qu);
         do drain(qu, a); while (qu.n != 0u || __ballot(qu.f_pend != 0u));      // until every update has landed
-        med_fill(a, ms, 1u);
+        med_fill(a, ms, 0u); med_fill(a, ms, 1u);
     }
 #ifdef LIME_PHASE_TIMING
     PT(7)
@@ -1049,26 +1174,22 @@ __global__ __launch_bounds__(SCAN_WG) void k_score_list(ScanArgs a, const lime_c
 }
 
 // =========================================================================================
-// k_score_med: the clusters the scan listed instead of scoring (5..SMALL_MAX symbols, or a
-// repeated document).  G = 8 or 16 lanes per cluster (list 0: <= 8 symbols, list 1: longer),
-// element i on sub-lane i, read straight from global memory; XOR-ing the sub-lane with 1..G-1
-// shows every lane every other element of its cluster.  With all documents distinct each read
-// lane scores each compatible genome it meets; a cluster with a repeated document is staged in
-// LDS and scored by the general routine.
+// k_score_med: the clusters the scan listed instead of scoring: list 1 = 2..SMALL_MAX symbols
+// with a repeated document (G = 16 lanes per cluster), list 0 = SMALL_MAX+1..64 symbols (G = 64).
+// Element i of a cluster sits on sub-lane i, read straight from global memory; XOR-ing the
+// sub-lane with 1..R (R + 1 = the power of two covering the longest cluster of the wave) shows
+// every lane every other element of its cluster.  General score, element per lane.  Pass 1: is
+// this element the first of its document, and the document's count / 16-bin histogram over the
+// cluster (counts <= 64: no wrap, no saturation).  Pass 2: every first-occurrence read meets
+// every first-occurrence genome once (pair_score; ClusterBWT_DA.cpp:107-190 / :192-252).
 // =========================================================================================
 template <int EBWT, int G>
-__global__ __launch_bounds__(SCAN_WG) void k_score_med(ScanArgs a)
+__device__ __forceinline__ uint32_t score_groups(const ScanArgs &a, const WgTables &T, UpdQueue &qu,
+                                                 const uint64_t *med, uint32_t n)
 {
-    __shared__ WgTables T;
-    __shared__ uint32_t s_qr[SCAN_WG / 64][QCAP], s_qg[SCAN_WG / 64][QCAP];
-    constexpr uint32_t PER = 64u / G, WHICH = G == 8 ? 0u : 1u;
+    constexpr uint32_t PER = 64u / G;
     const uint32_t lane = lane_id(), wave = threadIdx.x >> 6, sub = lane & (G - 1u), grp = lane / G;
-    tables_init(T);
-    UpdQueue qu; qu.qr = s_qr[wave]; qu.qg = s_qg[wave]; qu.n = 0; qu.cap = QCAP;
-    const uint64_t *med = a.med + (size_t)WHICH * a.med_cap;
-    const uint32_t n = a.stats->n_med[WHICH] < a.med_cap ? a.stats->n_med[WHICH] : a.med_cap;
     const uint32_t n_it = (n + PER - 1u) / PER, stride = gridDim.x * (SCAN_WG / 64);
-    const uint64_t gm = (((1ull << (G - 1)) << 1) - 1ull) << (lane & ~(G - 1u));
     uint32_t acc_upd = 0;
     // software pipeline over the wave's iterations: the record of iteration i+2 and the elements
     // of iteration i+1 are in flight while iteration i is scored
@@ -1094,78 +1215,23 @@ __global__ __launch_bounds__(SCAN_WG) void k_score_med(ScanArgs a)
             if (sub < l1) { const uint64_t q = (rec1 & 0xFFFFFFFFFFFFull) + sub; d1 = a.da[q]; if (EBWT) b1 = a.ebwt[q]; }
         }
         if (__ballot(rec != 0ull) == 0ull || a.ablate == 6) continue;
-        const uint32_t len = rec ? (uint32_t)(rec >> 48) + 1u : 0u;
-        const bool have = sub < len;
-        const uint32_t sy = (EBWT && have) ? T.symidx[bb] : 0u;
-        const bool isr = have && d < a.n_reads;
-        const uint32_t f = have ? (sy | (isr ? F_READ : F_GEN)) : 0u;
-        const uint32_t cs = EBWT ? T.compat[sy] : 0xFFFFu;
-        uint32_t dup = 0, hits = 0, bad = 0;
-#pragma unroll
-        for (int r = 1; r < G; ++r) {
-            const uint32_t pd = __shfl_xor(d, r), pf = __shfl_xor(f, r);
-            const bool both = f && pf;
-            dup |= (uint32_t)(both && pd == d);
-            const uint32_t g = pd - a.n_reads;
-            uint32_t ok = (uint32_t)(both && isr && (pf & F_GEN)) & ((cs >> (pf & F_SYM)) & 1u);
-            bad |= ok & (uint32_t)(g >= a.n_refs);
-            ok &= (uint32_t)(g < a.n_refs);
-            hits |= ok << r;
-        }
-        const bool gdup = (__ballot(dup != 0u) & gm) != 0ull;
-        if (__ballot(bad != 0u)) { if (bad && !gdup) atomicOr(&a.stats->flags, LIME_FLAG_DOCID); }
-        if (gdup) hits = 0u;
-        acc_upd += (uint32_t)__popc(hits);
-        // a lane can hit up to G-1 times: to the queue in rounds of at most 4 per lane
-        while (__ballot(hits != 0u)) {
-            if (qu.n > QCAP - 256u) drain(qu, a);
-            uint32_t take = 0, hsel = 0;
-#pragma unroll
-            for (int r = 1; r < G; ++r) { const uint32_t on = ((hits >> r) & 1u) & (uint32_t)(take < 4u); hsel |= on << r; take += on; }
-            const uint32_t incl = wave_incl_scan(take);
-            uint32_t slot = qu.n + incl - take;
-#pragma unroll
-            for (int r = 1; r < G; ++r) {
-                const uint32_t pd = __shfl_xor(d, r);
-                if ((hsel >> r) & 1u) { qu.qr[slot] = d; qu.qg[slot] = (pd - a.n_reads) | (1u << T_SHIFT); ++slot; }
-            }
-            qu.n += rl32(incl, 63);
-            hits &= ~hsel;
-        }
-        if (__ballot(gdup) && a.ablate != 7) {
-            // a repeated document somewhere in the group: the general score, still element-per-lane.
-            // Pass 1: is this element the first of its document, and the document's count / 16-bin
-            // histogram over the cluster (counts <= SMALL_MAX: no wrap, no saturation).  Pass 2: every
-            // first-occurrence read meets every first-occurrence genome once.
-            uint32_t earlier = 0, cnt = have ? 1u : 0u, hs[4] = {0u, 0u, 0u, 0u};
-            if (EBWT) hist_add(hs, sy, (uint32_t)have);
-#pragma unroll 1
-            for (int r = 1; r < G; ++r) {
-                const uint32_t pd = __shfl_xor(d, r), pf = __shfl_xor(f, r);
-                const uint32_t same = (uint32_t)(f && pf && pd == d);
-                earlier |= same & (uint32_t)((sub ^ (uint32_t)r) < sub);
-                cnt += same;
-                if (EBWT) hist_add(hs, pf & F_SYM, same);
-            }
-            const uint32_t lead = (uint32_t)(have && !earlier);
-#pragma unroll 1
-            for (int r = 1; r < G; ++r) {
-                const uint32_t pd = __shfl_xor(d, r), pf = __shfl_xor(f, r), pl = __shfl_xor(lead, r), pc = __shfl_xor(cnt, r);
-                uint32_t ph[4] = {0u, 0u, 0u, 0u};
-                if (EBWT) { ph[0] = __shfl_xor(hs[0], r); ph[1] = __shfl_xor(hs[1], r); ph[2] = __shfl_xor(hs[2], r); ph[3] = __shfl_xor(hs[3], r); }
-                const bool pair = gdup && lead && isr && pl && (pf & F_GEN);
-                if (__ballot(pair) == 0ull) continue;
-                uint32_t t = cnt < pc ? cnt : pc;
-                if (EBWT) {
-                    uint32_t h2[4], p2[4];           // only real pairs go through the (possibly slow) score
-#pragma unroll
-                    for (int k = 0; k < 4; ++k) { h2[k] = pair ? hs[k] : 0u; p2[k] = pair ? ph[k] : 0u; }
-                    t = pair_score(h2, p2);
-                }
-                acc_upd += emit(qu, a, pair && t, d, pd, t);
-            }
-        }
+        acc_upd += group_score<EBWT, G>(a, T, qu, d, bb, rec ? (uint32_t)(rec >> 48) + 1u : 0u);
     }
+    return acc_upd;
+}
+
+template <int EBWT>
+__global__ __launch_bounds__(SCAN_WG) void k_score_med(ScanArgs a)
+{
+    __shared__ WgTables T;
+    __shared__ uint32_t s_qr[SCAN_WG / 64][QCAP], s_qg[SCAN_WG / 64][QCAP];
+    const uint32_t lane = lane_id(), wave = threadIdx.x >> 6;
+    tables_init(T);
+    UpdQueue qu; qu.qr = s_qr[wave]; qu.qg = s_qg[wave]; qu.n = 0; qu.cap = QCAP;
+    const uint32_t n1 = a.stats->n_med[1] < a.med_cap ? a.stats->n_med[1] : a.med_cap;
+    const uint32_t n0 = a.stats->n_med[0] < a.med_cap ? a.stats->n_med[0] : a.med_cap;
+    uint32_t acc_upd = score_groups<EBWT, 16>(a, T, qu, a.med + (size_t)a.med_cap, n1);
+    if (n0) acc_upd += score_groups<EBWT, 64>(a, T, qu, a.med, n0);
     drain(qu, a);
     const uint32_t tu = wave_sum(acc_upd);
     if (lane == 0 && tu) atomicAdd(&a.stats->n_updates, (unsigned long long)tu);
@@ -1375,10 +1441,13 @@ void launch_score_list(int ebwt, const ScanArgs &a, const lime_cluster_t *list, 
 void launch_score_med(int ebwt, const ScanArgs &a, uint32_t blocks, hipStream_t st)
 {
     static uint32_t res[2] = {0, 0};                 // workgroups that fit the device at once, per instantiation
-    if (!res[0]) { res[0] = resident_blocks(k_score_med<1, 16>, SCAN_WG); res[1] = resident_blocks(k_score_med<0, 16>, SCAN_WG); }
-    (void)blocks;
-    if (ebwt) hipLaunchKernelGGL((k_score_med<1, 16>), dim3(res[0]), dim3(SCAN_WG), 0, st, a);
-    else      hipLaunchKernelGGL((k_score_med<0, 16>), dim3(res[1]), dim3(SCAN_WG), 0, st, a);
+    if (!res[0]) { res[0] = resident_blocks(k_score_med<1>, SCAN_WG); res[1] = resident_blocks(k_score_med<0>, SCAN_WG); }
+    // the lists are normally empty (the scan scores these clusters itself unless its per-wave store
+    // overflows): a small grid keeps the empty launch short
+    const uint32_t cap = blocks ? blocks : 256u;
+    const uint32_t g1 = res[0] < cap ? res[0] : cap, g0 = res[1] < cap ? res[1] : cap;
+    if (ebwt) hipLaunchKernelGGL((k_score_med<1>), dim3(g1), dim3(SCAN_WG), 0, st, a);
+    else      hipLaunchKernelGGL((k_score_med<0>), dim3(g0), dim3(SCAN_WG), 0, st, a);
 }
 
 void launch_score_big(int ebwt, const ScanArgs &a, uint32_t *scratch, hipStream_t st)
