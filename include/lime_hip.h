@@ -44,6 +44,10 @@ typedef struct lime_ctx lime_ctx;
 /* == ElementCluster, Tools.h:85-88; record of fileFasta.<alpha>.clrs */
 typedef struct { uint64_t pStart, len; } lime_cluster_t;
 
+/* a non-zero cell of a read's table row: the (idRef, sim) pair clusterChoose collects
+ * (ClusterBWT_DA.cpp:390-402; the reference's pair_sim holds sim already divided by norm) */
+typedef struct { uint32_t id_ref, sim; } lime_pair_t;
+
 /* Counters of the last scan on a ctx (device-resident until lime_get_stats syncs). */
 typedef struct {
     uint64_t n_clusters;   /* ClusterLCP.cpp:136 nClusters                                  */
@@ -100,6 +104,15 @@ int lime_fused(lime_ctx *ctx, const uint32_t *lcp, const uint32_t *da, const uin
 int lime_choose(lime_ctx *ctx, const uint8_t *sim, uint32_t n_reads, uint32_t n_refs,
                 uint8_t *row_max, uint32_t *row_nnz);
 
+/* clusterAnalyze + clusterChoose in one call (what the ClusterBWT_DA program does between reading
+ * its inputs and writing .res.*, ClusterBWT_DA.cpp:605-443): like lime_score, but the table never
+ * leaves the device; outputs as lime_choose_pairs_dev.  sim may be NULL (else it receives the table). */
+int lime_score_choose(lime_ctx *ctx, const uint32_t *da, const uint8_t *ebwt, uint64_t n,
+                      const lime_cluster_t *clusters, uint64_t n_clusters,
+                      uint32_t n_reads, uint32_t n_refs, uint32_t norm, float beta,
+                      uint8_t *row_max, uint64_t *row_off, lime_pair_t **pairs, uint64_t *n_pairs,
+                      uint8_t *sim);
+
 /* ---- device-pointer API (arrays already resident in HBM; asynchronous on `stream`) ----- *
  * `stream` is a hipStream_t passed as void* (NULL = default stream).  Device arrays must be
  * 16-byte aligned (hipMalloc is) and d_sim must be allocated with lime_sim_bytes() bytes.   */
@@ -134,6 +147,15 @@ int lime_score_dev(lime_ctx *ctx, const uint32_t *d_da, const uint8_t *d_ebwt, u
 int lime_choose_dev(lime_ctx *ctx, const uint8_t *d_sim, uint32_t n_reads, uint32_t n_refs,
                     uint8_t *d_row_max, uint32_t *d_row_nnz, void *stream);
 
+/* clusterChoose with the table left in HBM (ClusterBWT_DA.cpp:385-423): the row scan AND the
+ * (idRef, sim) lists of the reads that pass `float(max)/norm > beta` (:404-406) are made on the
+ * device; only row_max (n_reads bytes) and the compact lists come back.  HOST outputs:
+ * row_max[n_reads], row_off[n_reads+1] (cells of read r = pairs[row_off[r] .. row_off[r+1]),
+ * ascending idRef; empty for a read that does not pass), *pairs library-allocated (lime_free). */
+int lime_choose_pairs_dev(lime_ctx *ctx, const uint8_t *d_sim, uint32_t n_reads, uint32_t n_refs,
+                          uint32_t norm, float beta, uint8_t *row_max, uint64_t *row_off,
+                          lime_pair_t **pairs, uint64_t *n_pairs, void *stream);
+
 /* Synthetic inputs of SURVEY.md section 8(d): element i is a pure function of (seed, i0+i).
  * Any of the three outputs may be NULL.  mode 0 = iid, 1 = block-correlated symbols. */
 int lime_synth_dev(lime_ctx *ctx, uint64_t seed, uint64_t i0, uint64_t count,
@@ -165,6 +187,12 @@ int lime_write_res_txt(const char *path, const uint8_t *sim, const uint8_t *row_
 int lime_write_res_bin(const char *path_bin, const char *path_pos, const uint8_t *sim,
                        const uint8_t *row_max, uint32_t n_reads, uint32_t n_refs,
                        uint32_t norm, float beta);
+/* the same files from the compact form of lime_choose_pairs_dev / lime_score_choose */
+int lime_write_res_txt_pairs(const char *path, const uint8_t *row_max, const uint64_t *row_off,
+                             const lime_pair_t *pairs, uint32_t n_reads, uint32_t norm, float beta);
+int lime_write_res_bin_pairs(const char *path_bin, const char *path_pos, const uint8_t *row_max,
+                             const uint64_t *row_off, const lime_pair_t *pairs, uint32_t n_reads,
+                             uint32_t norm, float beta);
 
 #ifdef __cplusplus
 }

@@ -85,6 +85,41 @@ class Context:
         check(self.lib.lime_choose(self.h, sim.ctypes.data, nr, ng, mx.ctypes.data, nz.ctypes.data))
         return mx, nz
 
+    def _pairs_out(self, pp, npairs):
+        n = int(npairs.value)
+        out = np.zeros((n, 2), dtype=np.uint32)
+        if n:
+            C.memmove(out.ctypes.data, pp.value, n * 8)
+        self.lib.lime_free(pp)
+        return out
+
+    def score_choose(self, da, ebwt, clusters, n_reads, n_refs, norm, beta, want_sim=False):
+        """clusterAnalyze + clusterChoose with the table kept in HBM -> (row_max u8[n_reads],
+        row_off u64[n_reads+1], pairs u32[n,2] = (idRef, sim)[, sim])."""
+        da = np.ascontiguousarray(da, dtype=np.uint32)
+        cl = np.ascontiguousarray(clusters, dtype=np.uint64).reshape(-1, 2)
+        eb = None if ebwt is None else np.ascontiguousarray(ebwt, dtype=np.uint8)
+        mx = np.zeros(n_reads + 1, dtype=np.uint8)
+        off = np.zeros(n_reads + 2, dtype=np.uint64)
+        sim = np.zeros((n_reads, n_refs), dtype=np.uint8) if want_sim else None
+        pp, npairs = C.c_void_p(), C.c_uint64(0)
+        check(self.lib.lime_score_choose(self.h, da.ctypes.data, None if eb is None else eb.ctypes.data, len(da),
+                                         cl.ctypes.data if len(cl) else None, len(cl), n_reads, n_refs, norm, beta,
+                                         mx.ctypes.data, off.ctypes.data, C.byref(pp), C.byref(npairs),
+                                         None if sim is None else sim.ctypes.data))
+        pairs = self._pairs_out(pp, npairs)
+        res = (mx[:n_reads], off[:n_reads + 1], pairs)
+        return res + (sim,) if want_sim else res
+
+    def choose_pairs_dev(self, sim_t, n_reads, n_refs, norm, beta, stream=None):
+        """clusterChoose of a device-resident table -> (row_max, row_off, pairs) on the host."""
+        mx = np.zeros(n_reads + 1, dtype=np.uint8)
+        off = np.zeros(n_reads + 2, dtype=np.uint64)
+        pp, npairs = C.c_void_p(), C.c_uint64(0)
+        check(self.lib.lime_choose_pairs_dev(self.h, _ptr(sim_t), n_reads, n_refs, norm, beta, mx.ctypes.data,
+                                             off.ctypes.data, C.byref(pp), C.byref(npairs), stream))
+        return mx[:n_reads], off[:n_reads + 1], self._pairs_out(pp, npairs)
+
     # ---- array level, device pointers (torch tensors on this ctx's device) ---------------
     def stats(self, stream=None):
         s = Stats()

@@ -2,7 +2,7 @@
 // (<base>.out, fileFasta.<alpha>.clrs, fileFasta.da, fileFasta.ebwt), same outputs
 // (fileFasta.res.bin + .res.pos, or fileFasta.res.txt).  The reference's compile-time
 // switches are runtime here: LIME_EBWT (default 1, Makefile:13) and LIME_BIN (default 1,
-// Makefile:12).  Scoring runs on the MI355X through lime_score / lime_choose.
+// Makefile:12).  Scoring and the row scan run on the MI355X through lime_score_choose.
 #include <chrono>
 #include <iostream>
 #include <sstream>
@@ -60,25 +60,27 @@ int main(int argc, char **argv)
     std::cerr << "Computing similarity arrays SimArray_i[1,numRead]..." << std::endl;
     lime_ctx *ctx = nullptr;
     if (lime_init(pick_device(), &ctx) != LIME_OK) { std::cerr << "Error: " << lime_last_error() << std::endl; exit(EXIT_FAILURE); }
-    std::vector<uint8_t> sim((size_t)numRead * numRef + 16, 0);
-    int rc = lime_score(ctx, (const uint32_t *)da.data, EBWT ? (const uint8_t *)bwt.data : nullptr, n,
-                        (const lime_cluster_t *)clrs.data, nClusters, numRead, numRef, sim.data());
+    // the table stays in HBM: the row scan and the (idRef, sim) lists of the passing reads are made
+    // on the device and only those come back (lime_score_choose)
+    std::vector<uint8_t> rmax((size_t)numRead + 1);
+    std::vector<uint64_t> roff((size_t)numRead + 2);
+    lime_pair_t *pairs = nullptr; uint64_t nPairs = 0;
+    int rc = lime_score_choose(ctx, (const uint32_t *)da.data, EBWT ? (const uint8_t *)bwt.data : nullptr, n,
+                               (const lime_cluster_t *)clrs.data, nClusters, numRead, numRef, norm, beta,
+                               rmax.data(), roff.data(), &pairs, &nPairs, nullptr);
     if (rc != LIME_OK) { std::cerr << "Error: " << lime_last_error() << std::endl; exit(1); }
     fprintf(stderr, "TIME clusterAnalyze: %.6lf\n", std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count());
 
     auto t1 = std::chrono::steady_clock::now();
-    std::vector<uint8_t> rmax(numRead + 1);
-    std::vector<uint32_t> rnnz(numRead + 1);
-    rc = lime_choose(ctx, sim.data(), numRead, numRef, rmax.data(), rnnz.data());
-    if (rc != LIME_OK) { std::cerr << "Error: " << lime_last_error() << std::endl; exit(1); }
     const std::string fnF = fileFasta + ".res";
     if (BIN) {
         std::cerr << "Writing " << fnF << ".pos" << std::endl << "Writing " << fnF << ".bin" << std::endl;
-        rc = lime_write_res_bin((fnF + ".bin").c_str(), (fnF + ".pos").c_str(), sim.data(), rmax.data(), numRead, numRef, norm, beta);
+        rc = lime_write_res_bin_pairs((fnF + ".bin").c_str(), (fnF + ".pos").c_str(), rmax.data(), roff.data(), pairs, numRead, norm, beta);
     } else {
         std::cerr << "Writing " << fnF << ".txt" << std::endl;
-        rc = lime_write_res_txt((fnF + ".txt").c_str(), sim.data(), rmax.data(), numRead, numRef, norm, beta);
+        rc = lime_write_res_txt_pairs((fnF + ".txt").c_str(), rmax.data(), roff.data(), pairs, numRead, norm, beta);
     }
+    lime_free(pairs);
     if (rc != LIME_OK) { std::cerr << "Error opening " << fnF << "." << std::endl; exit(EXIT_FAILURE); }
     fprintf(stdout, "Time: %.6lf\n", std::chrono::duration<double>(std::chrono::steady_clock::now() - t1).count());
     lime_shutdown(ctx);

@@ -461,6 +461,73 @@ extern "C" int lime_choose(lime_ctx *c, const uint8_t *sim, uint32_t n_reads, ui
     return LIME_OK;
 }
 
+// clusterChoose on the device, compact results to the host
+extern "C" int lime_choose_pairs_dev(lime_ctx *c, const uint8_t *d_sim, uint32_t n_reads, uint32_t n_refs,
+                                     uint32_t norm, float beta, uint8_t *row_max, uint64_t *row_off,
+                                     lime_pair_t **pairs, uint64_t *n_pairs, void *stream)
+{
+    int rc = check_ctx(c, "lime_choose_pairs_dev"); if (rc) return rc;
+    if (!pairs || !n_pairs || !row_off || (n_reads && (!d_sim || !row_max)))
+        return fail(LIME_ERR_ARG, "lime_choose_pairs_dev: NULL array");
+    *pairs = nullptr; *n_pairs = 0; row_off[0] = 0;
+    if (!n_reads) return LIME_OK;
+    if (misaligned(d_sim, 4)) return fail(LIME_ERR_ARG, "lime_choose_pairs_dev: d_sim must be 4-byte aligned");
+    hipStream_t st = (hipStream_t)stream;
+    DevBuf dm, dz, doff, dp;
+    if ((rc = dm.alloc(n_reads))) return rc;
+    if ((rc = dz.alloc((size_t)n_reads * 4))) return rc;
+    launch_choose(d_sim, n_reads, n_refs, (uint8_t *)dm.p, (uint32_t *)dz.p, st);
+    HIP_TRY(hipGetLastError());
+    std::vector<uint32_t> nnz(n_reads);
+    HIP_TRY(hipMemcpyAsync(row_max, dm.p, n_reads, hipMemcpyDeviceToHost, st));
+    HIP_TRY(hipMemcpyAsync(nnz.data(), dz.p, (size_t)n_reads * 4, hipMemcpyDeviceToHost, st));
+    HIP_TRY(hipStreamSynchronize(st));
+    // the reference's test, in the reference's types (ClusterBWT_DA.cpp:404-406)
+    uint64_t total = 0;
+    for (uint32_t r = 0; r < n_reads; ++r) {
+        const float top = static_cast<float>(row_max[r]) / norm;
+        row_off[r] = total;
+        if (top > beta) total += nnz[r];
+    }
+    row_off[n_reads] = total;
+    *n_pairs = total;
+    if (!total) return LIME_OK;
+    if ((rc = doff.upload(row_off, ((size_t)n_reads + 1) * 8))) return rc;
+    if ((rc = dp.alloc((size_t)total * sizeof(lime_pair_t)))) return rc;
+    launch_gather_pairs(d_sim, n_reads, n_refs, (const uint64_t *)doff.p, (lime_pair_t *)dp.p, st);
+    HIP_TRY(hipGetLastError());
+    lime_pair_t *h = (lime_pair_t *)malloc((size_t)total * sizeof(lime_pair_t));
+    if (!h) return fail(LIME_ERR_NOMEM, "lime_choose_pairs_dev: out of host memory");
+    hipError_t e = hipMemcpyAsync(h, dp.p, (size_t)total * sizeof(lime_pair_t), hipMemcpyDeviceToHost, st);
+    if (e == hipSuccess) e = hipStreamSynchronize(st);
+    if (e != hipSuccess) { free(h); return fail(LIME_ERR_HIP, "hipMemcpy: %s", hipGetErrorString(e)); }
+    *pairs = h;
+    return LIME_OK;
+}
+
+extern "C" int lime_score_choose(lime_ctx *c, const uint32_t *da, const uint8_t *ebwt, uint64_t n,
+                                 const lime_cluster_t *clusters, uint64_t n_clusters, uint32_t n_reads,
+                                 uint32_t n_refs, uint32_t norm, float beta, uint8_t *row_max, uint64_t *row_off,
+                                 lime_pair_t **pairs, uint64_t *n_pairs, uint8_t *sim)
+{
+    int rc = check_ctx(c, "lime_score_choose"); if (rc) return rc;
+    if ((n && !da) || (n_clusters && !clusters)) return fail(LIME_ERR_ARG, "lime_score_choose: NULL array");
+    DevBuf dd, de, dc, ds;
+    if ((rc = dd.upload(da, n * 4))) return rc;
+    if (ebwt && (rc = de.upload(ebwt, n))) return rc;
+    if ((rc = dc.upload(clusters, n_clusters * sizeof(lime_cluster_t)))) return rc;
+    if ((rc = ds.alloc(lime_sim_bytes(n_reads, n_refs)))) return rc;
+    rc = lime_score_dev(c, (const uint32_t *)dd.p, ebwt ? (const uint8_t *)de.p : nullptr, n,
+                        (const lime_cluster_t *)dc.p, n_clusters, n_reads, n_refs, (uint8_t *)ds.p, 1, nullptr);
+    if (rc) return rc;
+    lime_stats_t s;
+    if ((rc = lime_get_stats(c, &s, nullptr))) return rc;
+    if ((rc = lime_choose_pairs_dev(c, (const uint8_t *)ds.p, n_reads, n_refs, norm, beta, row_max, row_off, pairs,
+                                    n_pairs, nullptr))) return rc;
+    if (sim) HIP_TRY(hipMemcpy(sim, ds.p, (size_t)n_reads * n_refs, hipMemcpyDeviceToHost));
+    return LIME_OK;
+}
+
 // ---- pure host helpers ------------------------------------------------------------------
 extern "C" uint8_t lime_sym_index(uint8_t b) { return (uint8_t)sym_index(b); }
 

@@ -123,3 +123,62 @@ extern "C" int lime_write_res_bin(const char *path_bin, const char *path_pos, co
     int e1 = ob.close(), e2 = op.close();
     return (e1 || e2) ? LIME_ERR_IO : LIME_OK;
 }
+
+// ---- the same two outputs from the compact form (row_max, row_off, pairs) -----------------
+extern "C" int lime_write_res_txt_pairs(const char *path, const uint8_t *row_max, const uint64_t *row_off,
+                                        const lime_pair_t *pairs, uint32_t n_reads, uint32_t norm, float beta)
+{
+    File o(path, "w");
+    if (!o.f) return LIME_ERR_IO;
+    std::vector<char> buf(1 << 16);
+    setvbuf(o.f, buf.data(), _IOFBF, buf.size());
+    for (uint32_t r = 0; r < n_reads; ++r) {
+        const float top = static_cast<float>(row_max[r]) / norm;
+        if (top > beta) {
+            fprintf(o.f, "%.5f", top);
+            for (uint64_t k = row_off[r]; k < row_off[r + 1]; ++k)
+                fprintf(o.f, "\t%u\t%.5f", pairs[k].id_ref, static_cast<float>(static_cast<uint8_t>(pairs[k].sim)) / norm);
+        }
+        fputc('\n', o.f);
+    }
+    return o.close() ? LIME_ERR_IO : LIME_OK;
+}
+
+extern "C" int lime_write_res_bin_pairs(const char *path_bin, const char *path_pos, const uint8_t *row_max,
+                                        const uint64_t *row_off, const lime_pair_t *pairs, uint32_t n_reads,
+                                        uint32_t norm, float beta)
+{
+    File ob(path_bin, "wb"), op(path_pos, "wb");
+    if (!ob.f || !op.f) return LIME_ERR_IO;
+    std::vector<PairSim> recs;
+    std::vector<uint64_t> pos;
+    recs.reserve(1 << 15); pos.reserve(1 << 15);
+    uint64_t total = 1;
+    PairSim sentinel = {0.0f, 0u};
+    if (fwrite(&sentinel, sizeof sentinel, 1, ob.f) != 1) return LIME_ERR_IO;
+    for (uint32_t r = 0; r < n_reads; ++r) {
+        const float top = static_cast<float>(row_max[r]) / norm;
+        if (top > beta) {
+            const uint32_t cnt = (uint32_t)(row_off[r + 1] - row_off[r]);
+            recs.push_back(PairSim{top, cnt});
+            for (uint64_t k = row_off[r]; k < row_off[r + 1]; ++k)
+                recs.push_back(PairSim{static_cast<float>(static_cast<uint8_t>(pairs[k].sim)) / norm, pairs[k].id_ref});
+            pos.push_back(total);
+            total += 1u + cnt;
+        } else {
+            pos.push_back(0);
+        }
+        if (recs.size() >= (1u << 15)) {
+            if (fwrite(recs.data(), sizeof(PairSim), recs.size(), ob.f) != recs.size()) return LIME_ERR_IO;
+            recs.clear();
+        }
+        if (pos.size() >= (1u << 15)) {
+            if (fwrite(pos.data(), 8, pos.size(), op.f) != pos.size()) return LIME_ERR_IO;
+            pos.clear();
+        }
+    }
+    if (!recs.empty() && fwrite(recs.data(), sizeof(PairSim), recs.size(), ob.f) != recs.size()) return LIME_ERR_IO;
+    if (!pos.empty() && fwrite(pos.data(), 8, pos.size(), op.f) != pos.size()) return LIME_ERR_IO;
+    int e1 = ob.close(), e2 = op.close();
+    return (e1 || e2) ? LIME_ERR_IO : LIME_OK;
+}

@@ -50,6 +50,8 @@ void launch_tile(int ebwt, int mode, const ScanArgs &a, uint32_t max_blocks, hip
 void launch_resolve(int mode, const ScanArgs &a, hipStream_t st);
 void launch_scan_tiles(const uint32_t *cnt, uint64_t *off, uint32_t n, unsigned long long *total, hipStream_t st);
 void launch_score_list(int ebwt, const ScanArgs &a, const lime_cluster_t *list, uint64_t count, uint32_t blocks, hipStream_t st);
+void launch_gather_pairs(const uint8_t *sim, uint32_t n_reads, uint32_t n_refs, const uint64_t *row_off,
+                         lime_pair_t *pairs, hipStream_t st);
 void launch_score_med(int ebwt, const ScanArgs &a, uint32_t blocks, hipStream_t st);
 void launch_score_big(int ebwt, const ScanArgs &a, uint32_t *scratch, hipStream_t st);
 void launch_choose(const uint8_t *sim, uint32_t n_reads, uint32_t n_refs, uint8_t *row_max,

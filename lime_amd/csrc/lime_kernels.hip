@@ -24,7 +24,6 @@ namespace lime {
 
 // ---- flag byte kept per staged position -------------------------------------------------
 constexpr uint32_t F_SYM = 0x0F;
-constexpr uint32_t F_HEAD = 0x10;
 constexpr uint32_t F_READ = 0x20;
 constexpr uint32_t F_GEN = 0x40;
 
@@ -1369,6 +1368,43 @@ __global__ __launch_bounds__(WGSZ) void k_choose(const uint8_t *sim, uint32_t n_
 }
 
 // =========================================================================================
+// k_gather_pairs: the non-zero cells of the selected table rows, compacted in ascending idRef
+// (the (idRef, sim) list of clusterChoose, ClusterBWT_DA.cpp:390-402).  One wave per row; cells of
+// row r go to pairs[row_off[r] .. row_off[r+1]) (an empty range skips the row).
+// =========================================================================================
+__global__ __launch_bounds__(WGSZ) void k_gather_pairs(const uint8_t *sim, uint32_t n_reads, uint32_t n_refs,
+                                                       const uint64_t *row_off, lime_pair_t *pairs)
+{
+    const uint32_t lane = threadIdx.x & 63u;
+    const uint64_t waves = (uint64_t)gridDim.x * (WGSZ / 64);
+    for (uint64_t r = (uint64_t)blockIdx.x * (WGSZ / 64) + (threadIdx.x >> 6); r < n_reads; r += waves) {
+        uint64_t out = row_off[r];
+        if (row_off[r + 1] == out) continue;
+        const uint64_t b0 = r * n_refs, b1 = b0 + n_refs;
+        const uint64_t w0 = b0 >> 2, w1 = (b1 + 3ull) >> 2;
+        for (uint64_t wb = w0; wb < w1; wb += 64u) {
+            const uint64_t w = wb + lane;
+            uint32_t v = w < w1 ? reinterpret_cast<const uint32_t *>(sim)[w] : 0u;
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {                      // bytes outside the row do not count
+                const uint64_t byte = w * 4ull + k;
+                if (byte < b0 || byte >= b1) v &= ~(255u << (8 * k));
+            }
+            const uint32_t nz = (uint32_t)((v & 0xFFu) != 0u) + (uint32_t)((v & 0xFF00u) != 0u) +
+                                (uint32_t)((v & 0xFF0000u) != 0u) + (uint32_t)((v >> 24) != 0u);
+            const uint32_t incl = wave_incl_scan(nz);
+            uint64_t o = out + incl - nz;
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                const uint32_t x = (v >> (8 * k)) & 255u;
+                if (x) { lime_pair_t pr; pr.id_ref = (uint32_t)(w * 4ull + k - b0); pr.sim = x; pairs[o++] = pr; }
+            }
+            out += rl32(incl, 63);
+        }
+    }
+}
+
+// =========================================================================================
 // k_synth: synthetic lcp/da/ebwt, element i a pure function of (seed, i0+i).
 // =========================================================================================
 __global__ __launch_bounds__(WGSZ) void k_synth(uint64_t seed, uint64_t i0, uint64_t count,
@@ -1463,6 +1499,14 @@ void launch_choose(const uint8_t *sim, uint32_t n_reads, uint32_t n_refs, uint8_
     if (blocks > 65536) blocks = 65536;
     if (!blocks) blocks = 1;
     hipLaunchKernelGGL(k_choose, dim3((uint32_t)blocks), dim3(WGSZ), 0, st, sim, n_reads, n_refs, row_max, row_nnz);
+}
+
+void launch_gather_pairs(const uint8_t *sim, uint32_t n_reads, uint32_t n_refs, const uint64_t *row_off,
+                         lime_pair_t *pairs, hipStream_t st)
+{
+    const uint64_t want = ((uint64_t)n_reads + WGSZ / 64 - 1) / (WGSZ / 64);
+    const uint32_t blocks = (uint32_t)(want < 16384u ? (want ? want : 1u) : 16384u);
+    hipLaunchKernelGGL(k_gather_pairs, dim3(blocks), dim3(WGSZ), 0, st, sim, n_reads, n_refs, row_off, pairs);
 }
 
 void launch_synth(uint64_t seed, uint64_t i0, uint64_t count, uint32_t n_reads, uint32_t n_refs,

@@ -60,6 +60,65 @@ def test_choose_golden(ctx, golden):
     assert np.array_equal(mx, emx) and np.array_equal(nz, enz)
 
 
+@pytest.mark.parametrize("ebwt_mode", [1, 0])
+def test_score_choose_writes_reference_files(ctx, golden, ebwt_mode, tmp_path):
+    """clusterAnalyze + clusterChoose with the table left on the device: the compact (row_max,
+    row_off, pairs) form written by the pair writers = the reference's .res.txt / .res.bin / .res.pos."""
+    import ctypes as C
+    eb = golden["ebwt"] if ebwt_mode else None
+    nr, ng = golden["n_reads"], golden["n_refs"]
+    norm, beta = golden["read_len"] + 1 - golden["alpha"], float(golden["beta"])
+    mx, off, pairs, sim = ctx.score_choose(golden["da"], eb, golden["clrs"], nr, ng, norm, beta, want_sim=True)
+    assert np.array_equal(sim, golden[f"sim_e{ebwt_mode}"])
+    emx, enz = O.choose(sim)
+    assert np.array_equal(mx, emx)
+    # the lists: non-zero cells of passing rows, ascending idRef
+    for r in range(nr):
+        row = pairs[int(off[r]):int(off[r + 1])]
+        if np.float32(mx[r]) / np.float32(norm) > np.float32(beta):
+            nzc = np.nonzero(sim[r])[0]
+            assert np.array_equal(row[:, 0], nzc) and np.array_equal(row[:, 1], sim[r][nzc])
+        else:
+            assert len(row) == 0
+    lib = ctx.lib
+    pr = np.ascontiguousarray(pairs)
+    mxa, offa = np.ascontiguousarray(mx), np.ascontiguousarray(off)
+    t, b, q = (str(tmp_path / n).encode() for n in ("r.txt", "r.bin", "r.pos"))
+    assert lib.lime_write_res_txt_pairs(t, mxa.ctypes.data, offa.ctypes.data, pr.ctypes.data, nr, norm, C.c_float(beta)) == 0
+    assert lib.lime_write_res_bin_pairs(b, q, mxa.ctypes.data, offa.ctypes.data, pr.ctypes.data, nr, norm, C.c_float(beta)) == 0
+    assert open(t, "rb").read() == golden[f"txt_e{ebwt_mode}"].tobytes()
+    assert open(b, "rb").read() == golden[f"bin_e{ebwt_mode}"].tobytes()
+    assert open(q, "rb").read() == golden[f"pos_e{ebwt_mode}"].tobytes()
+
+
+@pytest.mark.parametrize("n_reads,n_refs", [(1, 1), (7, 3), (300, 1), (129, 257), (1000, 930), (5, 5000)])
+def test_choose_pairs_dev_random_tables(ctx, n_reads, n_refs):
+    """compaction of a device-resident table vs numpy: ragged rows, widths that are not
+    multiples of 4, empty and full rows."""
+    import torch
+    rng = np.random.default_rng(n_reads * 7919 + n_refs)
+    sim = (rng.integers(0, 256, (n_reads, n_refs)) * (rng.random((n_reads, n_refs)) < 0.1)).astype(np.uint8)
+    if n_reads > 2:
+        sim[1] = 0
+        sim[2] = rng.integers(1, 256, n_refs)
+    import lime_amd
+    buf = torch.zeros(lime_amd.sim_bytes(n_reads, n_refs), dtype=torch.uint8, device="cuda:0")
+    buf[:n_reads * n_refs] = torch.from_numpy(sim.reshape(-1)).to("cuda:0")
+    norm, beta = 85, 0.25
+    mx, off, pairs = ctx.choose_pairs_dev(buf, n_reads, n_refs, norm, beta)
+    assert np.array_equal(mx, sim.max(axis=1))
+    total = 0
+    for r in range(n_reads):
+        row = pairs[int(off[r]):int(off[r + 1])]
+        if np.float32(mx[r]) / np.float32(norm) > np.float32(beta):
+            nzc = np.nonzero(sim[r])[0]
+            assert np.array_equal(row[:, 0], nzc) and np.array_equal(row[:, 1], sim[r][nzc])
+            total += len(nzc)
+        else:
+            assert len(row) == 0
+    assert total == len(pairs) == int(off[n_reads])
+
+
 # ---- the drop-in executables write the reference's bytes -----------------------------------
 @pytest.mark.parametrize("ebwt_mode,binary", [(1, 1), (1, 0), (0, 1), (0, 0)])
 def test_cli_dropin_files(golden, ebwt_mode, binary, tmp_path):
