@@ -99,6 +99,14 @@ int lime_fused(lime_ctx *ctx, const uint32_t *lcp, const uint32_t *da, const uin
                uint64_t n, uint32_t n_reads, uint32_t n_refs, uint32_t alpha,
                uint8_t *sim, uint64_t *n_clusters, uint64_t *max_len);
 
+/* lime_fused for collections of any size: the arrays stream from host memory (pageable or pinned)
+ * through HBM in position-range chunks of `chunk` symbols (0 = 64 Mi; rounded up to LIME_TILE), each
+ * with a read-ahead halo of LIME_MAX_CLUSTER + LIME_TILE positions, the copy of one chunk overlapping
+ * the scan of the previous one; the table stays in HBM until the end.  Same results as lime_fused. */
+int lime_fused_stream(lime_ctx *ctx, const uint32_t *lcp, const uint32_t *da, const uint8_t *ebwt,
+                      uint64_t n, uint32_t n_reads, uint32_t n_refs, uint32_t alpha, uint64_t chunk,
+                      uint8_t *sim, uint64_t *n_clusters, uint64_t *max_len);
+
 /* clusterChoose row scan, src/ClusterBWT_DA.cpp:385-402: per read the maximum cell and the
  * number of non-zero cells.  Normalisation/formatting stays on the host (:404-441). */
 int lime_choose(lime_ctx *ctx, const uint8_t *sim, uint32_t n_reads, uint32_t n_refs,

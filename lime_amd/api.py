@@ -77,6 +77,17 @@ class Context:
                                   len(lcp), n_reads, n_refs, alpha, sim.ctypes.data, C.byref(nc), C.byref(ml)))
         return sim, int(nc.value), int(ml.value)
 
+    def fused_stream(self, lcp, da, ebwt, n_reads, n_refs, alpha, chunk=0):
+        """lime_fused through HBM in position-range chunks (copy of chunk k+1 under the scan of chunk k)."""
+        lcp = np.ascontiguousarray(lcp, dtype=np.uint32)
+        da = np.ascontiguousarray(da, dtype=np.uint32)
+        eb = None if ebwt is None else np.ascontiguousarray(ebwt, dtype=np.uint8)
+        sim = np.zeros((n_reads, n_refs), dtype=np.uint8)
+        nc, ml = C.c_uint64(0), C.c_uint64(0)
+        check(self.lib.lime_fused_stream(self.h, lcp.ctypes.data, da.ctypes.data, None if eb is None else eb.ctypes.data,
+                                         len(lcp), n_reads, n_refs, alpha, chunk, sim.ctypes.data, C.byref(nc), C.byref(ml)))
+        return sim, int(nc.value), int(ml.value)
+
     def choose(self, sim):
         sim = np.ascontiguousarray(sim, dtype=np.uint8)
         nr, ng = sim.shape

@@ -223,19 +223,25 @@ extern "C" int lime_get_timing(lime_ctx *c, double *scan_ms_avg, uint64_t *launc
 }
 
 // ---- device-pointer API -----------------------------------------------------------------
-extern "C" int lime_fused_dev(lime_ctx *c, const uint32_t *d_lcp, const uint32_t *d_da, const uint8_t *d_ebwt,
-                              uint64_t n_own, uint64_t n_avail, int eof, uint32_t n_reads, uint32_t n_refs,
-                              uint32_t alpha, uint8_t *d_sim, int zero_sim, void *stream)
+// keep_stats: this call continues a position-range sequence on the same table (lime_fused_stream):
+// cluster / update counters and flags accumulate, only the per-call list counters restart.
+static int fused_dev_impl(lime_ctx *c, const uint32_t *d_lcp, const uint32_t *d_da, const uint8_t *d_ebwt,
+                          uint64_t n_own, uint64_t n_avail, int eof, uint32_t n_reads, uint32_t n_refs,
+                          uint32_t alpha, uint8_t *d_sim, int zero_sim, bool keep_stats, hipStream_t st)
 {
-    int rc = check_ctx(c, "lime_fused_dev"); if (rc) return rc;
-    hipStream_t st = (hipStream_t)stream;
+    int rc;
     if (n_own > n_avail) return fail(LIME_ERR_ARG, "lime_fused_dev: n_own > n_avail");
     if (n_avail && (!d_lcp || !d_da || !d_sim)) return fail(LIME_ERR_ARG, "lime_fused_dev: NULL array");
     if (misaligned(d_lcp, 16) || misaligned(d_da, 16) || misaligned(d_ebwt, 8) || misaligned(d_sim, 4))
         return fail(LIME_ERR_ARG, "lime_fused_dev: device arrays must be 16-byte aligned (ebwt: 8, sim: 4)");
     if (!n_reads || !n_refs) return fail(LIME_ERR_ARG, "lime_fused_dev: n_reads and n_refs must be > 0");
     if ((rc = ensure_scratch(c, n_avail, false, true, st))) return rc;
-    HIP_TRY(hipMemsetAsync(c->d_stats, 0, sizeof(DevStats), st));
+    if (keep_stats) {
+        HIP_TRY(hipMemsetAsync(&c->d_stats->n_cross, 0, 2 * sizeof(uint32_t), st));      // n_cross, n_big
+        HIP_TRY(hipMemsetAsync(&c->d_stats->n_med[0], 0, 2 * sizeof(uint32_t), st));
+    } else {
+        HIP_TRY(hipMemsetAsync(c->d_stats, 0, sizeof(DevStats), st));
+    }
     if (zero_sim) HIP_TRY(hipMemsetAsync(d_sim, 0, lime_sim_bytes(n_reads, n_refs), st));
     if (!n_avail) return LIME_OK;
     ScanArgs a = base_args(c, d_lcp, d_da, d_ebwt, n_own, n_avail, eof, n_reads, n_refs, alpha, d_sim);
@@ -248,6 +254,15 @@ extern "C" int lime_fused_dev(lime_ctx *c, const uint32_t *d_lcp, const uint32_t
     launch_score_big(ebwt, a, c->d_big_scratch, st);
     HIP_TRY(hipGetLastError());
     return LIME_OK;
+}
+
+extern "C" int lime_fused_dev(lime_ctx *c, const uint32_t *d_lcp, const uint32_t *d_da, const uint8_t *d_ebwt,
+                              uint64_t n_own, uint64_t n_avail, int eof, uint32_t n_reads, uint32_t n_refs,
+                              uint32_t alpha, uint8_t *d_sim, int zero_sim, void *stream)
+{
+    int rc = check_ctx(c, "lime_fused_dev"); if (rc) return rc;
+    return fused_dev_impl(c, d_lcp, d_da, d_ebwt, n_own, n_avail, eof, n_reads, n_refs, alpha, d_sim, zero_sim, false,
+                          (hipStream_t)stream);
 }
 
 extern "C" int lime_get_stats(lime_ctx *c, lime_stats_t *out, void *stream)
@@ -441,6 +456,82 @@ extern "C" int lime_fused(lime_ctx *c, const uint32_t *lcp, const uint32_t *da, 
     if (max_len) *max_len = s.max_len;
     if (rc) return rc;
     HIP_TRY(hipMemcpy(sim, ds.p, (size_t)n_reads * n_refs, hipMemcpyDeviceToHost));
+    return LIME_OK;
+}
+
+// ---- streaming from host memory: the collection goes through HBM in position-range chunks ------
+// Chunk k owns positions [k*chunk, (k+1)*chunk) and carries a read-ahead halo, exactly like a shard of
+// the multi-GPU partition (ClusterLCP.cpp:150-161,246-264); two device buffers alternate so that the
+// copy of chunk k+1 runs while chunk k is scanned; all chunks add into one table in HBM.
+namespace {
+struct Pipe {
+    hipStream_t copy = nullptr, comp = nullptr;
+    hipEvent_t copied[2] = {nullptr, nullptr}, consumed[2] = {nullptr, nullptr};
+    ~Pipe() {
+        for (int b = 0; b < 2; ++b) { if (copied[b]) (void)hipEventDestroy(copied[b]); if (consumed[b]) (void)hipEventDestroy(consumed[b]); }
+        if (copy) (void)hipStreamDestroy(copy);
+        if (comp) (void)hipStreamDestroy(comp);
+    }
+    int init() {
+        HIP_TRY(hipStreamCreateWithFlags(&copy, hipStreamNonBlocking));
+        HIP_TRY(hipStreamCreateWithFlags(&comp, hipStreamNonBlocking));
+        for (int b = 0; b < 2; ++b) {
+            HIP_TRY(hipEventCreateWithFlags(&copied[b], hipEventDisableTiming));
+            HIP_TRY(hipEventCreateWithFlags(&consumed[b], hipEventDisableTiming));
+        }
+        return LIME_OK;
+    }
+};
+const uint64_t STREAM_HALO = (uint64_t)LIME_MAX_CLUSTER + LIME_TILE;   // a run the reference accepts closes inside it
+const uint64_t STREAM_CHUNK = 64ull << 20;                              // default symbols per chunk
+}
+
+extern "C" int lime_fused_stream(lime_ctx *c, const uint32_t *lcp, const uint32_t *da, const uint8_t *ebwt, uint64_t n,
+                                 uint32_t n_reads, uint32_t n_refs, uint32_t alpha, uint64_t chunk, uint8_t *sim,
+                                 uint64_t *n_clusters, uint64_t *max_len)
+{
+    int rc = check_ctx(c, "lime_fused_stream"); if (rc) return rc;
+    if (!sim || (n && (!lcp || !da))) return fail(LIME_ERR_ARG, "lime_fused_stream: NULL array");
+    if (!n_reads || !n_refs) return fail(LIME_ERR_ARG, "lime_fused_stream: n_reads and n_refs must be > 0");
+    if (!chunk) chunk = STREAM_CHUNK;
+    chunk = (chunk + LIME_TILE - 1) / LIME_TILE * LIME_TILE;
+    const uint64_t cap = (chunk < n ? chunk : n) + STREAM_HALO;         // elements per device buffer
+    Pipe pp;
+    if ((rc = pp.init())) return rc;
+    DevBuf dl[2], dd[2], de[2], ds;
+    const int nbuf = n > chunk ? 2 : 1;
+    for (int b = 0; b < nbuf; ++b) {
+        if ((rc = dl[b].alloc(cap * 4 + 16))) return rc;
+        if ((rc = dd[b].alloc(cap * 4 + 16))) return rc;
+        if (ebwt && (rc = de[b].alloc(cap + 16))) return rc;
+    }
+    if ((rc = ds.alloc(lime_sim_bytes(n_reads, n_refs)))) return rc;
+    if (!n) HIP_TRY(hipMemsetAsync(ds.p, 0, lime_sim_bytes(n_reads, n_refs), pp.comp));
+    uint64_t k = 0;
+    for (uint64_t lo = 0; lo < n; lo += chunk, ++k) {
+        const int b = (int)(k & 1);
+        const uint64_t own = n - lo < chunk ? n - lo : chunk;
+        const uint64_t avail = n - lo < own + STREAM_HALO ? n - lo : own + STREAM_HALO;
+        const int eof = lo + avail == n;
+        if (k >= 2) HIP_TRY(hipStreamWaitEvent(pp.copy, pp.consumed[b], 0));        // the buffer is free again
+        HIP_TRY(hipMemcpyAsync(dl[b].p, lcp + lo, avail * 4, hipMemcpyHostToDevice, pp.copy));
+        HIP_TRY(hipMemcpyAsync(dd[b].p, da + lo, avail * 4, hipMemcpyHostToDevice, pp.copy));
+        if (ebwt) HIP_TRY(hipMemcpyAsync(de[b].p, ebwt + lo, avail, hipMemcpyHostToDevice, pp.copy));
+        HIP_TRY(hipEventRecord(pp.copied[b], pp.copy));
+        HIP_TRY(hipStreamWaitEvent(pp.comp, pp.copied[b], 0));
+        rc = fused_dev_impl(c, (const uint32_t *)dl[b].p, (const uint32_t *)dd[b].p, ebwt ? (const uint8_t *)de[b].p : nullptr,
+                            own, avail, eof, n_reads, n_refs, alpha, (uint8_t *)ds.p, k == 0, k != 0, pp.comp);
+        if (rc) { (void)hipDeviceSynchronize(); return rc; }
+        HIP_TRY(hipEventRecord(pp.consumed[b], pp.comp));
+    }
+    lime_stats_t s;
+    rc = lime_get_stats(c, &s, pp.comp);
+    if (n_clusters) *n_clusters = n ? s.n_clusters : 0;
+    if (max_len) *max_len = n ? s.max_len : 0;
+    if (rc) { (void)hipDeviceSynchronize(); return rc; }
+    HIP_TRY(hipMemcpyAsync(sim, ds.p, (size_t)n_reads * n_refs, hipMemcpyDeviceToHost, pp.comp));
+    HIP_TRY(hipStreamSynchronize(pp.comp));
+    HIP_TRY(hipStreamSynchronize(pp.copy));
     return LIME_OK;
 }
 

@@ -46,6 +46,29 @@ def test_fused_golden(ctx, golden, ebwt_mode):
     assert np.array_equal(sim, golden[f"sim_e{ebwt_mode}"])
 
 
+@pytest.mark.parametrize("ebwt_mode", [1, 0])
+def test_fused_stream_golden(ctx, golden, ebwt_mode):
+    """the chunked host-streaming entry point (one 4096-position chunk at a time) = lime_fused"""
+    eb = golden["ebwt"] if ebwt_mode else None
+    sim, nc, ml = ctx.fused_stream(golden["lcp"], golden["da"], eb, golden["n_reads"], golden["n_refs"],
+                                   golden["alpha"], chunk=4096)
+    assert nc == len(golden["clrs"])
+    assert ml == (int(golden["clrs"][:, 1].max()) if nc else 0)
+    assert np.array_equal(sim, golden[f"sim_e{ebwt_mode}"])
+
+
+@pytest.mark.parametrize("n,chunk", [(1, 4096), (4096, 4096), (4097, 4096), (300001, 8192), (300001, 65536),
+                                     (1000003, 0), (1000003, 262144)])
+def test_fused_stream_synth_vs_oracle(ctx, n, chunk):
+    nr, ng, alpha = 500, 40, 16
+    lcp, da, eb = O.synth(77, 0, n, nr, ng, alpha, 1)
+    clrs, _, ml = O.detect(lcp, da, nr, alpha)
+    exp = O.score(da, eb, clrs, nr, ng, threads=4)
+    sim, nc, gml = ctx.fused_stream(lcp, da, eb, nr, ng, alpha, chunk=chunk)
+    assert nc == len(clrs) and gml == ml
+    assert np.array_equal(sim, exp)
+
+
 def test_score_accepts_any_cluster_order(ctx, golden):
     rng = np.random.default_rng(3)
     cl = golden["clrs"][rng.permutation(len(golden["clrs"]))]
