@@ -389,76 +389,6 @@ struct DevBuf {
 };
 }
 
-extern "C" int lime_detect(lime_ctx *c, const uint32_t *lcp, const uint32_t *da, uint64_t n, uint32_t n_reads,
-                           uint32_t alpha, lime_cluster_t **clusters, uint64_t *n_clusters, uint64_t *max_len)
-{
-    int rc = check_ctx(c, "lime_detect"); if (rc) return rc;
-    if (!clusters || !n_clusters || !max_len) return fail(LIME_ERR_ARG, "lime_detect: NULL output");
-    *clusters = nullptr; *n_clusters = 0; *max_len = 0;
-    if (n && (!lcp || !da)) return fail(LIME_ERR_ARG, "lime_detect: NULL array");
-    if (!n) return LIME_OK;
-    DevBuf dl, dd;
-    if ((rc = dl.upload(lcp, n * 4))) return rc;
-    if ((rc = dd.upload(da, n * 4))) return rc;
-    const lime_cluster_t *dc = nullptr;
-    rc = lime_detect_dev(c, (const uint32_t *)dl.p, (const uint32_t *)dd.p, n, n, 1, 0, n_reads, alpha, &dc,
-                         n_clusters, max_len, nullptr);
-    if (rc) return rc;
-    if (*n_clusters) {
-        lime_cluster_t *h = (lime_cluster_t *)malloc((size_t)*n_clusters * sizeof(lime_cluster_t));
-        if (!h) return fail(LIME_ERR_NOMEM, "lime_detect: out of host memory");
-        hipError_t e = hipMemcpy(h, dc, (size_t)*n_clusters * sizeof(lime_cluster_t), hipMemcpyDeviceToHost);
-        if (e != hipSuccess) { free(h); return fail(LIME_ERR_HIP, "hipMemcpy: %s", hipGetErrorString(e)); }
-        *clusters = h;
-    } else {
-        HIP_TRY(hipDeviceSynchronize());
-    }
-    return LIME_OK;
-}
-
-extern "C" int lime_score(lime_ctx *c, const uint32_t *da, const uint8_t *ebwt, uint64_t n,
-                          const lime_cluster_t *clusters, uint64_t n_clusters, uint32_t n_reads,
-                          uint32_t n_refs, uint8_t *sim)
-{
-    int rc = check_ctx(c, "lime_score"); if (rc) return rc;
-    if (!sim || (n && !da) || (n_clusters && !clusters)) return fail(LIME_ERR_ARG, "lime_score: NULL array");
-    DevBuf dd, de, dc, ds;
-    if ((rc = dd.upload(da, n * 4))) return rc;
-    if (ebwt && (rc = de.upload(ebwt, n))) return rc;
-    if ((rc = dc.upload(clusters, n_clusters * sizeof(lime_cluster_t)))) return rc;
-    if ((rc = ds.alloc(lime_sim_bytes(n_reads, n_refs)))) return rc;
-    rc = lime_score_dev(c, (const uint32_t *)dd.p, ebwt ? (const uint8_t *)de.p : nullptr, n,
-                        (const lime_cluster_t *)dc.p, n_clusters, n_reads, n_refs, (uint8_t *)ds.p, 1, nullptr);
-    if (rc) return rc;
-    lime_stats_t s;
-    if ((rc = lime_get_stats(c, &s, nullptr))) return rc;
-    HIP_TRY(hipMemcpy(sim, ds.p, (size_t)n_reads * n_refs, hipMemcpyDeviceToHost));
-    return LIME_OK;
-}
-
-extern "C" int lime_fused(lime_ctx *c, const uint32_t *lcp, const uint32_t *da, const uint8_t *ebwt, uint64_t n,
-                          uint32_t n_reads, uint32_t n_refs, uint32_t alpha, uint8_t *sim, uint64_t *n_clusters,
-                          uint64_t *max_len)
-{
-    int rc = check_ctx(c, "lime_fused"); if (rc) return rc;
-    if (!sim || (n && (!lcp || !da))) return fail(LIME_ERR_ARG, "lime_fused: NULL array");
-    DevBuf dl, dd, de, ds;
-    if ((rc = dl.upload(lcp, n * 4))) return rc;
-    if ((rc = dd.upload(da, n * 4))) return rc;
-    if (ebwt && (rc = de.upload(ebwt, n))) return rc;
-    if ((rc = ds.alloc(lime_sim_bytes(n_reads, n_refs)))) return rc;
-    rc = lime_fused_dev(c, (const uint32_t *)dl.p, (const uint32_t *)dd.p, ebwt ? (const uint8_t *)de.p : nullptr,
-                        n, n, 1, n_reads, n_refs, alpha, (uint8_t *)ds.p, 1, nullptr);
-    if (rc) return rc;
-    lime_stats_t s;
-    rc = lime_get_stats(c, &s, nullptr);
-    if (n_clusters) *n_clusters = s.n_clusters;
-    if (max_len) *max_len = s.max_len;
-    if (rc) return rc;
-    HIP_TRY(hipMemcpy(sim, ds.p, (size_t)n_reads * n_refs, hipMemcpyDeviceToHost));
-    return LIME_OK;
-}
-
 // ---- streaming from host memory: the collection goes through HBM in position-range chunks ------
 // Chunk k owns positions [k*chunk, (k+1)*chunk) and carries a read-ahead halo, exactly like a shard of
 // the multi-GPU partition (ClusterLCP.cpp:150-161,246-264); two device buffers alternate so that the
@@ -532,6 +462,100 @@ extern "C" int lime_fused_stream(lime_ctx *c, const uint32_t *lcp, const uint32_
     HIP_TRY(hipMemcpyAsync(sim, ds.p, (size_t)n_reads * n_refs, hipMemcpyDeviceToHost, pp.comp));
     HIP_TRY(hipStreamSynchronize(pp.comp));
     HIP_TRY(hipStreamSynchronize(pp.copy));
+    return LIME_OK;
+}
+
+extern "C" int lime_detect(lime_ctx *c, const uint32_t *lcp, const uint32_t *da, uint64_t n, uint32_t n_reads,
+                           uint32_t alpha, lime_cluster_t **clusters, uint64_t *n_clusters, uint64_t *max_len)
+{
+    int rc = check_ctx(c, "lime_detect"); if (rc) return rc;
+    if (!clusters || !n_clusters || !max_len) return fail(LIME_ERR_ARG, "lime_detect: NULL output");
+    *clusters = nullptr; *n_clusters = 0; *max_len = 0;
+    if (n && (!lcp || !da)) return fail(LIME_ERR_ARG, "lime_detect: NULL array");
+    if (!n) return LIME_OK;
+    // position-range chunks with a read-ahead halo (see lime_fused_stream); records of chunk k follow
+    // those of chunk k-1, so the list stays in ascending pStart = the reference's 1-thread order
+    uint64_t chunk = STREAM_CHUNK;
+    if (const char *e = getenv("LIME_DETECT_CHUNK")) { const uint64_t v = strtoull(e, nullptr, 10); if (v) chunk = v; }
+    chunk = (chunk + LIME_TILE - 1) / LIME_TILE * LIME_TILE;
+    const uint64_t cap = (chunk < n ? chunk : n) + STREAM_HALO;
+    DevBuf dl, dd;
+    if ((rc = dl.alloc(cap * 4 + 16))) return rc;
+    if ((rc = dd.alloc(cap * 4 + 16))) return rc;
+    lime_cluster_t *h = nullptr;
+    uint64_t have = 0, room = 0, ml = 0;
+    for (uint64_t lo = 0; lo < n; lo += chunk) {
+        const uint64_t own = n - lo < chunk ? n - lo : chunk;
+        const uint64_t avail = n - lo < own + STREAM_HALO ? n - lo : own + STREAM_HALO;
+        hipError_t e = hipMemcpy(dl.p, lcp + lo, avail * 4, hipMemcpyHostToDevice);
+        if (e == hipSuccess) e = hipMemcpy(dd.p, da + lo, avail * 4, hipMemcpyHostToDevice);
+        if (e != hipSuccess) { free(h); return fail(LIME_ERR_HIP, "hipMemcpy: %s", hipGetErrorString(e)); }
+        const lime_cluster_t *dc = nullptr;
+        uint64_t cnt = 0, m = 0;
+        rc = lime_detect_dev(c, (const uint32_t *)dl.p, (const uint32_t *)dd.p, own, avail, lo + avail == n, lo, n_reads,
+                             alpha, &dc, &cnt, &m, nullptr);
+        if (rc) { free(h); return rc; }
+        if (m > ml) ml = m;
+        if (cnt) {
+            if (have + cnt > room) {
+                room = (have + cnt) + (have + cnt) / 2 + 1024;
+                lime_cluster_t *g = (lime_cluster_t *)realloc(h, (size_t)room * sizeof(lime_cluster_t));
+                if (!g) { free(h); return fail(LIME_ERR_NOMEM, "lime_detect: out of host memory"); }
+                h = g;
+            }
+            e = hipMemcpy(h + have, dc, (size_t)cnt * sizeof(lime_cluster_t), hipMemcpyDeviceToHost);
+            if (e != hipSuccess) { free(h); return fail(LIME_ERR_HIP, "hipMemcpy: %s", hipGetErrorString(e)); }
+            have += cnt;
+        } else {
+            HIP_TRY(hipDeviceSynchronize());
+        }
+    }
+    *clusters = h; *n_clusters = have; *max_len = ml;
+    return LIME_OK;
+}
+
+extern "C" int lime_score(lime_ctx *c, const uint32_t *da, const uint8_t *ebwt, uint64_t n,
+                          const lime_cluster_t *clusters, uint64_t n_clusters, uint32_t n_reads,
+                          uint32_t n_refs, uint8_t *sim)
+{
+    int rc = check_ctx(c, "lime_score"); if (rc) return rc;
+    if (!sim || (n && !da) || (n_clusters && !clusters)) return fail(LIME_ERR_ARG, "lime_score: NULL array");
+    DevBuf dd, de, dc, ds;
+    if ((rc = dd.upload(da, n * 4))) return rc;
+    if (ebwt && (rc = de.upload(ebwt, n))) return rc;
+    if ((rc = dc.upload(clusters, n_clusters * sizeof(lime_cluster_t)))) return rc;
+    if ((rc = ds.alloc(lime_sim_bytes(n_reads, n_refs)))) return rc;
+    rc = lime_score_dev(c, (const uint32_t *)dd.p, ebwt ? (const uint8_t *)de.p : nullptr, n,
+                        (const lime_cluster_t *)dc.p, n_clusters, n_reads, n_refs, (uint8_t *)ds.p, 1, nullptr);
+    if (rc) return rc;
+    lime_stats_t s;
+    if ((rc = lime_get_stats(c, &s, nullptr))) return rc;
+    HIP_TRY(hipMemcpy(sim, ds.p, (size_t)n_reads * n_refs, hipMemcpyDeviceToHost));
+    return LIME_OK;
+}
+
+extern "C" int lime_fused(lime_ctx *c, const uint32_t *lcp, const uint32_t *da, const uint8_t *ebwt, uint64_t n,
+                          uint32_t n_reads, uint32_t n_refs, uint32_t alpha, uint8_t *sim, uint64_t *n_clusters,
+                          uint64_t *max_len)
+{
+    int rc = check_ctx(c, "lime_fused"); if (rc) return rc;
+    if (!sim || (n && (!lcp || !da))) return fail(LIME_ERR_ARG, "lime_fused: NULL array");
+    if (n > 4 * STREAM_CHUNK)                             // large collections: bounded HBM footprint, copy under scan
+        return lime_fused_stream(c, lcp, da, ebwt, n, n_reads, n_refs, alpha, 0, sim, n_clusters, max_len);
+    DevBuf dl, dd, de, ds;
+    if ((rc = dl.upload(lcp, n * 4))) return rc;
+    if ((rc = dd.upload(da, n * 4))) return rc;
+    if (ebwt && (rc = de.upload(ebwt, n))) return rc;
+    if ((rc = ds.alloc(lime_sim_bytes(n_reads, n_refs)))) return rc;
+    rc = lime_fused_dev(c, (const uint32_t *)dl.p, (const uint32_t *)dd.p, ebwt ? (const uint8_t *)de.p : nullptr,
+                        n, n, 1, n_reads, n_refs, alpha, (uint8_t *)ds.p, 1, nullptr);
+    if (rc) return rc;
+    lime_stats_t s;
+    rc = lime_get_stats(c, &s, nullptr);
+    if (n_clusters) *n_clusters = s.n_clusters;
+    if (max_len) *max_len = s.max_len;
+    if (rc) return rc;
+    HIP_TRY(hipMemcpy(sim, ds.p, (size_t)n_reads * n_refs, hipMemcpyDeviceToHost));
     return LIME_OK;
 }
 

@@ -30,6 +30,14 @@ def test_detect_golden(ctx, golden):
     assert O.out_bytes(golden["n_reads"], golden["n_refs"], golden["alpha"], ml, nc) == golden["out"].tobytes()
 
 
+def test_detect_golden_in_chunks(ctx, golden, monkeypatch):
+    """lime_detect walks the arrays in position-range chunks (here 4096 positions): same records, same order"""
+    monkeypatch.setenv("LIME_DETECT_CHUNK", "4096")
+    cl, nc, ml = ctx.detect(golden["lcp"], golden["da"], golden["n_reads"], golden["alpha"])
+    assert nc == len(golden["clrs"]) and np.array_equal(cl, golden["clrs"])
+    assert ml == (int(golden["clrs"][:, 1].max()) if nc else 0)
+
+
 @pytest.mark.parametrize("ebwt_mode", [1, 0])
 def test_score_golden(ctx, golden, ebwt_mode):
     eb = golden["ebwt"] if ebwt_mode else None
