@@ -3,6 +3,7 @@
 // sequencing on the caller's stream, staging for the host-pointer entry points.
 // There is no CPU code path for the computation: every entry point needs a HIP device.
 #include <hip/hip_runtime.h>
+#include <algorithm>
 #include <stdarg.h>
 #include <stdio.h>
 #include <stdlib.h>
@@ -514,22 +515,79 @@ extern "C" int lime_detect(lime_ctx *c, const uint32_t *lcp, const uint32_t *da,
     return LIME_OK;
 }
 
+// clusterAnalyze of a host cluster list into the device table d_sim, the arrays going through HBM
+// in position-range chunks: a chunk takes the clusters that START in it (any input order: an index
+// sorted by pStart is built when needed) and the arrays up to the end of the last of them.
+static int score_in_chunks(lime_ctx *c, const uint32_t *da, const uint8_t *ebwt, uint64_t n,
+                           const lime_cluster_t *clusters, uint64_t n_clusters, uint32_t n_reads, uint32_t n_refs,
+                           uint8_t *d_sim)
+{
+    int rc;
+    HIP_TRY(hipMemset(d_sim, 0, lime_sim_bytes(n_reads, n_refs)));
+    if (!n_clusters) return LIME_OK;
+    uint64_t chunk = STREAM_CHUNK;
+    if (const char *e = getenv("LIME_SCORE_CHUNK")) { const uint64_t v = strtoull(e, nullptr, 10); if (v) chunk = v; }
+    bool sorted = true;
+    for (uint64_t i = 0; i < n_clusters; ++i) {
+        const lime_cluster_t &q = clusters[i];
+        if (q.len > LIME_MAX_CLUSTER) return fail(LIME_ERR_MAXLEN, "a cluster is longer than %u symbols", LIME_MAX_CLUSTER);
+        if (q.pStart > n || q.len > n - q.pStart) return fail(LIME_ERR_ARG, "a cluster record lies outside the arrays");
+        if (i && q.pStart < clusters[i - 1].pStart) sorted = false;
+    }
+    std::vector<lime_cluster_t> order;
+    const lime_cluster_t *cl = clusters;
+    if (!sorted) {
+        order.assign(clusters, clusters + n_clusters);
+        std::sort(order.begin(), order.end(), [](const lime_cluster_t &x, const lime_cluster_t &y) { return x.pStart < y.pStart; });
+        cl = order.data();
+    }
+    std::vector<lime_cluster_t> part;
+    DevBuf dd, de, dc;
+    size_t cap_el = 0, cap_cl = 0;
+    for (uint64_t i = 0; i < n_clusters;) {
+        const uint64_t lo = cl[i].pStart, hi = lo + chunk;
+        uint64_t j = i, end = lo;
+        part.clear();
+        while (j < n_clusters && cl[j].pStart < hi) {
+            lime_cluster_t q = cl[j]; q.pStart -= lo;
+            if (cl[j].pStart + cl[j].len > end) end = cl[j].pStart + cl[j].len;
+            part.push_back(q); ++j;
+        }
+        const uint64_t cnt = end - lo;
+        if (cnt > cap_el) {
+            if (dd.p) { HIP_TRY(hipDeviceSynchronize()); (void)hipFree(dd.p); dd.p = nullptr; if (de.p) { (void)hipFree(de.p); de.p = nullptr; } }
+            cap_el = (size_t)cnt + (size_t)cnt / 8;
+            if ((rc = dd.alloc(cap_el * 4 + 16))) return rc;
+            if (ebwt && (rc = de.alloc(cap_el + 16))) return rc;
+        }
+        if (part.size() > cap_cl) {
+            if (dc.p) { HIP_TRY(hipDeviceSynchronize()); (void)hipFree(dc.p); dc.p = nullptr; }
+            cap_cl = part.size() + part.size() / 8;
+            if ((rc = dc.alloc(cap_cl * sizeof(lime_cluster_t)))) return rc;
+        }
+        HIP_TRY(hipMemcpy(dd.p, da + lo, cnt * 4, hipMemcpyHostToDevice));
+        if (ebwt) HIP_TRY(hipMemcpy(de.p, ebwt + lo, cnt, hipMemcpyHostToDevice));
+        HIP_TRY(hipMemcpy(dc.p, part.data(), part.size() * sizeof(lime_cluster_t), hipMemcpyHostToDevice));
+        rc = lime_score_dev(c, (const uint32_t *)dd.p, ebwt ? (const uint8_t *)de.p : nullptr, cnt,
+                            (const lime_cluster_t *)dc.p, part.size(), n_reads, n_refs, d_sim, 0, nullptr);
+        if (rc) return rc;
+        lime_stats_t st;
+        if ((rc = lime_get_stats(c, &st, nullptr))) return rc;
+        i = j;
+    }
+    return LIME_OK;
+}
+
 extern "C" int lime_score(lime_ctx *c, const uint32_t *da, const uint8_t *ebwt, uint64_t n,
                           const lime_cluster_t *clusters, uint64_t n_clusters, uint32_t n_reads,
                           uint32_t n_refs, uint8_t *sim)
 {
     int rc = check_ctx(c, "lime_score"); if (rc) return rc;
     if (!sim || (n && !da) || (n_clusters && !clusters)) return fail(LIME_ERR_ARG, "lime_score: NULL array");
-    DevBuf dd, de, dc, ds;
-    if ((rc = dd.upload(da, n * 4))) return rc;
-    if (ebwt && (rc = de.upload(ebwt, n))) return rc;
-    if ((rc = dc.upload(clusters, n_clusters * sizeof(lime_cluster_t)))) return rc;
+    if (!n_reads || !n_refs) return fail(LIME_ERR_ARG, "lime_score: n_reads and n_refs must be > 0");
+    DevBuf ds;
     if ((rc = ds.alloc(lime_sim_bytes(n_reads, n_refs)))) return rc;
-    rc = lime_score_dev(c, (const uint32_t *)dd.p, ebwt ? (const uint8_t *)de.p : nullptr, n,
-                        (const lime_cluster_t *)dc.p, n_clusters, n_reads, n_refs, (uint8_t *)ds.p, 1, nullptr);
-    if (rc) return rc;
-    lime_stats_t s;
-    if ((rc = lime_get_stats(c, &s, nullptr))) return rc;
+    if ((rc = score_in_chunks(c, da, ebwt, n, clusters, n_clusters, n_reads, n_refs, (uint8_t *)ds.p))) return rc;
     HIP_TRY(hipMemcpy(sim, ds.p, (size_t)n_reads * n_refs, hipMemcpyDeviceToHost));
     return LIME_OK;
 }
@@ -627,16 +685,10 @@ extern "C" int lime_score_choose(lime_ctx *c, const uint32_t *da, const uint8_t 
 {
     int rc = check_ctx(c, "lime_score_choose"); if (rc) return rc;
     if ((n && !da) || (n_clusters && !clusters)) return fail(LIME_ERR_ARG, "lime_score_choose: NULL array");
-    DevBuf dd, de, dc, ds;
-    if ((rc = dd.upload(da, n * 4))) return rc;
-    if (ebwt && (rc = de.upload(ebwt, n))) return rc;
-    if ((rc = dc.upload(clusters, n_clusters * sizeof(lime_cluster_t)))) return rc;
+    if (!n_reads || !n_refs) return fail(LIME_ERR_ARG, "lime_score_choose: n_reads and n_refs must be > 0");
+    DevBuf ds;
     if ((rc = ds.alloc(lime_sim_bytes(n_reads, n_refs)))) return rc;
-    rc = lime_score_dev(c, (const uint32_t *)dd.p, ebwt ? (const uint8_t *)de.p : nullptr, n,
-                        (const lime_cluster_t *)dc.p, n_clusters, n_reads, n_refs, (uint8_t *)ds.p, 1, nullptr);
-    if (rc) return rc;
-    lime_stats_t s;
-    if ((rc = lime_get_stats(c, &s, nullptr))) return rc;
+    if ((rc = score_in_chunks(c, da, ebwt, n, clusters, n_clusters, n_reads, n_refs, (uint8_t *)ds.p))) return rc;
     if ((rc = lime_choose_pairs_dev(c, (const uint8_t *)ds.p, n_reads, n_refs, norm, beta, row_max, row_off, pairs,
                                     n_pairs, nullptr))) return rc;
     if (sim) HIP_TRY(hipMemcpy(sim, ds.p, (size_t)n_reads * n_refs, hipMemcpyDeviceToHost));

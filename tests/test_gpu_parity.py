@@ -77,6 +77,17 @@ def test_fused_stream_synth_vs_oracle(ctx, n, chunk):
     assert np.array_equal(sim, exp)
 
 
+def test_score_in_chunks(ctx, golden, monkeypatch):
+    """lime_score takes the arrays through HBM in position-range chunks (here 4096 positions), clusters in
+    any order"""
+    monkeypatch.setenv("LIME_SCORE_CHUNK", "4096")
+    rng = np.random.default_rng(5)
+    cl = golden["clrs"][rng.permutation(len(golden["clrs"]))]
+    for mode in (1, 0):
+        sim = ctx.score(golden["da"], golden["ebwt"] if mode else None, cl, golden["n_reads"], golden["n_refs"])
+        assert np.array_equal(sim, golden[f"sim_e{mode}"])
+
+
 def test_score_accepts_any_cluster_order(ctx, golden):
     rng = np.random.default_rng(3)
     cl = golden["clrs"][rng.permutation(len(golden["clrs"]))]
