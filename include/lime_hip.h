@@ -202,6 +202,17 @@ int lime_write_res_bin_pairs(const char *path_bin, const char *path_pos, const u
                              const uint64_t *row_off, const lime_pair_t *pairs, uint32_t n_reads,
                              uint32_t norm, float beta);
 
+/* ---- read assignment from the .res files (the consumer of the path, src/Classify.cpp) ---- *
+ * inputs: n_files (2 single-end, 4 paired-end) .res base names, in the reference's argv order
+ * (Classify.cpp:352-360); binary != 0 reads base.bin + base.pos (BIN=1, the Makefile default), else
+ * base.txt; rank 0..6 as the reference's taxRank; higher != 0 = the HIGHER=1 build.  Writes the
+ * reference's classification file; counts = {classified, not classified, ambiguous, higher rank}.
+ * Pure host code.  Error text: lime_classify_error(). */
+int lime_classify(uint32_t n_files, const char *const *inputs, int binary, uint32_t n_reads,
+                  uint32_t n_targ, const char *path_out, const char *path_tax, int rank, int higher,
+                  uint64_t counts[4]);
+const char *lime_classify_error(void);
+
 #ifdef __cplusplus
 }
 #endif

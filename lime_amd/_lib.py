@@ -63,6 +63,8 @@ SYMBOLS = {
     "lime_read_aux": (_i, [C.c_char_p, C.POINTER(_u32), C.POINTER(_u32), C.POINTER(_u32), _pu64, _pu64]),
     "lime_write_res_txt": (_i, [C.c_char_p, _vp, _vp, _u32, _u32, _u32, C.c_float]),
     "lime_write_res_bin": (_i, [C.c_char_p, C.c_char_p, _vp, _vp, _u32, _u32, _u32, C.c_float]),
+    "lime_classify": (_i, [_u32, _vp, _i, _u32, _u32, C.c_char_p, C.c_char_p, _i, _i, _vp]),
+    "lime_classify_error": (C.c_char_p, []),
     "lime_fused_stream": (_i, [_vp, _vp, _vp, _vp, _u64, _u32, _u32, _u32, _u64, _vp, _pu64, _pu64]),
     "lime_choose_pairs_dev": (_i, [_vp, _vp, _u32, _u32, _u32, C.c_float, _vp, _vp, _pp, _pu64, _vp]),
     "lime_score_choose": (_i, [_vp, _vp, _vp, _u64, _vp, _u64, _u32, _u32, _u32, C.c_float, _vp, _vp, _pp, _pu64, _vp]),
