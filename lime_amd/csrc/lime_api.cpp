@@ -236,6 +236,8 @@ static int fused_dev_impl(lime_ctx *c, const uint32_t *d_lcp, const uint32_t *d_
     if (misaligned(d_lcp, 16) || misaligned(d_da, 16) || misaligned(d_ebwt, 8) || misaligned(d_sim, 4))
         return fail(LIME_ERR_ARG, "lime_fused_dev: device arrays must be 16-byte aligned (ebwt: 8, sim: 4)");
     if (!n_reads || !n_refs) return fail(LIME_ERR_ARG, "lime_fused_dev: n_reads and n_refs must be > 0");
+    if (n_refs >= (1u << 27) || (uint64_t)n_reads + n_refs > 0xFFFFFFF0ull)
+        return fail(LIME_ERR_ARG, "lime_fused_dev: n_refs must be < 2^27 and n_reads + n_refs <= 2^32 - 16");
     if ((rc = ensure_scratch(c, n_avail, false, true, st))) return rc;
     if (keep_stats) {
         HIP_TRY(hipMemsetAsync(&c->d_stats->n_cross, 0, 2 * sizeof(uint32_t), st));      // n_cross, n_big
@@ -331,6 +333,8 @@ extern "C" int lime_score_dev(lime_ctx *c, const uint32_t *d_da, const uint8_t *
     if (!d_sim || (n && !d_da) || (n_clusters && !d_clusters)) return fail(LIME_ERR_ARG, "lime_score_dev: NULL array");
     if (misaligned(d_sim, 4)) return fail(LIME_ERR_ARG, "lime_score_dev: d_sim must be 4-byte aligned");
     if (!n_reads || !n_refs) return fail(LIME_ERR_ARG, "lime_score_dev: n_reads and n_refs must be > 0");
+    if (n_refs >= (1u << 27) || (uint64_t)n_reads + n_refs > 0xFFFFFFF0ull)
+        return fail(LIME_ERR_ARG, "lime_score_dev: n_refs must be < 2^27 and n_reads + n_refs <= 2^32 - 16");
     if ((rc = ensure_scratch(c, n, false, true, st))) return rc;
     // every listed cluster longer than the in-tile limit lands in the big list
     if (n_clusters + 16 > c->big_cap) {

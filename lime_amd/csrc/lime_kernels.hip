@@ -83,12 +83,13 @@ struct alignas(16) ScanLds {
     alignas(8) uint8_t hb[WPOS / 8 + 8];
     alignas(8) uint8_t rb[WPOS / 8 + 8];
     uint16_t listM[WIN / 5 + 4];
+    uint32_t listX[64];               // this window's clusters of SMALL_MAX+1 .. MID_MAX symbols (start | len << 16)
     uint16_t m_tstart[64];            // < 64 clusters x 120 pairs
     uint8_t m_flag[64], m_dup[64];
     alignas(8) uint64_t asw[NW];
     uint32_t prew[NW];
     uint32_t q_read[QCAP_SCAN], q_gen[QCAP_SCAN];
-    uint32_t f_read[256], f_gen[256];   // entries whose compare-and-swap is in flight
+    uint32_t f_read[256], f_gen[256], f_exp[256];   // entries whose compare-and-swap is in flight, and the word each expects
     uint32_t g_doc[DUP_SLOTS][SMALL_MAX];   // clusters with a repeated document waiting for dup_flush
     uint8_t g_sym[DUP_SLOTS][SMALL_MAX], g_len[DUP_SLOTS];
 };
@@ -123,6 +124,25 @@ __device__ __forceinline__ uint32_t wave_max(uint32_t v)
     return v;
 }
 
+// position of the j-th (0-based) set bit of x (j < popcount(x)): binary search over popcounts of
+// halves, branch-free (a "clear the lowest bit j times" loop would run as long as the slowest lane)
+__device__ __forceinline__ uint32_t select_bit(uint64_t x, uint32_t j)
+{
+    uint32_t v = (uint32_t)x, pos = 0;
+    uint32_t c = (uint32_t)__popc(v);
+    if (j >= c) { j -= c; v = (uint32_t)(x >> 32); pos = 32u; }
+#pragma unroll
+    for (uint32_t half = 16u; half >= 1u; half >>= 1) {
+        const uint32_t lowm = (1u << half) - 1u;
+        c = (uint32_t)__popc(v & lowm);
+        const bool up = j >= c;
+        j -= up ? c : 0u;
+        v = up ? (v >> half) : (v & lowm);
+        pos += up ? half : 0u;
+    }
+    return pos;
+}
+
 // inclusive prefix sum over the 64 lanes with DPP row shifts / row broadcasts (no LDS)
 __device__ __forceinline__ uint32_t wave_incl_scan(uint32_t v)
 {
@@ -137,7 +157,10 @@ __device__ __forceinline__ uint32_t wave_incl_scan(uint32_t v)
 
 // byte -> symbol index, and symbol index -> set of symbol indices it scores 1 against
 // (iupac_match); filled once per workgroup
-struct WgTables { uint8_t symidx[256]; uint16_t compat[16]; };
+// pairlut[rmask | (len-1) << 4] for a cluster of len = 2..4 symbols with read bits rmask: bit k = position
+// pair k of (0,1)(0,2)(0,3)(1,2)(1,3)(2,3) joins a read with a genome inside the cluster, bit 8+k =
+// the pair's FIRST position is the read
+struct WgTables { uint8_t symidx[256]; uint16_t compat[16]; uint16_t pairlut[64]; };
 
 __device__ __forceinline__ void tables_init(WgTables &T)
 {
@@ -147,6 +170,17 @@ __device__ __forceinline__ void tables_init(WgTables &T)
         uint32_t m = 0;
         for (uint32_t b = 0; b < 16u; ++b) m |= iupac_match(t, b) << b;
         T.compat[t] = (uint16_t)m;
+    }
+    for (uint32_t e = t; e < 64u; e += blockDim.x) {
+        const uint32_t len = (e >> 4) + 1u, vm = (1u << len) - 1u, r = e & 15u & vm, g = ~r & vm;
+        uint32_t v = 0, k = 0;
+        for (uint32_t i = 0; i < 4u; ++i)
+            for (uint32_t j = i + 1u; j < 4u; ++j, ++k) {
+                const uint32_t ri = (r >> i) & 1u, rj = (r >> j) & 1u, gi = (g >> i) & 1u, gj = (g >> j) & 1u;
+                v |= ((ri & gj) | (gi & rj)) << k;
+                v |= ri << (8u + k);
+            }
+        T.pairlut[e] = (uint16_t)v;
     }
     __syncthreads();
 }
@@ -176,8 +210,8 @@ struct UpdQueue { uint32_t *qr, *qg; uint32_t n, cap;
     // Lane l owns in-flight slots 64 j + l (j < 4): entry kept in fr/fg, value the CAS expected
     // and value it returned in registers.
     bool async = false;
-    uint32_t *fr = nullptr, *fg = nullptr;
-    uint32_t f_old[4], f_exp[4], f_pend = 0;
+    uint32_t *fr = nullptr, *fg = nullptr, *fe = nullptr;   // entry (read, genome | t) and the word value its CAS expected
+    uint32_t f_old[4], f_pend = 0;
 #ifdef LIME_PHASE_TIMING
     uint64_t t_drain = 0; uint32_t n_drain = 0;
 #endif
@@ -194,8 +228,8 @@ __device__ __forceinline__ void drain_async(UpdQueue &q, const ScanArgs &a)
 #pragma unroll
     for (int j = 0; j < 4; ++j)
         if ((q.f_pend >> j) & 1u) {
-            if (q.f_old[j] == q.f_exp[j]) q.f_pend &= ~(1u << j);
-            else q.f_exp[j] = q.f_old[j];
+            if (q.f_old[j] == q.fe[64u * (uint32_t)j + lane]) q.f_pend &= ~(1u << j);
+            else q.fe[64u * (uint32_t)j + lane] = q.f_old[j];
         }
     uint32_t n = q.n;
 #pragma unroll
@@ -206,7 +240,7 @@ __device__ __forceinline__ void drain_async(UpdQueue &q, const ScanArgs &a)
         if (fre && r < n) {
             const uint32_t k = n - 1u - r;
             q.fr[64u * (uint32_t)j + lane] = q.qr[k]; q.fg[64u * (uint32_t)j + lane] = q.qg[k];
-            q.f_exp[j] = 0u; q.f_pend |= 1u << j;
+            q.fe[64u * (uint32_t)j + lane] = 0u; q.f_pend |= 1u << j;
         }
         n -= c < n ? c : n;
     }
@@ -217,7 +251,7 @@ __device__ __forceinline__ void drain_async(UpdQueue &q, const ScanArgs &a)
         if ((q.f_pend >> j) & 1u) {
             const uint32_t gt = q.fg[64u * (uint32_t)j + lane];
             const uint64_t cell = (uint64_t)q.fr[64u * (uint32_t)j + lane] * a.n_refs + (gt & ((1u << T_SHIFT) - 1u));
-            const uint32_t sh = (uint32_t)(cell & 3ull) * 8u, e = q.f_exp[j];
+            const uint32_t sh = (uint32_t)(cell & 3ull) * 8u, e = q.fe[64u * (uint32_t)j + lane];
             const uint32_t b = ((e >> sh) + (gt >> T_SHIFT)) & 255u;
             q.f_old[j] = atomicCAS(reinterpret_cast<uint32_t *>(a.sim + (cell & ~3ull)), e, (e & ~(255u << sh)) | (b << sh));
         }
@@ -546,6 +580,7 @@ __device__ __forceinline__ uint32_t score_small(LDS &L, const WgTables &T, UpdQu
     const uint32_t kb = p >> 3, sh = p & 7u;
     const uint32_t rbits = (uint32_t)L.rb[kb] | ((uint32_t)L.rb[kb + 1u] << 8);
     const uint32_t rmask = (rbits >> sh) & ((1u << len) - 1u);
+    const uint32_t pl = T.pairlut[rmask | (((len - 1u) & 3u) << 4)];
     uint32_t d[4], sy[4], cs[4];
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
@@ -553,42 +588,42 @@ __device__ __forceinline__ uint32_t score_small(LDS &L, const WgTables &T, UpdQu
         sy[i] = EBWT ? T.symidx[L.fl[p + i]] : 0u;
         cs[i] = EBWT ? T.compat[sy[i]] : 0xFFFFu;
     }
-    uint32_t dup = 0;
+    // positions past the cluster get values no document has (the API bounds n_reads + n_refs), so that
+    // the six equality tests need no length checks
+    d[2] = len > 2u ? d[2] : 0xFFFFFFFEu;
+    d[3] = len > 3u ? d[3] : 0xFFFFFFFFu;
+    const bool dup = on && ((d[0] == d[1]) | (d[0] == d[2]) | (d[0] == d[3]) | (d[1] == d[2]) | (d[1] == d[3]) | (d[2] == d[3]));
+    dup_push<EBWT>(L, n_dup, a, ms, dup, lo, p, len);
+    uint32_t compat6 = 0;
+    {
+        int pi = 0;
 #pragma unroll
-    for (int i = 0; i < 4; ++i)
+        for (int i = 0; i < 4; ++i)
 #pragma unroll
-        for (int j = i + 1; j < 4; ++j) dup |= (uint32_t)(d[i] == d[j]) & (uint32_t)((uint32_t)j < len);
-    dup_push<EBWT>(L, n_dup, a, ms, dup != 0u, lo, p, len);
-    uint32_t hits = 0, bad = 0;
-    int pi = 0;
-#pragma unroll
-    for (int i = 0; i < 4; ++i)
-#pragma unroll
-        for (int j = i + 1; j < 4; ++j, ++pi) {
-            const uint32_t ri = (rmask >> i) & 1u, rj = (rmask >> j) & 1u;
-            const uint32_t g = (ri ? d[j] : d[i]) - a.n_reads;
-            uint32_t ok = (uint32_t)((uint32_t)j < len) & (ri ^ rj) & ((cs[i] >> sy[j]) & 1u) & (uint32_t)!dup;
-            bad |= ok & (uint32_t)(g >= a.n_refs);
-            ok &= (uint32_t)(g < a.n_refs);
-            hits |= ok << pi;
-        }
-    if (__ballot(bad != 0u)) { if (bad) atomicOr(&a.stats->flags, LIME_FLAG_DOCID); }
+            for (int j = i + 1; j < 4; ++j, ++pi) compat6 |= ((cs[i] >> sy[j]) & 1u) << pi;
+    }
+    const uint32_t hits = (dup || !on) ? 0u : (pl & compat6 & 0x3Fu), rsel = pl >> 8;
     const uint32_t nh = (uint32_t)__popc(hits);
     const uint32_t incl = wave_incl_scan(nh), total = rl32(incl, 63);
     while (qu.n + total > qu.cap) drain(qu, a);              // total <= 4 per lane = 256 <= cap
-    uint32_t slot = qu.n + incl - nh;
-    pi = 0;
+    uint32_t slot = qu.n + incl - nh, bad = 0;
+    {
+        int pi = 0;
 #pragma unroll
-    for (int i = 0; i < 4; ++i)
+        for (int i = 0; i < 4; ++i)
 #pragma unroll
-        for (int j = i + 1; j < 4; ++j, ++pi) {
-            if ((hits >> pi) & 1u) {
-                const bool ri = (rmask >> i) & 1u;
-                qu.qr[slot] = ri ? d[i] : d[j];
-                qu.qg[slot] = ((ri ? d[j] : d[i]) - a.n_reads) | (1u << T_SHIFT);
-                ++slot;
+            for (int j = i + 1; j < 4; ++j, ++pi) {
+                if ((hits >> pi) & 1u) {
+                    const bool ri = (rsel >> pi) & 1u;
+                    uint32_t gd = (ri ? d[j] : d[i]) - a.n_reads;
+                    if (gd >= a.n_refs) { bad = 1u; gd = 0u; }      // reported below; the result is void anyway
+                    qu.qr[slot] = ri ? d[i] : d[j];
+                    qu.qg[slot] = gd | (1u << T_SHIFT);
+                    ++slot;
+                }
             }
-        }
+    }
+    if (__ballot(bad != 0u)) { if (bad) atomicOr(&a.stats->flags, LIME_FLAG_DOCID); }
     qu.n += total;
     return nh;
 }
@@ -810,14 +845,14 @@ __global__ __launch_bounds__(SCANK_WG) __attribute__((amdgpu_waves_per_eu(LIME_S
 {
     __shared__ ScanLds lds[SCANK_WG / 64];
     __shared__ WgTables T;
-    const uint32_t lane = lane_id(), wave = threadIdx.x >> 6;
+    const uint32_t lane = lane_id(), wave = (uint32_t)__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));   // wave-uniform: LDS bases stay scalar
     ScanLds &L = lds[wave];
     tables_init(T);                                        // the only workgroup barrier of the kernel
     const uint32_t n_win = a.n_tiles, stride = gridDim.x * (SCANK_WG / 64);
     uint32_t win = blockIdx.x * (SCANK_WG / 64) + wave;
     if (win >= n_win) return;
     UpdQueue qu; qu.qr = L.q_read; qu.qg = L.q_gen; qu.n = 0; qu.cap = QCAP_SCAN;
-    qu.async = true; qu.fr = L.f_read; qu.fg = L.f_gen;
+    qu.async = true; qu.fr = L.f_read; qu.fg = L.f_gen; qu.fe = L.f_exp;
     MedState ms = {{0u, 0u}, {0u, 0u}, {0u, 0u}};          // no chunk reserved yet
     WinRegs regs;
     window_load<EBWT>(regs, a, (uint64_t)win * WIN);
@@ -918,7 +953,7 @@ __global__ __launch_bounds__(SCANK_WG) __attribute__((amdgpu_waves_per_eu(LIME_S
 #pragma unroll
             for (int k = 1; k < (int)NW; ++k) pk[k] = rl32(pre, k);
             if (lane < NW) { L.asw[lane] = c.ah; L.prew[lane] = pre; }         // looked up by word below
-            uint32_t nM = 0;
+            uint32_t nM = 0, nX = 0;
             PT(3)
             for (uint32_t base = 0; base < total; base += 64u) {
                 const uint32_t t = base + lane;
@@ -928,8 +963,7 @@ __global__ __launch_bounds__(SCANK_WG) __attribute__((amdgpu_waves_per_eu(LIME_S
                 for (int k = 1; k < (int)NW; ++k) w += (uint32_t)(t >= pk[k]);
                 uint64_t x = L.asw[w];
                 uint32_t j = on ? t - L.prew[w] : 0u;
-                while (__ballot(j != 0u)) { if (j) { x &= x - 1ull; --j; } }
-                const uint32_t p = on ? 64u * w + (uint32_t)__builtin_ctzll(x | (1ull << 63)) : 0u;
+                const uint32_t p = on ? 64u * w + select_bit(x, j) : 0u;
                 // cluster length: distance to the next head, from the staged head bytes
                 const uint32_t kb = p >> 3, sh = p & 7u;
                 const uint32_t hbits = (uint32_t)L.hb[kb] | ((uint32_t)L.hb[kb + 1u] << 8) | ((uint32_t)L.hb[kb + 2u] << 16);
@@ -949,16 +983,11 @@ __global__ __launch_bounds__(SCANK_WG) __attribute__((amdgpu_waves_per_eu(LIME_S
                             if (k < a.big_cap) { a.big[k].pStart = lo + p; a.big[k].len = len; }
                         }
                     }
-                    // SMALL_MAX+1 .. MID_MAX symbols: scored at once, the whole wave one lane group on the
-                    // staged window (such a cluster closes inside the window + read-ahead)
-                    uint64_t mm = __ballot(len > SMALL_MAX && len <= MID_MAX);
-                    while (mm) {
-                        const uint32_t l0 = (uint32_t)__builtin_ctzll(mm);
-                        mm &= mm - 1ull;
-                        const uint32_t p0 = rl32(p, l0), len0 = rl32(len, l0);
-                        const bool hv = lane < len0;
-                        acc_upd += group_score<EBWT, 64>(a, T, qu, hv ? L.da[p0 + lane] : 0u, (EBWT && hv) ? L.fl[p0 + lane] : 0u, len0);
-                    }
+                    // SMALL_MAX+1 .. MID_MAX symbols: noted, scored after the hand-out (at most 61 per window)
+                    const bool cX = len > SMALL_MAX && len <= MID_MAX;
+                    const uint64_t mX = __ballot(cX);
+                    if (cX) L.listX[nX + (uint32_t)__popcll(mX & lt)] = p | (len << 16);
+                    nX += (uint32_t)__popcll(mX);
                 }
                 acc_max = len > acc_max ? len : acc_max;
                 const bool cM = on && len > 4u && len <= SMALL_MAX;
@@ -978,6 +1007,14 @@ __global__ __launch_bounds__(SCANK_WG) __attribute__((amdgpu_waves_per_eu(LIME_S
 #else
                 acc_upd += score_medium<EBWT>(L, T, qu, ms, n_dup, a, lo, nM);
 #endif
+            }
+            // 17..64 symbols: the whole wave is one lane group on the staged window (such a cluster
+            // closes inside the window + read-ahead)
+#pragma unroll 1
+            for (uint32_t k = 0; k < nX; ++k) {
+                const uint32_t it = L.listX[k], p0 = it & 0xFFFFu, len0 = it >> 16;
+                const bool hv = lane < len0;
+                acc_upd += group_score<EBWT, 64>(a, T, qu, hv ? L.da[p0 + lane] : 0u, (EBWT && hv) ? L.fl[p0 + lane] : 0u, len0);
             }
             if (n_dup >= DUP_SLOTS / 2u) acc_upd += dup_flush<EBWT>(L, n_dup, a, T, qu);
             PT(6)
@@ -1125,7 +1162,7 @@ __global__ __launch_bounds__(SCAN_WG) void k_score_list(ScanArgs a, const lime_c
 {
     __shared__ WaveLds<64 * SMALL_MAX> lds[SCAN_WG / 64];
     __shared__ uint32_t c_off[SCAN_WG / 64][65];
-    const uint32_t lane = lane_id(), wave = threadIdx.x >> 6;
+    const uint32_t lane = lane_id(), wave = (uint32_t)__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));   // wave-uniform: LDS bases stay scalar
     WaveLds<64 * SMALL_MAX> &L = lds[wave];
     uint32_t *off = c_off[wave];
     const uint64_t n_batches = (n_list + 63u) / 64u, stride = (uint64_t)gridDim.x * (SCAN_WG / 64);
@@ -1224,7 +1261,7 @@ __global__ __launch_bounds__(SCAN_WG) void k_score_med(ScanArgs a)
 {
     __shared__ WgTables T;
     __shared__ uint32_t s_qr[SCAN_WG / 64][QCAP], s_qg[SCAN_WG / 64][QCAP];
-    const uint32_t lane = lane_id(), wave = threadIdx.x >> 6;
+    const uint32_t lane = lane_id(), wave = (uint32_t)__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));   // wave-uniform: LDS bases stay scalar
     tables_init(T);
     UpdQueue qu; qu.qr = s_qr[wave]; qu.qg = s_qg[wave]; qu.n = 0; qu.cap = QCAP;
     const uint32_t n1 = a.stats->n_med[1] < a.med_cap ? a.stats->n_med[1] : a.med_cap;
