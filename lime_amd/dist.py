@@ -4,7 +4,7 @@ The reference partitions positions [0,N) over OpenMP threads (src/ClusterLCP.cpp
 thread skips to the first cluster head in its chunk (:196-202) and reads past its end until
 the open run closes (:246-264).  Here a rank owns a tile-aligned range [lo,hi) and holds a
 read-ahead halo [hi,hi_halo); a cluster belongs to the rank that owns its first position.
-Per-rank outputs: a private uint8 table (combined by ONE all-reduce, sum modulo 256), the
+Per-rank outputs: a private uint8 table (combined by ONE all-reduce or reduce-scatter, sum modulo 256), the
 cluster count (sum) and the maximum length (max).  No other data-path collective.
 """
 from __future__ import annotations
@@ -35,6 +35,25 @@ def allreduce_tables(sim_t, group=None):
     return sim_t
 
 
+def table_block_bytes(sim_bytes, world):
+    """bytes of one rank's block when the table is cut into `world` equal, 16-byte aligned blocks
+    (the buffer handed to reduce_scatter_tables must hold world * this many bytes, zero padded)"""
+    return (sim_bytes + 16 * world - 1) // (16 * world) * 16
+
+
+def reduce_scatter_tables(sim_t, out_t, group=None, async_op=False):
+    """Sum the per-rank uint8 tables modulo 256 and leave rank r with block r of the result (the
+    form SURVEY 8e prefers: clusterChoose is row-independent, so each rank goes on with its block and
+    only half the bytes of an all-reduce cross xGMI).  len(sim_t) == world * len(out_t).
+    Returns the async work handle (RCCL) or None."""
+    import torch.distributed as dist
+    if dist.get_backend(group) == "gloo":                 # CPU tests: gloo has no reduce-scatter
+        dist.all_reduce(sim_t, op=dist.ReduceOp.SUM, group=group)
+        out_t.copy_(sim_t.view(dist.get_world_size(group), -1)[dist.get_rank(group)])
+        return None
+    return dist.reduce_scatter_tensor(out_t, sim_t, op=dist.ReduceOp.SUM, group=group, async_op=async_op)
+
+
 def combine_counters(n_clusters, max_len, device, group=None):
     """(sum of cluster counts, max of maximum lengths) over ranks."""
     import torch
@@ -56,3 +75,8 @@ def check_uint8_sum_wraps(device, group=None):
     want = (200 * w) % 256
     if not bool((t == want).all()):
         raise RuntimeError(f"uint8 all-reduce does not wrap modulo 256: got {int(t[0])}, want {want}")
+    src = torch.full((64 * w,), 200, dtype=torch.uint8, device=device)
+    blk = torch.empty(64, dtype=torch.uint8, device=device)
+    reduce_scatter_tables(src, blk, group)
+    if not bool((blk == want).all()):
+        raise RuntimeError(f"uint8 reduce-scatter does not wrap modulo 256: got {int(blk[0])}, want {want}")

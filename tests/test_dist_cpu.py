@@ -15,7 +15,8 @@ import torch.multiprocessing as mp
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 
-from lime_amd.dist import DEFAULT_HALO, allreduce_tables, check_uint8_sum_wraps, combine_counters, shard_ranges  # noqa: E402
+from lime_amd.dist import (DEFAULT_HALO, allreduce_tables, check_uint8_sum_wraps, combine_counters,  # noqa: E402
+                           reduce_scatter_tables, shard_ranges, table_block_bytes)
 from lime_amd._lib import TILE  # noqa: E402
 
 
@@ -52,7 +53,16 @@ def _worker(rank, world, port, n, nr, ng, out):
         assert (mine[:, 0] + mine[:, 1] <= hh).all(), "an owned cluster leaves the halo"
         sim = torch.from_numpy(O.score(da, eb, mine, nr, ng))
         sim += 250                                      # force wrap-around in the reduction
+        # the reduce-scatter form first (bench.py): rank r ends up with block r of the summed table
+        blk = table_block_bytes(sim.numel(), world)
+        padded = torch.zeros(blk * world, dtype=torch.uint8)
+        padded[:sim.numel()] = sim.reshape(-1)
+        mine_blk = torch.empty(blk, dtype=torch.uint8)
+        reduce_scatter_tables(padded.clone(), mine_blk)
         allreduce_tables(sim)
+        whole = torch.zeros(blk * world, dtype=torch.uint8)
+        whole[:sim.numel()] = sim.reshape(-1)
+        assert torch.equal(mine_blk, whole[rank * blk:(rank + 1) * blk]), "reduce-scatter block differs"
         nc, ml = combine_counters(len(mine), int(mine[:, 1].max()) if len(mine) else 0, "cpu")
         if rank == 0:
             exp = O.score(da, eb, cl, nr, ng)
