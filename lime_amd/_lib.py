@@ -99,3 +99,10 @@ def load():
 def check(rc):
     if rc != LIME_OK:
         raise LimeError(rc, load().lime_last_error().decode(errors="replace"))
+
+
+def hip_memcpy_d2d(dst, src, nbytes):
+    """device-to-device copy through the HIP runtime torch already loaded (tests: library-owned lists)"""
+    hip = C.CDLL("libamdhip64.so", mode=C.RTLD_GLOBAL)
+    hip.hipMemcpy.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_int]
+    return hip.hipMemcpy(dst, src, nbytes, 3)          # hipMemcpyDeviceToDevice

@@ -146,6 +146,19 @@ class Context:
         check(self.lib.lime_fused_dev(self.h, _ptr(lcp_t), _ptr(da_t), _ptr(ebwt_t), n_own, n_avail, int(eof),
                                       n_reads, n_refs, alpha, _ptr(sim_t), int(zero_sim), stream))
 
+    def detect_dev(self, lcp_t, da_t, n_own, n_avail, eof, pos_base, n_reads, alpha, stream=None):
+        """-> (device pointer of the library-owned record list, n_clusters, max_len); the list stays valid
+        until the next detect_dev on this context."""
+        dc, nc, ml = C.c_void_p(), C.c_uint64(0), C.c_uint64(0)
+        check(self.lib.lime_detect_dev(self.h, _ptr(lcp_t), _ptr(da_t), n_own, n_avail, int(eof), pos_base, n_reads,
+                                       alpha, C.byref(dc), C.byref(nc), C.byref(ml), stream))
+        return dc.value, int(nc.value), int(ml.value)
+
+    def score_dev(self, da_t, ebwt_t, n, clusters_ptr, n_clusters, n_reads, n_refs, sim_t, zero_sim=True, stream=None):
+        """clusters_ptr: device address of n_clusters lime_cluster_t records (e.g. from detect_dev)"""
+        check(self.lib.lime_score_dev(self.h, _ptr(da_t), _ptr(ebwt_t), n, C.c_void_p(clusters_ptr), n_clusters, n_reads,
+                                      n_refs, _ptr(sim_t), int(zero_sim), stream))
+
     def choose_dev(self, sim_t, n_reads, n_refs, max_t, nnz_t, stream=None):
         check(self.lib.lime_choose_dev(self.h, _ptr(sim_t), n_reads, n_refs, _ptr(max_t), _ptr(nnz_t), stream))
 

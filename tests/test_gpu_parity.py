@@ -354,6 +354,58 @@ def test_position_range_shards_sum_to_whole(ctx, n_shards):
     assert np.array_equal(total, exp)
 
 
+@pytest.mark.parametrize("shape", ["C2", "C3"])
+def test_full_size_paths_agree(ctx, shape):
+    """BASELINE.json's full sizes (configs[1]: 10^8 symbols, 10^5 x 500, EBWT=1; configs[2]: 10^9 symbols,
+    10^6 x 5000, EBWT=0), inputs generated on the device.  Too big for the oracle, so size-independent
+    properties: (1) the table of one fused pass == the table accumulated over 3 position-range shards with
+    halos (ownership + mod-256 addition); (2) == the table of the two-program flow, detection then scoring of
+    the emitted cluster list (independent kernels); (3) the cluster list is sorted, its length and longest
+    record equal the fused counters; (4) the row maxima of k_choose == a plain reduction of the table."""
+    import ctypes as C
+    import torch
+    import lime_amd
+    from lime_amd.dist import shard_ranges
+    n, nr, ng, ebwt_on = (100_000_000, 100_000, 500, True) if shape == "C2" else (1_000_000_000, 1_000_000, 5000, False)
+    alpha, dev = 16, torch.device("cuda:0")
+    lcp = torch.empty(n, dtype=torch.int32, device=dev); da = torch.empty_like(lcp)
+    eb = torch.empty(n, dtype=torch.uint8, device=dev) if ebwt_on else None
+    ctx.synth_dev(42, 0, n, nr, ng, alpha, 0, lcp, da, eb)
+    tb = lime_amd.sim_bytes(nr, ng)
+    A = torch.empty(tb, dtype=torch.uint8, device=dev)
+    ctx.fused_dev(lcp, da, eb, n, n, True, nr, ng, alpha, A, True)
+    sA, rc = ctx.stats(); assert rc == 0
+    assert sA.n_clusters > n // 30 and sA.n_updates > 0
+    # (1) three shards into one table
+    B = torch.empty(tb, dtype=torch.uint8, device=dev)
+    tot_c, tot_m, tot_u = 0, 0, 0
+    for k, (lo, hi, hh) in enumerate(shard_ranges(n, 3)):
+        ctx.fused_dev(lcp[lo:], da[lo:], None if eb is None else eb[lo:], hi - lo, hh - lo, hh == n, nr, ng, alpha, B, k == 0)
+        s, rc = ctx.stats(); assert rc == 0
+        tot_c += s.n_clusters; tot_m = max(tot_m, s.max_len); tot_u += s.n_updates
+    assert (tot_c, tot_m, tot_u) == (sA.n_clusters, sA.max_len, sA.n_updates)
+    assert torch.equal(A, B)
+    del B
+    # (2),(3) detection, then scoring of the list
+    ptr, nc, ml = ctx.detect_dev(lcp, da, n, n, True, 0, nr, alpha)
+    assert (nc, ml) == (sA.n_clusters, sA.max_len)
+    rec = torch.empty((nc, 2), dtype=torch.int64, device=dev)
+    assert lime_amd._lib.hip_memcpy_d2d(rec.data_ptr(), ptr, nc * 16) == 0
+    assert bool((rec[1:, 0] > rec[:-1, 0]).all()) and int(rec[:, 1].min()) >= 2 and int(rec[:, 1].max()) == ml
+    assert bool((rec[:-1, 0] + rec[:-1, 1] <= rec[1:, 0]).all())          # clusters do not overlap
+    Cc = torch.empty(tb, dtype=torch.uint8, device=dev)
+    ctx.score_dev(da, eb, n, rec.data_ptr(), nc, nr, ng, Cc, True)
+    s, rc = ctx.stats(); assert rc == 0 and s.n_updates == sA.n_updates
+    assert torch.equal(A, Cc)
+    del Cc, rec
+    # (4) row scan
+    mx = torch.empty(nr, dtype=torch.uint8, device=dev); nz = torch.empty(nr, dtype=torch.int32, device=dev)
+    ctx.choose_dev(A, nr, ng, mx, nz)
+    t2 = A[:nr * ng].view(nr, ng)
+    assert torch.equal(mx, t2.amax(dim=1))
+    assert int(nz.sum()) == int(torch.count_nonzero(t2))
+
+
 def lime_sim_bytes(nr, ng):
     import lime_amd
     return lime_amd.sim_bytes(nr, ng)
