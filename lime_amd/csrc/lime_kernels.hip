@@ -795,6 +795,14 @@ __device__ __forceinline__ WinCtx window_context(uint64_t h, uint64_t r, uint64_
 struct WinRegs { uint32_t lv[PPL], dv[PPL], bv[PPL / 4], hl, hd, hb; };
 typedef uint32_t __attribute__((may_alias, aligned(1))) u32u;    // ebwt words: any byte alignment
 
+// the three input arrays are read once: non-temporal loads keep them from displacing the score table
+// (the target of the compare-and-swaps) in the caches
+#ifdef LIME_PLAIN_LOADS
+#define LIME_STREAM_LOAD(p) (*(p))
+#else
+#define LIME_STREAM_LOAD(p) __builtin_nontemporal_load(p)
+#endif
+
 template <int EBWT>
 __device__ __forceinline__ void window_load(WinRegs &t, const ScanArgs &a, uint64_t lo)
 {
@@ -802,10 +810,10 @@ __device__ __forceinline__ void window_load(WinRegs &t, const ScanArgs &a, uint6
     const uint32_t *lp = a.lcp + lo + lane, *dp = a.da + lo + lane;
     if (lo + WIN <= a.n_avail) {                           // wave-uniform: the whole window is data
 #pragma unroll
-        for (int j = 0; j < (int)PPL; ++j) { t.lv[j] = lp[64 * j]; t.dv[j] = dp[64 * j]; }
+        for (int j = 0; j < (int)PPL; ++j) { t.lv[j] = LIME_STREAM_LOAD(lp + 64 * j); t.dv[j] = LIME_STREAM_LOAD(dp + 64 * j); }
 #pragma unroll
         for (int k = 0; k < (int)PPL / 4; ++k)
-            t.bv[k] = EBWT ? *reinterpret_cast<const u32u *>(a.ebwt + lo + 256u * (uint32_t)k + 4u * lane) : 0u;
+            t.bv[k] = EBWT ? LIME_STREAM_LOAD(reinterpret_cast<const u32u *>(a.ebwt + lo + 256u * (uint32_t)k + 4u * lane)) : 0u;
     } else {
         // the last window of the data: addresses clamped to the last element (what the padding
         // positions read is never used: the masks mark them), ebwt byte by byte
@@ -815,6 +823,9 @@ __device__ __forceinline__ void window_load(WinRegs &t, const ScanArgs &a, uint6
         for (int j = 0; j < (int)PPL; ++j) {
             const uint32_t p = 64u * (uint32_t)j + lane, q = p < last ? p : last;
             t.lv[j] = a.lcp[lo + q]; t.dv[j] = a.da[lo + q];
+            // opaque to the optimiser: otherwise it folds these loads with the fast path's into one load
+            // through a selected 64-bit address per register (32 address pairs of VGPRs, no `nt`)
+            asm volatile("" : "+v"(t.lv[j]), "+v"(t.dv[j]));
         }
 #pragma unroll
         for (int k = 0; k < (int)PPL / 4; ++k) {
@@ -825,6 +836,7 @@ __device__ __forceinline__ void window_load(WinRegs &t, const ScanArgs &a, uint6
                     const uint32_t p = 256u * (uint32_t)k + 4u * lane + (uint32_t)b;
                     w |= (uint32_t)a.ebwt[lo + (p < last ? p : last)] << (8 * b);
                 }
+            asm volatile("" : "+v"(w));
             t.bv[k] = w;
         }
     }
