@@ -406,6 +406,23 @@ def test_full_size_paths_agree(ctx, shape):
     assert int(nz.sum()) == int(torch.count_nonzero(t2))
 
 
+@pytest.mark.parametrize("nr,ng,mode", [(1, 1, 0), (2, 2, 1), (3, 5, 1), (2, 40, 0)])
+def test_repeated_documents_everywhere(ctx, nr, ng, mode):
+    """very few documents: nearly every cluster holds a repeated document, far more per window than a wave's
+    LDS store takes, so the overflow lists and the fallback kernel (k_score_med) carry most of the scoring;
+    counts wrap modulo 256 many times"""
+    n = 400003
+    lcp, da, eb = O.synth(1234 + nr, 0, n, nr, ng, 16, mode)
+    cl, nc, ml = O.detect(lcp, da, nr, 16)
+    for e in (eb, None):
+        exp = O.score(da, e, cl, nr, ng, threads=4)
+        sim, gnc, gml = ctx.fused(lcp, da, e, nr, ng, 16)
+        s, rc = ctx.stats()
+        assert rc == 0 and (ng > 5 or s.n_med[1] > 0), "the overflow list was not used"
+        assert (gnc, gml) == (nc, ml) and np.array_equal(sim, exp)
+        assert np.array_equal(ctx.score(da, e, cl, nr, ng), exp)
+
+
 def lime_sim_bytes(nr, ng):
     import lime_amd
     return lime_amd.sim_bytes(nr, ng)
