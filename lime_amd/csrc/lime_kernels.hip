@@ -1141,14 +1141,19 @@ __global__ __launch_bounds__(256) void k_resolve(ScanArgs a)
 __global__ __launch_bounds__(1024) void k_scan_tiles(const uint32_t *cnt, uint64_t *off,
                                                      uint32_t n, unsigned long long *total)
 {
+    constexpr uint32_t PER = 16;                       // consecutive counters per thread and round
     __shared__ uint64_t wsum[16];
     __shared__ uint64_t carry;
     const uint32_t tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
     if (tid == 0) carry = 0;
     __syncthreads();
-    for (uint32_t base = 0; base < n; base += 1024u) {
-        const uint32_t i = base + tid;
-        uint64_t v = (i < n) ? cnt[i] : 0ull, x = v;
+    for (uint32_t base = 0; base < n; base += 1024u * PER) {
+        const uint32_t i0 = base + tid * PER;
+        uint32_t v[PER];
+        uint64_t mine = 0;
+#pragma unroll
+        for (uint32_t k = 0; k < PER; ++k) { v[k] = (i0 + k < n) ? cnt[i0 + k] : 0u; mine += v[k]; }
+        uint64_t x = mine;
 #pragma unroll
         for (int d = 1; d < 64; d <<= 1) { uint64_t y = __shfl_up(x, d); if ((int)lane >= d) x += y; }
         if (lane == 63u) wsum[wave] = x;
@@ -1156,9 +1161,11 @@ __global__ __launch_bounds__(1024) void k_scan_tiles(const uint32_t *cnt, uint64
         uint64_t wpre = 0;
         for (uint32_t k = 0; k < wave; ++k) wpre += wsum[k];
         const uint64_t c = carry;
-        if (i < n) off[i] = c + wpre + x - v;
+        uint64_t run = c + wpre + x - mine;
+#pragma unroll
+        for (uint32_t k = 0; k < PER; ++k) { if (i0 + k < n) off[i0 + k] = run; run += v[k]; }
         __syncthreads();
-        if (tid == 1023u) carry = c + wpre + x;
+        if (tid == 1023u) carry = run;
         __syncthreads();
     }
     if (tid == 0) *total = carry;
