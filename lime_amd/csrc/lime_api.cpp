@@ -45,6 +45,7 @@ struct lime_ctx {
     uint32_t *d_tile_cnt = nullptr;
     uint64_t *d_tile_off = nullptr;
     CrossRec *d_cross = nullptr;
+    WinMasks *d_wmask = nullptr; size_t wmask_cap = 0;
     // cluster lists
     lime_cluster_t *d_small = nullptr; uint32_t small_cap = 0;
     lime_cluster_t *d_big = nullptr; uint32_t big_cap = 0;
@@ -103,7 +104,7 @@ extern "C" void lime_shutdown(lime_ctx *c)
     (void)hipDeviceSynchronize();
     for (hipEvent_t e : c->ev) (void)hipEventDestroy(e);
     (void)hipFree(c->d_stats); (void)hipFree(c->d_total); (void)hipFree(c->d_summ);
-    (void)hipFree(c->d_tile_cnt); (void)hipFree(c->d_tile_off); (void)hipFree(c->d_cross);
+    (void)hipFree(c->d_tile_cnt); (void)hipFree(c->d_tile_off); (void)hipFree(c->d_cross); (void)hipFree(c->d_wmask);
     (void)hipFree(c->d_small); (void)hipFree(c->d_big); (void)hipFree(c->d_med); (void)hipFree(c->d_out);
     (void)hipFree(c->d_big_scratch);
     delete c;
@@ -152,7 +153,11 @@ static int ensure_scratch(lime_ctx *c, uint64_t n_avail, bool detect, bool score
             HIP_TRY(hipGetLastError());
         }
     }
-    (void)detect;
+    if (detect && c->tile_cap > c->wmask_cap) {
+        HIP_TRY(hipStreamSynchronize(st));
+        if ((rc = regrow(c->d_wmask, c->tile_cap))) return rc;
+        c->wmask_cap = c->tile_cap;
+    }
     return LIME_OK;
 }
 
@@ -179,6 +184,7 @@ static ScanArgs base_args(lime_ctx *c, const uint32_t *lcp, const uint32_t *da, 
     a.small = c->d_small; a.cross_cap = c->small_cap; a.big = c->d_big; a.big_cap = c->big_cap;
     a.med = c->d_med; a.med_cap = c->med_cap;
     a.tile_cnt = c->d_tile_cnt; a.tile_off = c->d_tile_off; a.cross = c->d_cross; a.out = c->d_out;
+    a.wmask = c->d_wmask;
     a.ablate = c->ablate;
     return a;
 }
@@ -317,7 +323,7 @@ extern "C" int lime_detect_dev(lime_ctx *c, const uint32_t *d_lcp, const uint32_
     }
     if (total) {
         a.out = c->d_out;
-        launch_tile(0, 2, a, c->max_blocks, st);
+        launch_emit(a, st);
         HIP_TRY(hipGetLastError());
     }
     *d_clusters = c->d_out; *n_clusters = total; *max_len = s.max_len;

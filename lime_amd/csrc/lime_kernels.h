@@ -31,6 +31,10 @@ struct DevStats {                            // same layout as lime_stats_t
 };
 static_assert(sizeof(DevStats) == sizeof(lime_stats_t), "DevStats must mirror lime_stats_t");
 
+// what the count pass keeps of a window for the emit pass: per mask word the heads of accepted owned
+// clusters, all heads, and where the segment of the word's last head ends
+struct WinMasks { uint64_t ah[NW + 1], h[NW + 1]; uint32_t e_suf[NW + 1]; uint32_t pad; };
+
 struct ScanArgs {
     const uint32_t *lcp; const uint32_t *da; const uint8_t *ebwt;
     uint64_t n_own, n_avail, pos_base;
@@ -43,11 +47,13 @@ struct ScanArgs {
     lime_cluster_t *big; uint32_t big_cap;       // clusters > SMALL_MAX
     uint64_t *med; uint32_t med_cap;             // 2 lists of med_cap records for k_score_med: pStart | (len-1) << 48
     uint32_t *tile_cnt; uint64_t *tile_off; CrossRec *cross; lime_cluster_t *out;   // detect only
+    WinMasks *wmask;                             // detect only: count pass -> emit pass
     int ablate;                                  // timing experiments only (LIME_ABLATE): 0 = full kernel
 };
 
 void launch_tile(int ebwt, int mode, const ScanArgs &a, uint32_t max_blocks, hipStream_t st);
 void launch_resolve(int mode, const ScanArgs &a, hipStream_t st);
+void launch_emit(const ScanArgs &a, hipStream_t st);
 void launch_scan_tiles(const uint32_t *cnt, uint64_t *off, uint32_t n, unsigned long long *total, hipStream_t st);
 void launch_score_list(int ebwt, const ScanArgs &a, const lime_cluster_t *list, uint64_t count, uint32_t blocks, hipStream_t st);
 void launch_gather_pairs(const uint8_t *sim, uint32_t n_reads, uint32_t n_refs, const uint64_t *row_off,

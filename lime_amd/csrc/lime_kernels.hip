@@ -933,7 +933,7 @@ __global__ __launch_bounds__(SCANK_WG) __attribute__((amdgpu_waves_per_eu(LIME_S
                 pre = (((rw & wlow) || (rl64(c.r, fw) & below)) ? 1u : 0u) | (((gw & wlow) || (rl64(c.g, fw) & below)) ? 2u : 0u);
                 suf = (((rw & whigh) || (rl64(c.r, lw) & from)) ? 1u : 0u) | (((gw & whigh) || (rl64(c.g, lw) & from)) ? 2u : 0u);
             }
-            if (lane == 0 && MODE != 2) { sm.pre = pre; sm.suf = suf; a.summ[win] = sm; }
+            if (lane == 0) { sm.pre = pre; sm.suf = suf; a.summ[win] = sm; }
             // a run closed by padding instead of data while more data exists beyond the shard's
             // halo: the last data head in sight is owned and nothing but padding follows it
             if (!a.eof && lim < WPOS) {
@@ -1042,7 +1042,11 @@ __global__ __launch_bounds__(SCANK_WG) __attribute__((amdgpu_waves_per_eu(LIME_S
             uint32_t rank = x - my_n;
             const uint32_t win_cnt = rl32(x, 63);
             if (MODE == 1 && lane == 0) a.tile_cnt[win] = win_cnt;
-            while (__ballot(ahb != 0u)) {
+            if (MODE == 1 && lane <= NW) {                        // kept for k_emit: no second pass over the arrays
+                WinMasks &m = a.wmask[win];
+                m.ah[lane] = c.ah; m.h[lane] = c.h; m.e_suf[lane] = c.e_suf;
+            }
+            while (__ballot(ahb != 0u)) {                         // longest record of the window
                 const bool act = ahb != 0u;
                 const uint32_t b = act ? (uint32_t)__builtin_ctz(ahb) : 0u;
                 ahb &= ahb - 1u;
@@ -1051,17 +1055,6 @@ __global__ __launch_bounds__(SCANK_WG) __attribute__((amdgpu_waves_per_eu(LIME_S
                 const uint32_t e = ha ? 64u * w + (uint32_t)__builtin_ctzll(ha) : e_suf;
                 const uint32_t len = act ? e - p : 0u;
                 acc_max = len > acc_max ? len : acc_max;
-                if (MODE == 2 && act) {
-                    lime_cluster_t rec; rec.pStart = a.pos_base + lo + p; rec.len = len;
-                    a.out[a.tile_off[win] + rank] = rec; ++rank;
-                }
-            }
-            if (MODE == 2 && lane == 0) {
-                const CrossRec cr = a.cross[win];
-                if (cr.len) {
-                    lime_cluster_t rec; rec.pStart = a.pos_base + cr.start; rec.len = cr.len;
-                    a.out[a.tile_off[win] + win_cnt] = rec;
-                }
             }
         }
         }
@@ -1083,12 +1076,50 @@ __global__ __launch_bounds__(SCANK_WG) __attribute__((amdgpu_waves_per_eu(LIME_S
                (unsigned long long)pt_acc[4], (unsigned long long)pt_acc[5], (unsigned long long)pt_acc[6], (unsigned long long)pt_acc[7],
                pt_nwin, (unsigned long long)pt_m[0], (unsigned long long)pt_m[1], (unsigned long long)pt_m[2], (unsigned long long)pt_m[3], qu.n_drain, (unsigned long long)qu.t_drain);
 #endif
-    if (MODE != 2) {
+    {
         const uint32_t tn = wave_sum(acc_n), tm = wave_max(acc_max), tu = wave_sum(acc_upd);
         if (lane == 0) {
             if (tn) atomicAdd(&a.stats->n_clusters, (unsigned long long)tn);
             if (tm) atomicMax(&a.stats->max_len, (unsigned long long)tm);
             if (MODE == 0 && tu) atomicAdd(&a.stats->n_updates, (unsigned long long)tu);
+        }
+    }
+}
+
+// =========================================================================================
+// k_emit: the (pStart, len) records of every window, in ascending pStart, from the masks the
+// count pass kept (WinMasks) and the windows' record offsets.  A wave per window; lane l walks the
+// accepted heads among positions [16 l, 16 l + 16).  The record of a run that crosses the window's
+// read-ahead (k_resolve) goes last: its head is the window's last.
+// =========================================================================================
+__global__ __launch_bounds__(256) void k_emit(ScanArgs a)
+{
+    const uint32_t lane = lane_id();
+    const uint32_t win = blockIdx.x * 4u + (threadIdx.x >> 6);
+    if (win >= a.n_tiles) return;
+    const uint64_t lo = (uint64_t)win * WIN;
+    const WinMasks &m = a.wmask[win];
+    const uint32_t w = (PPL * lane) >> 6, o = (PPL * lane) & 63u;
+    const uint64_t AHw = m.ah[w], Hw = m.h[w];
+    const uint32_t e_suf = m.e_suf[w];
+    uint32_t ahb = (uint32_t)(AHw >> o) & ((1u << PPL) - 1u);
+    const uint32_t my_n = (uint32_t)__popc(ahb);
+    const uint32_t x = wave_incl_scan(my_n);
+    uint64_t at = a.tile_off[win] + x - my_n;
+    while (ahb) {
+        const uint32_t b = (uint32_t)__builtin_ctz(ahb);
+        ahb &= ahb - 1u;
+        const uint32_t bit = o + b, p = 64u * w + bit;
+        const uint64_t ha = (bit == 63u) ? 0ull : (Hw & (~0ull << (bit + 1u)));
+        const uint32_t e = ha ? 64u * w + (uint32_t)__builtin_ctzll(ha) : e_suf;
+        lime_cluster_t rec; rec.pStart = a.pos_base + lo + p; rec.len = e - p;
+        a.out[at++] = rec;
+    }
+    if (lane == 63u) {
+        const CrossRec cr = a.cross[win];
+        if (cr.len) {
+            lime_cluster_t rec; rec.pStart = a.pos_base + cr.start; rec.len = cr.len;
+            a.out[at] = rec;                              // lane 63: `at` is past all records of the window
         }
     }
 }
@@ -1508,8 +1539,12 @@ void launch_tile(int ebwt, int mode, const ScanArgs &a, uint32_t max_blocks, hip
     if (mode == 0) {
         if (ebwt) launch_scan_kernel(k_scan<1, 0>, a, max_blocks, st);
         else      launch_scan_kernel(k_scan<0, 0>, a, max_blocks, st);
-    } else if (mode == 1) launch_scan_kernel(k_scan<0, 1>, a, max_blocks, st);
-    else                  launch_scan_kernel(k_scan<0, 2>, a, max_blocks, st);
+    } else launch_scan_kernel(k_scan<0, 1>, a, max_blocks, st);
+}
+
+void launch_emit(const ScanArgs &a, hipStream_t st)
+{
+    hipLaunchKernelGGL(k_emit, dim3((a.n_tiles + 3u) / 4u), dim3(256), 0, st, a);
 }
 
 void launch_resolve(int mode, const ScanArgs &a, hipStream_t st)
