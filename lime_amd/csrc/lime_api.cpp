@@ -505,6 +505,17 @@ extern "C" int lime_detect(lime_ctx *c, const uint32_t *lcp, const uint32_t *da,
         uint64_t cnt = 0, m = 0;
         rc = lime_detect_dev(c, (const uint32_t *)dl.p, (const uint32_t *)dd.p, own, avail, lo + avail == n, lo, n_reads,
                              alpha, &dc, &cnt, &m, nullptr);
+        if (rc == LIME_ERR_HALO && chunk < n) {
+            // a run longer than the halo crosses a chunk border.  ClusterLCP itself has no length limit
+            // (only ClusterBWT_DA refuses such a cluster later): redo the whole collection as one chunk
+            free(h); h = nullptr; have = 0; room = 0; ml = 0;
+            chunk = (n + LIME_TILE - 1) / LIME_TILE * LIME_TILE;
+            (void)hipFree(dl.p); dl.p = nullptr; (void)hipFree(dd.p); dd.p = nullptr;
+            if ((rc = dl.alloc(n * 4 + 16))) return rc;
+            if ((rc = dd.alloc(n * 4 + 16))) return rc;
+            lo = 0 - chunk;                               // the loop's increment brings it back to 0
+            continue;
+        }
         if (rc) { free(h); return rc; }
         if (m > ml) ml = m;
         if (cnt) {

@@ -160,12 +160,17 @@ __device__ __forceinline__ uint32_t wave_incl_scan(uint32_t v)
 // pairlut[rmask | (len-1) << 4] for a cluster of len = 2..4 symbols with read bits rmask: bit k = position
 // pair k of (0,1)(0,2)(0,3)(1,2)(1,3)(2,3) joins a read with a genome inside the cluster, bit 8+k =
 // the pair's FIRST position is the read
-struct WgTables { uint8_t symidx[256]; uint16_t compat[16]; uint16_t pairlut[64]; };
+struct WgTables { uint8_t symidx[256]; uint16_t compat[16]; uint16_t pairlut[64]; uint16_t compatb[256]; };   // compatb[byte] = compat[symidx[byte]]
 
 __device__ __forceinline__ void tables_init(WgTables &T)
 {
     const uint32_t t = threadIdx.x;
-    for (uint32_t b = t; b < 256u; b += blockDim.x) T.symidx[b] = (uint8_t)sym_index(b);
+    for (uint32_t b = t; b < 256u; b += blockDim.x) {
+        const uint32_t si = sym_index(b);
+        uint32_t m = 0;
+        for (uint32_t k = 0; k < 16u; ++k) m |= iupac_match(si, k) << k;
+        T.symidx[b] = (uint8_t)si; T.compatb[b] = (uint16_t)m;
+    }
     if (t < 16u) {
         uint32_t m = 0;
         for (uint32_t b = 0; b < 16u; ++b) m |= iupac_match(t, b) << b;
@@ -585,8 +590,9 @@ __device__ __forceinline__ uint32_t score_small(LDS &L, const WgTables &T, UpdQu
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
         d[i] = L.da[p + i];
-        sy[i] = EBWT ? T.symidx[L.fl[p + i]] : 0u;
-        cs[i] = EBWT ? T.compat[sy[i]] : 0xFFFFu;
+        const uint32_t by = EBWT ? L.fl[p + i] : 0u;
+        sy[i] = EBWT ? T.symidx[by] : 0u;
+        cs[i] = EBWT ? T.compatb[by] : 0xFFFFu;          // same depth as symidx: one LDS round trip less
     }
     // positions past the cluster get values no document has (the API bounds n_reads + n_refs), so that
     // the six equality tests need no length checks
@@ -684,7 +690,7 @@ __device__ __forceinline__ uint32_t score_medium(LDS &L, const WgTables &T, UpdQ
                 PT(0)
                 const uint32_t rem = on ? cl - 1u - i : 0u;                 // positions after i in the cluster
                 const uint32_t di = L.da[q];
-                const uint32_t ci = EBWT ? T.compat[T.symidx[L.fl[q]]] : 0xFFFFu;
+                const uint32_t ci = EBWT ? T.compatb[L.fl[q]] : 0xFFFFu;
                 // read bits of q .. q+15 from the staged mask bytes
                 const uint32_t kb = q >> 3;
                 const uint32_t rb16 = ((uint32_t)L.rb[kb] | ((uint32_t)L.rb[kb + 1u] << 8) | ((uint32_t)L.rb[kb + 2u] << 16)) >> (q & 7u);

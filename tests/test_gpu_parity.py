@@ -302,6 +302,19 @@ def test_maxlen_error(ctx):
         ctx.score(da, None, cl, 1, 1)
 
 
+def test_detect_in_chunks_with_a_run_longer_than_the_halo(ctx, monkeypatch):
+    """ClusterLCP has no length limit: a run longer than the chunk halo makes the chunked walk start over as
+    one chunk instead of failing"""
+    monkeypatch.setenv("LIME_DETECT_CHUNK", "4096")
+    n = 200000
+    lcp, da, _ = O.synth(5, 0, n, 50, 7, 16, 0)
+    lcp[30000:110000] = 30                                  # one run of 80001 positions
+    da[30000] = 0; da[30001] = 60                            # a read and a genome inside it
+    cl, nc, ml = ctx.detect(lcp, da, 50, 16)
+    ecl, enc, eml = O.detect(lcp, da, 50, 16)
+    assert (nc, ml) == (enc, eml) and np.array_equal(cl, ecl) and ml > 80000
+
+
 def test_docid_out_of_range_is_reported(ctx):
     import lime_amd
     lcp = np.array([0, 20, 20, 0], np.uint32)
