@@ -367,7 +367,7 @@ extern "C" int lime_choose_dev(lime_ctx *c, const uint8_t *d_sim, uint32_t n_rea
 {
     int rc = check_ctx(c, "lime_choose_dev"); if (rc) return rc;
     if (!d_sim || !d_row_max || !d_row_nnz) return fail(LIME_ERR_ARG, "lime_choose_dev: NULL array");
-    if (misaligned(d_sim, 4)) return fail(LIME_ERR_ARG, "lime_choose_dev: d_sim must be 4-byte aligned");
+    if (misaligned(d_sim, 16)) return fail(LIME_ERR_ARG, "lime_choose_dev: d_sim must be 16-byte aligned (and lime_sim_bytes() long)");
     if (!n_reads) return LIME_OK;
     launch_choose(d_sim, n_reads, n_refs, d_row_max, d_row_nnz, (hipStream_t)stream);
     HIP_TRY(hipGetLastError());
@@ -665,7 +665,7 @@ extern "C" int lime_choose_pairs_dev(lime_ctx *c, const uint8_t *d_sim, uint32_t
         return fail(LIME_ERR_ARG, "lime_choose_pairs_dev: NULL array");
     *pairs = nullptr; *n_pairs = 0; row_off[0] = 0;
     if (!n_reads) return LIME_OK;
-    if (misaligned(d_sim, 4)) return fail(LIME_ERR_ARG, "lime_choose_pairs_dev: d_sim must be 4-byte aligned");
+    if (misaligned(d_sim, 16)) return fail(LIME_ERR_ARG, "lime_choose_pairs_dev: d_sim must be 16-byte aligned (and lime_sim_bytes() long)");
     hipStream_t st = (hipStream_t)stream;
     DevBuf dm, dz, doff, dp;
     if ((rc = dm.alloc(n_reads))) return rc;

@@ -1437,19 +1437,31 @@ __global__ __launch_bounds__(WGSZ) void k_choose(const uint8_t *sim, uint32_t n_
 {
     const uint32_t lane = threadIdx.x & 63u;
     const uint64_t waves = (uint64_t)gridDim.x * (WGSZ / 64);
+    // max and non-zero count of the four bytes of a word, SWAR (no per-byte bounds checks: the caller
+    // has cleared the bytes outside the row)
+    auto word = [](uint32_t v, uint32_t &mx, uint32_t &nz) {
+        const uint32_t b0 = v & 255u, b1 = (v >> 8) & 255u, b2 = (v >> 16) & 255u, b3 = v >> 24;
+        const uint32_t m01 = b0 > b1 ? b0 : b1, m23 = b2 > b3 ? b2 : b3, m = m01 > m23 ? m01 : m23;
+        mx = m > mx ? m : mx;
+        uint32_t t = v | (v >> 4); t |= t >> 2; t |= t >> 1;
+        nz += (uint32_t)__popc(t & 0x01010101u);
+    };
     for (uint64_t r = (uint64_t)blockIdx.x * (WGSZ / 64) + (threadIdx.x >> 6); r < n_reads; r += waves) {
         const uint64_t b0 = r * n_refs, b1 = b0 + n_refs;
-        const uint64_t w0 = b0 >> 2, w1 = (b1 + 3ull) >> 2;
+        const uint64_t q0 = b0 >> 4, q1 = (b1 + 15ull) >> 4;            // 16-byte groups covering the row
         uint32_t mx = 0, nz = 0;
-        for (uint64_t w = w0 + lane; w < w1; w += 64u) {
-            uint32_t v = reinterpret_cast<const uint32_t *>(sim)[w];
+        for (uint64_t q = q0 + lane; q < q1; q += 64u) {
+            uint4 v = reinterpret_cast<const uint4 *>(sim)[q];            // the table is padded to 16 bytes
+            if (q == q0 || q + 1 == q1) {                                 // first / last group: clear foreign bytes
+                uint32_t w[4] = {v.x, v.y, v.z, v.w};
 #pragma unroll
-            for (int k = 0; k < 4; ++k) {
-                const uint64_t byte = w * 4ull + k;
-                const uint32_t x = (byte >= b0 && byte < b1) ? ((v >> (8 * k)) & 255u) : 0u;
-                mx = x > mx ? x : mx;
-                nz += (x != 0u);
+                for (int k = 0; k < 16; ++k) {
+                    const uint64_t byte = q * 16ull + k;
+                    if (byte < b0 || byte >= b1) w[k >> 2] &= ~(255u << (8 * (k & 3)));
+                }
+                v = make_uint4(w[0], w[1], w[2], w[3]);
             }
+            word(v.x, mx, nz); word(v.y, mx, nz); word(v.z, mx, nz); word(v.w, mx, nz);
         }
 #pragma unroll
         for (int d = 32; d > 0; d >>= 1) {
