@@ -31,9 +31,9 @@ struct DevStats {                            // same layout as lime_stats_t
 };
 static_assert(sizeof(DevStats) == sizeof(lime_stats_t), "DevStats must mirror lime_stats_t");
 
-// what the count pass keeps of a window for the emit pass: per mask word the heads of accepted owned
-// clusters, all heads, and where the segment of the word's last head ends
-struct WinMasks { uint64_t ah[NW + 1], h[NW + 1]; uint32_t e_suf[NW + 1]; uint32_t pad; };
+// what the count pass keeps of a window for the emit pass: per 16-position chunk the heads of accepted
+// owned clusters, all heads, and where the segment of the chunk's last head ends
+struct WinMasks { uint16_t ah[64], h[64]; uint32_t e_suf[64]; };     // per 16-position chunk (lane)
 
 struct ScanArgs {
     const uint32_t *lcp; const uint32_t *da; const uint8_t *ebwt;

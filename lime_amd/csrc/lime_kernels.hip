@@ -75,7 +75,7 @@ struct alignas(16) WaveLds {
 #define LIME_SCAN_WAVES 3
 #endif
 constexpr int SCANK_WG = LIME_SCANK_WG;   // threads per workgroup of k_scan; its waves work independently
-constexpr uint32_t DUP_SLOTS = 16;    // clusters with a repeated document a wave of k_scan holds before scoring them
+constexpr uint32_t DUP_SLOTS = 8;     // clusters with a repeated document a wave of k_scan holds before scoring them
 constexpr uint32_t QCAP_SCAN = 256;   // >= the 256 hits one batch of 64 clusters of <= 4 symbols can add
 struct alignas(16) ScanLds {
     uint32_t da[WPOS + SMALL_MAX];    // padded: rows of score_medium read up to SMALL_MAX-1 past a position
@@ -1048,10 +1048,6 @@ __global__ __launch_bounds__(SCANK_WG) __attribute__((amdgpu_waves_per_eu(LIME_S
             uint32_t rank = x - my_n;
             const uint32_t win_cnt = rl32(x, 63);
             if (MODE == 1 && lane == 0) a.tile_cnt[win] = win_cnt;
-            if (MODE == 1 && lane <= NW) {                        // kept for k_emit: no second pass over the arrays
-                WinMasks &m = a.wmask[win];
-                m.ah[lane] = c.ah; m.h[lane] = c.h; m.e_suf[lane] = c.e_suf;
-            }
             while (__ballot(ahb != 0u)) {                         // longest record of the window
                 const bool act = ahb != 0u;
                 const uint32_t b = act ? (uint32_t)__builtin_ctz(ahb) : 0u;
@@ -1093,6 +1089,282 @@ __global__ __launch_bounds__(SCANK_WG) __attribute__((amdgpu_waves_per_eu(LIME_S
 }
 
 // =========================================================================================
+// k_scan2: the scan with a CHUNK front end.  Lane l owns positions [16 l, 16 l + 16) of the window:
+// its head / read bits are 16-bit masks (cut out of the ballot-built mask words),
+// cluster acceptance inside a chunk is the carry-ripple trick on 16 bits (32-bit
+// arithmetic), the segment of a chunk's LAST head is decided with wave ballots over "chunk has a
+// head / a read / a genome" and one ds_bpermute, the read-ahead being one more chunk (wave-uniform).
+// Every lane then writes the (position, length) of its accepted clusters into an LDS list at the slots
+// a wave prefix sum gives it; the scoring rounds read that list.  Back end (scoring, table updates)
+// and MODE semantics as k_scan.
+// =========================================================================================
+struct alignas(16) ScanLds2 {
+    uint32_t da[WPOS + SMALL_MAX];
+    uint8_t fl[WPOS + SMALL_MAX];
+    alignas(8) uint8_t hb[WPOS / 8 + 14];    // head / read bit of every staged position (byte k = positions 8k..8k+7)
+    alignas(8) uint8_t rb[WPOS / 8 + 14];
+    // accepted clusters of the window, in order: start | min(len, 63) << 10.  The scoring rounds read it 64
+    // entries at a time and write the list of the clusters of 5..SMALL_MAX symbols (start | (len-1) << 12) over
+    // its already consumed head: the k-th such cluster is at most the k-th cluster read.
+    uint16_t listM[WIN / 2];
+    uint32_t listX[64];
+    uint16_t m_tstart[64];
+    uint8_t m_flag[64], m_dup[64];
+    uint32_t q_read[QCAP_SCAN], q_gen[QCAP_SCAN];
+    uint32_t f_read[256], f_gen[256], f_exp[256];
+    uint32_t g_doc[DUP_SLOTS][SMALL_MAX];
+    uint8_t g_sym[DUP_SLOTS][SMALL_MAX], g_len[DUP_SLOTS];
+};
+
+struct Ctx16 {
+    uint32_t h, r, g;   // 16-bit masks of this lane's chunk
+    uint32_t ah;        // heads of accepted, owned clusters that close inside window + read-ahead
+    uint32_t e_suf;     // window position where the segment of the chunk's last head ends (NONE32: open)
+    uint64_t HW, RW, GW;  // chunk has a head / a read / a genome (wave ballots)
+    uint32_t info;      // fh | lh << 5 | pre_r << 10 | pre_g << 11 | suf_r << 12 | suf_g << 13
+};
+
+// H64 / R64 / G64: the read-ahead chunk (16 bits, wave-uniform).  own_lim <= WIN.
+__device__ __forceinline__ Ctx16 chunk_context(uint32_t h, uint32_t r, uint32_t g, uint32_t H64, uint32_t R64, uint32_t G64,
+                                                uint32_t own_lim)
+{
+    const uint32_t lane = lane_id();
+    Ctx16 c;
+    c.h = h; c.r = r; c.g = g;
+    const bool has_h = h != 0u;
+    c.HW = __ballot(has_h); c.RW = __ballot(r != 0u); c.GW = __ballot(g != 0u);
+    const uint32_t fh = has_h ? (uint32_t)__builtin_ctz(h) : 16u;
+    const uint32_t lh = has_h ? 31u - (uint32_t)__builtin_clz(h) : 0u;
+    const uint32_t lowm = (1u << fh) - 1u;                                        // headless: the whole chunk
+    const uint32_t pre_r = (r & lowm) != 0u, pre_g = (g & lowm) != 0u;
+    const uint32_t him = has_h ? ((0xFFFFu << lh) & 0xFFFFu) : 0u;
+    const uint32_t suf_r = (r & him) != 0u, suf_g = (g & him) != 0u;
+    c.info = fh | (lh << 5) | (pre_r << 10) | (pre_g << 11) | (suf_r << 12) | (suf_g << 13);
+    const uint64_t gt = (lane == 63u) ? 0ull : (~0ull << (lane + 1u));
+    const uint64_t above = c.HW & gt;
+    const bool next_lane = above != 0ull;
+    const uint32_t wn = next_lane ? (uint32_t)__builtin_ctzll(above) : 64u;
+    const uint64_t between = gt & (wn >= 64u ? ~0ull : ((1ull << wn) - 1ull));   // headless chunks after this one
+    const uint32_t mid_r = (c.RW & between) != 0ull, mid_g = (c.GW & between) != 0ull;
+    const uint32_t nx = (uint32_t)__shfl((int)c.info, next_lane ? (int)wn : (int)lane);
+    // no head in a later chunk of the window: the read-ahead chunk comes next
+    const uint32_t hfh = H64 ? (uint32_t)__builtin_ctz(H64) : 16u, hlow = (1u << hfh) - 1u;
+    const uint32_t n_r = next_lane ? (nx >> 10) & 1u : (uint32_t)((R64 & hlow) != 0u);
+    const uint32_t n_g = next_lane ? (nx >> 11) & 1u : (uint32_t)((G64 & hlow) != 0u);
+    const bool has_next = next_lane || H64 != 0u;
+    c.e_suf = next_lane ? PPL * wn + (nx & 31u) : (H64 ? WIN + hfh : NONE32);
+    const uint32_t acc_suf = (has_next && (suf_r | mid_r | n_r) && (suf_g | mid_g | n_g)) ? 1u : 0u;
+    // carry ripple on 16 bits (see window_context): bit-reversed, a head is the top of its segment
+    const uint32_t Hr = __builtin_bitreverse32(h) >> 16, Mr = ~(Hr << 1) & 0xFFFFu;
+    uint32_t Xr = __builtin_bitreverse32(r) >> 16, Y = (Xr << 1) & Mr;
+    const uint32_t RH = (Xr | (((Mr + Y) ^ Mr) & Mr) | Y) & Hr;
+    Xr = __builtin_bitreverse32(g) >> 16; Y = (Xr << 1) & Mr;
+    const uint32_t GH = (Xr | (((Mr + Y) ^ Mr) & Mr) | Y) & Hr;
+    uint32_t ah = __builtin_bitreverse32(RH & GH) >> 16;
+    ah = (ah & ~(1u << lh)) | (acc_suf << lh);                     // last head: decided with the chunks after
+    const uint32_t c0 = PPL * lane;                                // ownership: window part owned by this shard
+    ah &= own_lim >= c0 + PPL ? 0xFFFFu : (own_lim <= c0 ? 0u : ((1u << (own_lim - c0)) - 1u));
+    c.ah = has_h ? ah : 0u;
+    return c;
+}
+
+template <int EBWT, int MODE>
+__global__ __launch_bounds__(SCANK_WG) __attribute__((amdgpu_waves_per_eu(LIME_SCAN_WAVES, LIME_SCAN_WAVES))) void k_scan2(ScanArgs a)
+{
+    __shared__ ScanLds2 lds[SCANK_WG / 64];
+    __shared__ WgTables T;
+    const uint32_t lane = lane_id(), wave = (uint32_t)__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));   // wave-uniform: LDS bases stay scalar
+    ScanLds2 &L = lds[wave];
+    tables_init(T);                                        // the only workgroup barrier of the kernel
+    const uint32_t n_win = a.n_tiles, stride = gridDim.x * (SCANK_WG / 64);
+    uint32_t win = blockIdx.x * (SCANK_WG / 64) + wave;
+    if (win >= n_win) return;
+    UpdQueue qu; qu.qr = L.q_read; qu.qg = L.q_gen; qu.n = 0; qu.cap = QCAP_SCAN;
+    qu.async = true; qu.fr = L.f_read; qu.fg = L.f_gen; qu.fe = L.f_exp;
+    MedState ms = {{0u, 0u}, {0u, 0u}, {0u, 0u}};          // no chunk reserved yet
+    WinRegs regs;
+    window_load<EBWT>(regs, a, (uint64_t)win * WIN);
+    uint32_t acc_n = 0, acc_max = 0, acc_upd = 0;          // per-lane partial counters, reduced once at the end
+    uint32_t n_dup = 0;                                    // clusters waiting in the wave's dup store
+    const uint64_t lt = (1ull << lane) - 1ull;
+    for (;;) {
+        const uint64_t lo = (uint64_t)win * WIN;
+        const uint32_t own_lim = (uint32_t)(a.n_own > lo ? (a.n_own - lo < WIN ? a.n_own - lo : (uint64_t)WIN) : 0ull);
+        const uint64_t lim64 = a.n_avail - lo;             // valid positions of the window + read-ahead: [0, lim)
+        const uint32_t lim = (uint32_t)(lim64 < WPOS ? lim64 : (uint64_t)WPOS);
+        // ---- stage the window in LDS and build the masks.  Loads are lane-strided (register j of lane l =
+        // position 64 j + l: every load instruction reads 64 consecutive elements -- a lane reading its own 16
+        // positions would touch 64 cache lines per instruction), so mask word j is the wave ballot of the
+        // comparison on register j; v_writelane puts word j into lane j, and lane l then takes ITS 16 bits
+        // (word l / 4, bits 16 (l % 4) ..) with one 64-bit permute per mask --------------------------------
+        uint32_t hb, rb, gb, vb, H64, R64, G64, Hd64;
+        {
+            uint32_t hlo = 0, hhi = 0, rlo = 0, rhi = 0;
+            static_assert(PPL == 16 && WIN / 64 == 16, "mask words are written lane by lane below");
+#define LIME_WORD(J) { const uint64_t bh = __ballot(regs.lv[J] < a.alpha), br = __ballot(regs.dv[J] < a.n_reads); \
+                       hlo = write_lane<J>(hlo, (uint32_t)bh); hhi = write_lane<J>(hhi, (uint32_t)(bh >> 32)); \
+                       rlo = write_lane<J>(rlo, (uint32_t)br); rhi = write_lane<J>(rhi, (uint32_t)(br >> 32)); }
+            LIME_WORD(0) LIME_WORD(1) LIME_WORD(2) LIME_WORD(3) LIME_WORD(4) LIME_WORD(5) LIME_WORD(6) LIME_WORD(7)
+            LIME_WORD(8) LIME_WORD(9) LIME_WORD(10) LIME_WORD(11) LIME_WORD(12) LIME_WORD(13) LIME_WORD(14) LIME_WORD(15)
+#undef LIME_WORD
+            const uint32_t v16 = lim > WIN ? ((1u << (lim - WIN)) - 1u) & 0xFFFFu : 0u;       // data positions of the read-ahead
+            Hd64 = (uint32_t)__ballot(lane < HALO && regs.hl < a.alpha) & v16;
+            R64 = (uint32_t)__ballot(lane < HALO && regs.hd < a.n_reads) & v16;
+            H64 = (Hd64 | ~v16) & 0xFFFFu; G64 = v16 & ~R64;
+            hlo = write_lane<16>(hlo, H64); rlo = write_lane<16>(rlo, R64);
+            uint64_t h = ((uint64_t)hhi << 32) | hlo, r = ((uint64_t)rhi << 32) | rlo;
+            if (lim < WPOS) {                              // the end of the data: padding closes runs, is nobody's
+                const uint32_t wl = 64u * lane;
+                const uint64_t v = lim >= wl + 64u ? ~0ull : (lim <= wl ? 0ull : ((1ull << (lim - wl)) - 1ull));
+                if (lane < NW) { h |= ~v; r &= v; }
+            }
+#pragma unroll
+            for (int j = 0; j < (int)PPL; ++j) L.da[64 * j + (int)lane] = regs.dv[j];
+            if (EBWT)
+#pragma unroll
+                for (int k = 0; k < (int)PPL / 4; ++k) reinterpret_cast<u32u *>(L.fl)[64 * k + (int)lane] = regs.bv[k];
+            if (lane < HALO) { L.da[WIN + lane] = regs.hd; if (EBWT) L.fl[WIN + lane] = (uint8_t)regs.hb; }
+            if (lane <= WIN / 64) {
+                *reinterpret_cast<u64a *>(&L.hb[8u * lane]) = h;
+                *reinterpret_cast<u64a *>(&L.rb[8u * lane]) = r;
+            }
+            const uint32_t sh = 16u * (lane & 3u);
+            hb = (uint32_t)(shfl64(h, (int)(lane >> 2)) >> sh) & 0xFFFFu;
+            rb = (uint32_t)(shfl64(r, (int)(lane >> 2)) >> sh) & 0xFFFFu;
+            const uint32_t c0_ = PPL * lane;
+            vb = lim >= c0_ + PPL ? 0xFFFFu : (lim <= c0_ ? 0u : ((1u << (lim - c0_)) - 1u));
+            gb = vb & ~rb;
+        }
+        const uint32_t c0 = PPL * lane;
+        // ---- the next window's loads go out now and land while this one is processed ----------
+        const uint32_t next = win + stride;
+        if (next < n_win) window_load<EBWT>(regs, a, (uint64_t)next * WIN);
+
+        const Ctx16 c = chunk_context(hb, rb, gb, H64, R64, G64, own_lim);
+        // ---- window summary for the segment that is still open after the read-ahead ------------
+        {
+            TileSummary sm;
+            sm.first_head = NONE32; sm.last_head = NONE32;
+            uint32_t pre = (c.RW ? 1u : 0u) | (c.GW ? 2u : 0u), suf = 0u;       // no head: the whole window is "prefix"
+            if (c.HW) {                                                         // wave-uniform: scalar arithmetic
+                const uint32_t fw = (uint32_t)__builtin_ctzll(c.HW), lw = 63u - (uint32_t)__clzll((long long)c.HW);
+                const uint32_t fi = rl32(c.info, fw), li = rl32(c.info, lw);
+                sm.first_head = PPL * fw + (fi & 31u); sm.last_head = PPL * lw + ((li >> 5) & 31u);
+                const uint64_t wlow = (1ull << fw) - 1ull, whigh = (lw == 63u) ? 0ull : (~0ull << (lw + 1u));
+                pre = (((c.RW & wlow) || ((fi >> 10) & 1u)) ? 1u : 0u) | (((c.GW & wlow) || ((fi >> 11) & 1u)) ? 2u : 0u);
+                suf = (((c.RW & whigh) || ((li >> 12) & 1u)) ? 1u : 0u) | (((c.GW & whigh) || ((li >> 13) & 1u)) ? 2u : 0u);
+            }
+            if (lane == 0) { sm.pre = pre; sm.suf = suf; a.summ[win] = sm; }
+            // a run closed by padding instead of data while more data exists beyond the shard's
+            // halo: the last data head in sight is owned and nothing but padding follows it
+            if (!a.eof && lim < WPOS && Hd64 == 0u) {
+                const uint32_t dh = hb & vb;
+                const uint64_t dw = __ballot(dh != 0u);
+                if (dw) {
+                    const uint32_t lw2 = 63u - (uint32_t)__clzll((long long)dw);
+                    const uint32_t hl2 = rl32(dh, lw2);
+                    const uint32_t sstar = PPL * lw2 + 31u - (uint32_t)__builtin_clz(hl2);
+                    if (lane == 0 && sstar < own_lim) atomicOr(&a.stats->flags, LIME_FLAG_HALO);
+                }
+            }
+        }
+        // ---- every lane lists the accepted clusters of its chunk: slots from a wave prefix sum ---------
+        const uint32_t cnt = (uint32_t)__popc(c.ah);
+        const uint32_t incl = wave_incl_scan(cnt), total = rl32(incl, 63);
+        acc_n += cnt;
+        if (MODE == 0) {
+            {
+                uint32_t m = c.ah, k = incl - cnt;
+                while (__ballot(m != 0u)) {
+                    if (m) {
+                        const uint32_t b = (uint32_t)__builtin_ctz(m);
+                        m &= m - 1u;
+                        const uint32_t p = c0 + b, hi = c.h >> (b + 1u);
+                        const uint32_t e = hi ? p + 1u + (uint32_t)__builtin_ctz(hi) : c.e_suf;
+                        const uint32_t len = e - p;
+                        acc_max = len > acc_max ? len : acc_max;
+                        L.listM[k++] = (uint16_t)(p | ((len < 63u ? len : 63u) << 10));
+                    }
+                }
+            }
+            uint32_t nM = 0, nX = 0;
+            for (uint32_t base = 0; base < total; base += 64u) {
+                const uint32_t t = base + lane;
+                const bool on = t < total;
+                const uint32_t item = on ? L.listM[t] : 0u;
+                const uint32_t p = item & 1023u;
+                uint32_t len = item >> 10;
+                if (__ballot(len > SMALL_MAX)) {
+                    if (len >= 63u) {                                 // rare: walk the head bytes to the end of the run
+                        uint32_t q = p + 17u, e = WPOS;               // an accepted cluster closes before WPOS
+                        while (q < WPOS) {
+                            const uint32_t hbq = (uint32_t)L.hb[q >> 3] >> (q & 7u);
+                            if (hbq) { e = q + (uint32_t)__builtin_ctz(hbq); break; }
+                            q = (q | 7u) + 1u;
+                        }
+                        len = e - p;
+                        if (len > MID_MAX) {                          // one workgroup per such cluster later
+                            const uint32_t kk = atomicAdd(&a.stats->n_big, 1u);
+                            if (kk < a.big_cap) { a.big[kk].pStart = lo + p; a.big[kk].len = len; }
+                        }
+                    }
+                    // SMALL_MAX+1 .. MID_MAX symbols: noted, scored after the rounds (at most 61 per window)
+                    const bool cX = len > SMALL_MAX && len <= MID_MAX;
+                    const uint64_t mX = __ballot(cX);
+                    if (cX) L.listX[nX + (uint32_t)__popcll(mX & lt)] = p | (len << 16);
+                    nX += (uint32_t)__popcll(mX);
+                }
+                const bool cM = on && len > 4u && len <= SMALL_MAX;
+                const uint64_t mM = __ballot(cM);
+                if (mM) {
+                    if (cM) L.listM[nM + (uint32_t)__popcll(mM & lt)] = (uint16_t)(p | ((len - 1u) << 12));
+                    nM += (uint32_t)__popcll(mM);
+                }
+                const bool sm4 = on && len <= 4u;
+                acc_upd += score_small<EBWT>(L, T, qu, ms, n_dup, a, lo, sm4, sm4 ? p : 0u, sm4 ? len : 0u);
+            }
+            if (nM) acc_upd += score_medium<EBWT>(L, T, qu, ms, n_dup, a, lo, nM);
+            // 17..64 symbols: the whole wave is one lane group on the staged window
+#pragma unroll 1
+            for (uint32_t k = 0; k < nX; ++k) {
+                const uint32_t it = L.listX[k], p0 = it & 0xFFFFu, len0 = it >> 16;
+                const bool hvv = lane < len0;
+                acc_upd += group_score<EBWT, 64>(a, T, qu, hvv ? L.da[p0 + lane] : 0u, (EBWT && hvv) ? L.fl[p0 + lane] : 0u, len0);
+            }
+            if (n_dup >= DUP_SLOTS / 2u) acc_upd += dup_flush<EBWT>(L, n_dup, a, T, qu);
+        } else {
+            // ---- count: records of the window, its masks for k_emit, the longest record -----------
+            if (lane == 0) a.tile_cnt[win] = total;
+            WinMasks &m = a.wmask[win];
+            m.ah[lane] = (uint16_t)c.ah; m.h[lane] = (uint16_t)c.h; m.e_suf[lane] = c.e_suf;
+            uint32_t mm = c.ah;
+            while (mm) {
+                const uint32_t b = (uint32_t)__builtin_ctz(mm);
+                mm &= mm - 1u;
+                const uint32_t p = c0 + b, hi = c.h >> (b + 1u);
+                const uint32_t e = hi ? p + 1u + (uint32_t)__builtin_ctz(hi) : c.e_suf;
+                acc_max = e - p > acc_max ? e - p : acc_max;
+            }
+        }
+        if (next >= n_win) break;
+        win = next;
+    }
+    if (MODE == 0) {
+        if (n_dup) acc_upd += dup_flush<EBWT>(L, n_dup, a, T, qu);
+        do drain(qu, a); while (qu.n != 0u || __ballot(qu.f_pend != 0u));      // until every update has landed
+        med_fill(a, ms, 0u); med_fill(a, ms, 1u);
+    }
+    {
+        const uint32_t tn = wave_sum(acc_n), tm = wave_max(acc_max), tu = wave_sum(acc_upd);
+        if (lane == 0) {
+            if (tn) atomicAdd(&a.stats->n_clusters, (unsigned long long)tn);
+            if (tm) atomicMax(&a.stats->max_len, (unsigned long long)tm);
+            if (MODE == 0 && tu) atomicAdd(&a.stats->n_updates, (unsigned long long)tu);
+        }
+    }
+}
+
+// =========================================================================================
 // k_emit: the (pStart, len) records of every window, in ascending pStart, from the masks the
 // count pass kept (WinMasks) and the windows' record offsets.  A wave per window; lane l walks the
 // accepted heads among positions [16 l, 16 l + 16).  The record of a run that crosses the window's
@@ -1105,19 +1377,16 @@ __global__ __launch_bounds__(256) void k_emit(ScanArgs a)
     if (win >= a.n_tiles) return;
     const uint64_t lo = (uint64_t)win * WIN;
     const WinMasks &m = a.wmask[win];
-    const uint32_t w = (PPL * lane) >> 6, o = (PPL * lane) & 63u;
-    const uint64_t AHw = m.ah[w], Hw = m.h[w];
-    const uint32_t e_suf = m.e_suf[w];
-    uint32_t ahb = (uint32_t)(AHw >> o) & ((1u << PPL) - 1u);
+    const uint32_t hh = m.h[lane], e_suf = m.e_suf[lane];
+    uint32_t ahb = m.ah[lane];
     const uint32_t my_n = (uint32_t)__popc(ahb);
     const uint32_t x = wave_incl_scan(my_n);
     uint64_t at = a.tile_off[win] + x - my_n;
     while (ahb) {
         const uint32_t b = (uint32_t)__builtin_ctz(ahb);
         ahb &= ahb - 1u;
-        const uint32_t bit = o + b, p = 64u * w + bit;
-        const uint64_t ha = (bit == 63u) ? 0ull : (Hw & (~0ull << (bit + 1u)));
-        const uint32_t e = ha ? 64u * w + (uint32_t)__builtin_ctzll(ha) : e_suf;
+        const uint32_t p = PPL * lane + b, hi = hh >> (b + 1u);
+        const uint32_t e = hi ? p + 1u + (uint32_t)__builtin_ctz(hi) : e_suf;
         lime_cluster_t rec; rec.pStart = a.pos_base + lo + p; rec.len = e - p;
         a.out[at++] = rec;
     }
@@ -1555,9 +1824,14 @@ template <typename K> static void launch_scan_kernel(K kernel, const ScanArgs &a
 void launch_tile(int ebwt, int mode, const ScanArgs &a, uint32_t max_blocks, hipStream_t st)
 {
     if (mode == 0) {
+#ifdef LIME_OLD_FRONT
         if (ebwt) launch_scan_kernel(k_scan<1, 0>, a, max_blocks, st);
         else      launch_scan_kernel(k_scan<0, 0>, a, max_blocks, st);
-    } else launch_scan_kernel(k_scan<0, 1>, a, max_blocks, st);
+#else
+        if (ebwt) launch_scan_kernel(k_scan2<1, 0>, a, max_blocks, st);
+        else      launch_scan_kernel(k_scan2<0, 0>, a, max_blocks, st);
+#endif
+    } else launch_scan_kernel(k_scan2<0, 1>, a, max_blocks, st);
 }
 
 void launch_emit(const ScanArgs &a, hipStream_t st)
