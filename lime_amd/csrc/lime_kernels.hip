@@ -77,22 +77,6 @@ struct alignas(16) WaveLds {
 constexpr int SCANK_WG = LIME_SCANK_WG;   // threads per workgroup of k_scan; its waves work independently
 constexpr uint32_t DUP_SLOTS = 8;     // clusters with a repeated document a wave of k_scan holds before scoring them
 constexpr uint32_t QCAP_SCAN = 256;   // >= the 256 hits one batch of 64 clusters of <= 4 symbols can add
-struct alignas(16) ScanLds {
-    uint32_t da[WPOS + SMALL_MAX];    // padded: rows of score_medium read up to SMALL_MAX-1 past a position
-    uint8_t fl[WPOS + SMALL_MAX];
-    alignas(8) uint8_t hb[WPOS / 8 + 8];
-    alignas(8) uint8_t rb[WPOS / 8 + 8];
-    uint16_t listM[WIN / 5 + 4];
-    uint32_t listX[64];               // this window's clusters of SMALL_MAX+1 .. MID_MAX symbols (start | len << 16)
-    uint16_t m_tstart[64];            // < 64 clusters x 120 pairs
-    uint8_t m_flag[64], m_dup[64];
-    alignas(8) uint64_t asw[NW];
-    uint32_t prew[NW];
-    uint32_t q_read[QCAP_SCAN], q_gen[QCAP_SCAN];
-    uint32_t f_read[256], f_gen[256], f_exp[256];   // entries whose compare-and-swap is in flight, and the word each expects
-    uint32_t g_doc[DUP_SLOTS][SMALL_MAX];   // clusters with a repeated document waiting for dup_flush
-    uint8_t g_sym[DUP_SLOTS][SMALL_MAX], g_len[DUP_SLOTS];
-};
 
 __device__ __forceinline__ uint32_t lane_id() { return threadIdx.x & 63u; }
 __device__ __forceinline__ uint64_t brev64(uint64_t x) { return __builtin_bitreverse64(x); }
@@ -122,25 +106,6 @@ __device__ __forceinline__ uint32_t wave_max(uint32_t v)
 #pragma unroll
     for (int d = 32; d > 0; d >>= 1) { const uint32_t o = __shfl_xor(v, d); v = o > v ? o : v; }
     return v;
-}
-
-// position of the j-th (0-based) set bit of x (j < popcount(x)): binary search over popcounts of
-// halves, branch-free (a "clear the lowest bit j times" loop would run as long as the slowest lane)
-__device__ __forceinline__ uint32_t select_bit(uint64_t x, uint32_t j)
-{
-    uint32_t v = (uint32_t)x, pos = 0;
-    uint32_t c = (uint32_t)__popc(v);
-    if (j >= c) { j -= c; v = (uint32_t)(x >> 32); pos = 32u; }
-#pragma unroll
-    for (uint32_t half = 16u; half >= 1u; half >>= 1) {
-        const uint32_t lowm = (1u << half) - 1u;
-        c = (uint32_t)__popc(v & lowm);
-        const bool up = j >= c;
-        j -= up ? c : 0u;
-        v = up ? (v >> half) : (v & lowm);
-        pos += up ? half : 0u;
-    }
-    return pos;
 }
 
 // inclusive prefix sum over the 64 lanes with DPP row shifts / row broadcasts (no LDS)
@@ -744,56 +709,6 @@ __device__ __forceinline__ uint32_t score_medium(LDS &L, const WgTables &T, UpdQ
     return nupd;
 }
 
-// ---- window context, lane = 64-bit mask word (words 0..7 owned, word 8 = read-ahead) --------
-// Which heads open an accepted cluster.  Segments wholly inside a word are decided by
-// carry-ripple arithmetic on that word's masks; the segment headed at a word's LAST head may
-// run into later words: its end and its read/genome content come from the words after it,
-// found with bit-scans on the wave-wide "word has a head" ballot.
-struct WinCtx {
-    uint64_t h, r, g;   // masks of this lane's word
-    uint64_t ah;        // heads of accepted, owned clusters that close inside window + read-ahead
-    uint32_t e_suf;     // window position where the segment of the word's last head ends (NONE32: open)
-};
-
-__device__ __forceinline__ WinCtx window_context(uint64_t h, uint64_t r, uint64_t g, uint64_t own_lim)
-{
-    const uint32_t lane = lane_id();
-    WinCtx c;
-    c.h = h; c.r = r; c.g = g;
-    const bool has_h = h != 0ull;
-    const uint64_t HW = __ballot(has_h), RW = __ballot(r != 0ull), GW = __ballot(g != 0ull);
-    const uint32_t fh = has_h ? (uint32_t)__builtin_ctzll(h) : 64u;
-    const uint32_t lh = has_h ? 63u - (uint32_t)__clzll((long long)h) : 0u;
-    const uint64_t lowm = fh >= 64u ? ~0ull : ((1ull << fh) - 1ull);
-    const uint32_t pre_r = (r & lowm) != 0ull, pre_g = (g & lowm) != 0ull;       // headless: whole word
-    const uint64_t him = has_h ? (~0ull << lh) : 0ull;
-    const uint32_t suf_r = (r & him) != 0ull, suf_g = (g & him) != 0ull;
-    const uint64_t gt = (lane == 63u) ? 0ull : (~0ull << (lane + 1u));
-    const uint64_t above = HW & gt;
-    const bool has_next = above != 0ull;
-    const uint32_t wn = has_next ? (uint32_t)__builtin_ctzll(above) : 64u;
-    const uint64_t between = gt & (wn >= 64u ? ~0ull : ((1ull << wn) - 1ull));   // headless words after this one
-    const uint32_t mid_r = (RW & between) != 0ull, mid_g = (GW & between) != 0ull;
-    const int src = has_next ? (int)wn : (int)lane;
-    const uint32_t n_r = __shfl(pre_r, src), n_g = __shfl(pre_g, src), n_fh = __shfl(fh, src);
-    c.e_suf = has_next ? wn * 64u + n_fh : NONE32;
-    const uint64_t acc_suf = (has_next && (suf_r | mid_r | n_r) && (suf_g | mid_g | n_g)) ? 1ull : 0ull;
-    // "segment contains a read / a genome", gathered onto the segment's head bit: in
-    // bit-reversed order a head is the TOP of its segment, and adding the seeds to the
-    // "may receive from below" mask ripples a carry through each segment up to its head.
-    const uint64_t Hr = brev64(h), Mr = ~(Hr << 1);
-    uint64_t Xr = brev64(r), Y = (Xr << 1) & Mr;
-    const uint64_t RH = (Xr | (((Mr + Y) ^ Mr) & Mr) | Y) & Hr;
-    Xr = brev64(g); Y = (Xr << 1) & Mr;
-    const uint64_t GH = (Xr | (((Mr + Y) ^ Mr) & Mr) | Y) & Hr;
-    uint64_t ah = brev64(RH & GH);
-    ah = (ah & ~(1ull << lh)) | (acc_suf << lh);                  // last head: decided with the words after
-    const uint64_t wlo = (uint64_t)lane * 64u;                     // ownership: window part owned by this shard
-    ah &= own_lim >= wlo + 64u ? ~0ull : (own_lim <= wlo ? 0ull : ((1ull << (own_lim - wlo)) - 1ull));
-    c.ah = has_h ? ah : 0ull;
-    return c;
-}
-
 // ---- window loads: lane l holds positions 64 j + l (j < PPL) of the window -- every load
 // instruction reads 64 consecutive elements, and the wave ballot of a comparison on register j IS
 // mask word j -- the ebwt bytes 256 k + 4 l .. + 3 (k < PPL/4), and position WIN + l of the
@@ -854,251 +769,18 @@ __device__ __forceinline__ void window_load(WinRegs &t, const ScanArgs &a, uint6
 }
 
 // =========================================================================================
-// k_scan: the streaming scan.  Every wave is an independent worker over windows of WIN
-// positions (stride = number of waves in the grid); no workgroup barrier in the loop.
-// MODE: 0 detect + score, 1 count clusters per window, 2 emit cluster records in order.
+// k_scan: the streaming scan.  Every wave is an independent worker over windows of WIN positions
+// (stride = number of waves in the grid); no workgroup barrier in the loop.
+// MODE 0: detect + score; 1: count clusters per window and keep the window's masks for k_emit.
+// Front end: lane-strided loads; mask words from wave ballots; lane l owns the CHUNK of positions
+// [16 l, 16 l + 16): its head / read bits are 16-bit masks cut out of the mask words, cluster
+// acceptance inside a chunk is a carry ripple on 16 bits (32-bit arithmetic), the segment of a
+// chunk's LAST head is decided with wave ballots over "chunk has a head / a read / a genome" and
+// one ds_bpermute, the read-ahead being one more chunk (wave-uniform).  Every lane then writes
+// (position, length) of its accepted clusters into an LDS list at the slots a wave prefix sum gives
+// it; the scoring rounds read that list 64 clusters at a time.
 // =========================================================================================
-template <int EBWT, int MODE>
-__global__ __launch_bounds__(SCANK_WG) __attribute__((amdgpu_waves_per_eu(LIME_SCAN_WAVES, LIME_SCAN_WAVES))) void k_scan(ScanArgs a)
-{
-    __shared__ ScanLds lds[SCANK_WG / 64];
-    __shared__ WgTables T;
-    const uint32_t lane = lane_id(), wave = (uint32_t)__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));   // wave-uniform: LDS bases stay scalar
-    ScanLds &L = lds[wave];
-    tables_init(T);                                        // the only workgroup barrier of the kernel
-    const uint32_t n_win = a.n_tiles, stride = gridDim.x * (SCANK_WG / 64);
-    uint32_t win = blockIdx.x * (SCANK_WG / 64) + wave;
-    if (win >= n_win) return;
-    UpdQueue qu; qu.qr = L.q_read; qu.qg = L.q_gen; qu.n = 0; qu.cap = QCAP_SCAN;
-    qu.async = true; qu.fr = L.f_read; qu.fg = L.f_gen; qu.fe = L.f_exp;
-    MedState ms = {{0u, 0u}, {0u, 0u}, {0u, 0u}};          // no chunk reserved yet
-    WinRegs regs;
-    window_load<EBWT>(regs, a, (uint64_t)win * WIN);
-    uint32_t acc_n = 0, acc_max = 0, acc_upd = 0;          // per-lane partial counters, reduced once at the end
-    uint32_t n_dup = 0;                                    // clusters waiting in the wave's dup store
-    const uint64_t lt = (1ull << lane) - 1ull;
-    PT_DECL
-    for (;;) {
-        PT_WAITVM PT(0)
-        const uint64_t lo = (uint64_t)win * WIN;
-        const uint64_t own_lim = a.n_own > lo ? (a.n_own - lo < WIN ? a.n_own - lo : (uint64_t)WIN) : 0ull;
-        const uint64_t lim = a.n_avail - lo;               // valid positions of the window + read-ahead: [0, lim)
-        // ---- stage the window in LDS (documents, raw ebwt bytes) and build the masks with lane =
-        // word: word j of the head mask (lcp < alpha) / read mask (da < n_reads) is the ballot of the
-        // comparison on register j, written into lane j; word WIN/64 holds the read-ahead ------------
-        uint64_t h = 0ull, r = 0ull, g = 0ull;
-        {
-            uint32_t hlo = 0, hhi = 0, rlo = 0, rhi = 0;
-            static_assert(PPL == 16 && WIN / 64 == 16, "mask words are written lane by lane below");
-#define LIME_WORD(J) { const uint64_t bh = __ballot(regs.lv[J] < a.alpha), br = __ballot(regs.dv[J] < a.n_reads); \
-                       hlo = write_lane<J>(hlo, (uint32_t)bh); hhi = write_lane<J>(hhi, (uint32_t)(bh >> 32)); \
-                       rlo = write_lane<J>(rlo, (uint32_t)br); rhi = write_lane<J>(rhi, (uint32_t)(br >> 32)); }
-            LIME_WORD(0) LIME_WORD(1) LIME_WORD(2) LIME_WORD(3) LIME_WORD(4) LIME_WORD(5) LIME_WORD(6) LIME_WORD(7)
-            LIME_WORD(8) LIME_WORD(9) LIME_WORD(10) LIME_WORD(11) LIME_WORD(12) LIME_WORD(13) LIME_WORD(14) LIME_WORD(15)
-#undef LIME_WORD
-            const uint64_t bh = __ballot(lane < HALO && regs.hl < a.alpha), br = __ballot(lane < HALO && regs.hd < a.n_reads);
-            hlo = write_lane<16>(hlo, (uint32_t)bh); rlo = write_lane<16>(rlo, (uint32_t)br);
-            h = ((uint64_t)hhi << 32) | hlo; r = ((uint64_t)rhi << 32) | rlo;
-            const uint64_t wl = 64ull * lane;                 // the end of the data: padding closes runs, is nobody's
-            const uint64_t v = lim >= wl + 64u ? ~0ull : (lim <= wl ? 0ull : ((1ull << (lim - wl)) - 1ull));
-            h |= ~v; r &= v; g = v & ~r;
-            if (lane == WIN / 64) { h &= 0xFFFFull; g &= 0xFFFFull; }
-            if (lane > WIN / 64) { h = 0ull; g = 0ull; }
-#pragma unroll
-            for (int j = 0; j < (int)PPL; ++j) L.da[64 * j + (int)lane] = regs.dv[j];
-            if (EBWT)
-#pragma unroll
-                for (int k = 0; k < (int)PPL / 4; ++k) reinterpret_cast<u32u *>(L.fl)[64 * k + (int)lane] = regs.bv[k];
-            if (lane < HALO) { L.da[WIN + lane] = regs.hd; if (EBWT) L.fl[WIN + lane] = (uint8_t)regs.hb; }
-            if (lane <= WIN / 64) {
-                *reinterpret_cast<u64a *>(&L.hb[8u * lane]) = h;
-                *reinterpret_cast<u64a *>(&L.rb[8u * lane]) = r;
-            }
-        }
-        // ---- the next window's loads go out now and land while this one is processed ----------
-        const uint32_t next = win + stride;
-        if (next < n_win && a.ablate != 8) window_load<EBWT>(regs, a, (uint64_t)next * WIN);
-        PT(1)
-        if (a.ablate != 1) {
-        const WinCtx c = window_context(h, r, g, own_lim);
-
-        // ---- window summary for the segment that is still open after the read-ahead ------------
-        {
-            const bool ow = lane < WIN / 64;
-            const uint64_t hw = __ballot(ow && c.h != 0ull), rw = __ballot(ow && c.r != 0ull), gw = __ballot(ow && c.g != 0ull);
-            TileSummary sm;
-            sm.first_head = NONE32; sm.last_head = NONE32;
-            uint32_t pre = (rw ? 1u : 0u) | (gw ? 2u : 0u), suf = 0u;       // no head: the whole window is "prefix"
-            if (hw) {                                                       // wave-uniform: scalar arithmetic
-                const uint32_t fw = (uint32_t)__builtin_ctzll(hw), lw = 63u - (uint32_t)__clzll((long long)hw);
-                const uint64_t hf0 = rl64(c.h, fw), hl0 = rl64(c.h, lw);
-                const uint32_t fb = (uint32_t)__builtin_ctzll(hf0), lb = 63u - (uint32_t)__clzll((long long)hl0);
-                sm.first_head = fw * 64u + fb; sm.last_head = lw * 64u + lb;
-                const uint64_t below = fb ? (~0ull >> (64u - fb)) : 0ull, from = ~0ull << lb;
-                const uint64_t wlow = (1ull << fw) - 1ull, whigh = (lw == 63u) ? 0ull : (~0ull << (lw + 1u));
-                pre = (((rw & wlow) || (rl64(c.r, fw) & below)) ? 1u : 0u) | (((gw & wlow) || (rl64(c.g, fw) & below)) ? 2u : 0u);
-                suf = (((rw & whigh) || (rl64(c.r, lw) & from)) ? 1u : 0u) | (((gw & whigh) || (rl64(c.g, lw) & from)) ? 2u : 0u);
-            }
-            if (lane == 0) { sm.pre = pre; sm.suf = suf; a.summ[win] = sm; }
-            // a run closed by padding instead of data while more data exists beyond the shard's
-            // halo: the last data head in sight is owned and nothing but padding follows it
-            if (!a.eof && lim < WPOS) {
-                const uint64_t wl = (uint64_t)lane * 64u;
-                const uint64_t dh = wl >= lim ? 0ull : (wl + 64u <= lim ? c.h : (c.h & ((1ull << (lim - wl)) - 1ull)));
-                const uint64_t dw = __ballot(dh != 0ull);
-                if (dw) {
-                    const uint32_t lw2 = 63u - (uint32_t)__clzll((long long)dw);
-                    const uint64_t hl2 = rl64(dh, lw2);
-                    const uint64_t sstar = (uint64_t)lw2 * 64u + 63u - (uint32_t)__clzll((long long)hl2);
-                    if (lane == 0 && sstar < own_lim) atomicOr(&a.stats->flags, LIME_FLAG_HALO);
-                }
-            }
-        }
-        PT(2)
-        if (a.ablate != 3) {
-        acc_n += (uint32_t)__popcll(c.ah);
-        if (MODE == 0) {
-            // ---- hand the accepted heads to lanes: lane t takes the t-th set bit of `ah` ------------
-            if (a.ablate != 4) {
-            const uint32_t cnt = (uint32_t)__popcll(c.ah);
-            uint32_t incl = cnt;
-            incl += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)incl, 0x111, 0xF, 0xF, false);
-            incl += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)incl, 0x112, 0xF, 0xF, false);
-            incl += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)incl, 0x114, 0xF, 0xF, false);
-            incl += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)incl, 0x118, 0xF, 0xF, false);
-            const uint32_t pre = incl - cnt, total = rl32(incl, NW - 1);
-            uint32_t pk[NW];                                   // clusters before each word (wave-uniform)
-#pragma unroll
-            for (int k = 1; k < (int)NW; ++k) pk[k] = rl32(pre, k);
-            if (lane < NW) { L.asw[lane] = c.ah; L.prew[lane] = pre; }         // looked up by word below
-            uint32_t nM = 0, nX = 0;
-            PT(3)
-            for (uint32_t base = 0; base < total; base += 64u) {
-                const uint32_t t = base + lane;
-                const bool on = t < total;
-                uint32_t w = 0;
-#pragma unroll
-                for (int k = 1; k < (int)NW; ++k) w += (uint32_t)(t >= pk[k]);
-                uint64_t x = L.asw[w];
-                uint32_t j = on ? t - L.prew[w] : 0u;
-                const uint32_t p = on ? 64u * w + select_bit(x, j) : 0u;
-                // cluster length: distance to the next head, from the staged head bytes
-                const uint32_t kb = p >> 3, sh = p & 7u;
-                const uint32_t hbits = (uint32_t)L.hb[kb] | ((uint32_t)L.hb[kb + 1u] << 8) | ((uint32_t)L.hb[kb + 2u] << 16);
-                const uint32_t near = (hbits >> (sh + 1u)) & 0xFFFFu;
-                uint32_t len = on ? (uint32_t)__builtin_ctz(near | 0x10000u) + 1u : 0u;    // 17: farther than 16
-                if (__ballot(len > SMALL_MAX)) {                      // rare: walk the head bytes to the end of the run
-                    if (len > SMALL_MAX) {
-                        uint32_t q = p + 17u, e = WPOS;               // an accepted cluster closes before WPOS
-                        while (q < WPOS) {
-                            const uint32_t hbq = (uint32_t)L.hb[q >> 3] >> (q & 7u);
-                            if (hbq) { e = q + (uint32_t)__builtin_ctz(hbq); break; }
-                            q = (q | 7u) + 1u;
-                        }
-                        len = e - p;
-                        if (len > MID_MAX) {                          // one workgroup per such cluster later
-                            const uint32_t k = atomicAdd(&a.stats->n_big, 1u);
-                            if (k < a.big_cap) { a.big[k].pStart = lo + p; a.big[k].len = len; }
-                        }
-                    }
-                    // SMALL_MAX+1 .. MID_MAX symbols: noted, scored after the hand-out (at most 61 per window)
-                    const bool cX = len > SMALL_MAX && len <= MID_MAX;
-                    const uint64_t mX = __ballot(cX);
-                    if (cX) L.listX[nX + (uint32_t)__popcll(mX & lt)] = p | (len << 16);
-                    nX += (uint32_t)__popcll(mX);
-                }
-                acc_max = len > acc_max ? len : acc_max;
-                const bool cM = on && len > 4u && len <= SMALL_MAX;
-                const uint64_t mM = __ballot(cM);
-                if (mM) {
-                    if (cM) L.listM[nM + (uint32_t)__popcll(mM & lt)] = (uint16_t)(p | ((len - 1u) << 12));
-                    nM += (uint32_t)__popcll(mM);
-                }
-                const bool sm4 = on && len <= 4u;
-                PT(4)
-                if (a.ablate != 10) acc_upd += score_small<EBWT>(L, T, qu, ms, n_dup, a, lo, sm4, sm4 ? p : 0u, sm4 ? len : 0u);
-                PT(5)
-            }
-            if (nM && a.ablate != 10 && a.ablate != 11) {
-#ifdef LIME_PHASE_TIMING
-                acc_upd += score_medium<EBWT>(L, T, qu, ms, n_dup, a, lo, nM, pt_m); ++pt_nwin;
-#else
-                acc_upd += score_medium<EBWT>(L, T, qu, ms, n_dup, a, lo, nM);
-#endif
-            }
-            // 17..64 symbols: the whole wave is one lane group on the staged window (such a cluster
-            // closes inside the window + read-ahead)
-#pragma unroll 1
-            for (uint32_t k = 0; k < nX; ++k) {
-                const uint32_t it = L.listX[k], p0 = it & 0xFFFFu, len0 = it >> 16;
-                const bool hv = lane < len0;
-                acc_upd += group_score<EBWT, 64>(a, T, qu, hv ? L.da[p0 + lane] : 0u, (EBWT && hv) ? L.fl[p0 + lane] : 0u, len0);
-            }
-            if (n_dup >= DUP_SLOTS / 2u) acc_upd += dup_flush<EBWT>(L, n_dup, a, T, qu);
-            PT(6)
-            }
-        } else {
-            // ---- count / emit: lane l walks the accepted heads among ITS 8 positions ---------------
-            const uint32_t w = (PPL * lane) >> 6, o = (PPL * lane) & 63u;
-            const uint64_t AHw = shfl64(c.ah, (int)w), Hw = shfl64(c.h, (int)w);
-            const uint32_t e_suf = __shfl(c.e_suf, (int)w);
-            uint32_t ahb = (uint32_t)(AHw >> o) & ((1u << PPL) - 1u);
-            const uint32_t my_n = (uint32_t)__popc(ahb);
-            const uint32_t x = wave_incl_scan(my_n);
-            uint32_t rank = x - my_n;
-            const uint32_t win_cnt = rl32(x, 63);
-            if (MODE == 1 && lane == 0) a.tile_cnt[win] = win_cnt;
-            while (__ballot(ahb != 0u)) {                         // longest record of the window
-                const bool act = ahb != 0u;
-                const uint32_t b = act ? (uint32_t)__builtin_ctz(ahb) : 0u;
-                ahb &= ahb - 1u;
-                const uint32_t bit = o + b, p = 64u * w + bit;
-                const uint64_t ha = (bit == 63u) ? 0ull : (Hw & (~0ull << (bit + 1u)));
-                const uint32_t e = ha ? 64u * w + (uint32_t)__builtin_ctzll(ha) : e_suf;
-                const uint32_t len = act ? e - p : 0u;
-                acc_max = len > acc_max ? len : acc_max;
-            }
-        }
-        }
-        }
-        if (next >= n_win) break;
-        if (a.ablate == 8) window_load<EBWT>(regs, a, (uint64_t)next * WIN);
-        win = next;
-    }
-    if (MODE == 0) {
-        if (n_dup) acc_upd += dup_flush<EBWT>(L, n_dup, a, T, qu);
-        do drain(qu, a); while (qu.n != 0u || __ballot(qu.f_pend != 0u));      // until every update has landed
-        med_fill(a, ms, 0u); med_fill(a, ms, 1u);
-    }
-#ifdef LIME_PHASE_TIMING
-    PT(7)
-    if (MODE == 0 && lane == 0 && wave == 0 && blockIdx.x % 181u == 0u)
-        printf("blk %u: wait %llu stage %llu ctx %llu prefix %llu enum %llu small %llu medium %llu tail %llu | med calls %u map %llu rows %llu emit %llu push %llu | drains %u cycles %llu\n", blockIdx.x,
-               (unsigned long long)pt_acc[0], (unsigned long long)pt_acc[1], (unsigned long long)pt_acc[2], (unsigned long long)pt_acc[3],
-               (unsigned long long)pt_acc[4], (unsigned long long)pt_acc[5], (unsigned long long)pt_acc[6], (unsigned long long)pt_acc[7],
-               pt_nwin, (unsigned long long)pt_m[0], (unsigned long long)pt_m[1], (unsigned long long)pt_m[2], (unsigned long long)pt_m[3], qu.n_drain, (unsigned long long)qu.t_drain);
-#endif
-    {
-        const uint32_t tn = wave_sum(acc_n), tm = wave_max(acc_max), tu = wave_sum(acc_upd);
-        if (lane == 0) {
-            if (tn) atomicAdd(&a.stats->n_clusters, (unsigned long long)tn);
-            if (tm) atomicMax(&a.stats->max_len, (unsigned long long)tm);
-            if (MODE == 0 && tu) atomicAdd(&a.stats->n_updates, (unsigned long long)tu);
-        }
-    }
-}
-
-// =========================================================================================
-// k_scan2: the scan with a CHUNK front end.  Lane l owns positions [16 l, 16 l + 16) of the window:
-// its head / read bits are 16-bit masks (cut out of the ballot-built mask words),
-// cluster acceptance inside a chunk is the carry-ripple trick on 16 bits (32-bit
-// arithmetic), the segment of a chunk's LAST head is decided with wave ballots over "chunk has a
-// head / a read / a genome" and one ds_bpermute, the read-ahead being one more chunk (wave-uniform).
-// Every lane then writes the (position, length) of its accepted clusters into an LDS list at the slots
-// a wave prefix sum gives it; the scoring rounds read that list.  Back end (scoring, table updates)
-// and MODE semantics as k_scan.
-// =========================================================================================
-struct alignas(16) ScanLds2 {
+struct alignas(16) ScanLds {
     uint32_t da[WPOS + SMALL_MAX];
     uint8_t fl[WPOS + SMALL_MAX];
     alignas(8) uint8_t hb[WPOS / 8 + 14];    // head / read bit of every staged position (byte k = positions 8k..8k+7)
@@ -1154,7 +836,9 @@ __device__ __forceinline__ Ctx16 chunk_context(uint32_t h, uint32_t r, uint32_t 
     const bool has_next = next_lane || H64 != 0u;
     c.e_suf = next_lane ? PPL * wn + (nx & 31u) : (H64 ? WIN + hfh : NONE32);
     const uint32_t acc_suf = (has_next && (suf_r | mid_r | n_r) && (suf_g | mid_g | n_g)) ? 1u : 0u;
-    // carry ripple on 16 bits (see window_context): bit-reversed, a head is the top of its segment
+    // "segment contains a read / a genome" gathered onto the segment's head bit by a carry ripple on 16
+    // bits: in bit-reversed order a head is the TOP of its segment, and adding the seeds (Y) to the "may
+    // receive from below" mask (Mr) ripples a carry through each segment up to its head
     const uint32_t Hr = __builtin_bitreverse32(h) >> 16, Mr = ~(Hr << 1) & 0xFFFFu;
     uint32_t Xr = __builtin_bitreverse32(r) >> 16, Y = (Xr << 1) & Mr;
     const uint32_t RH = (Xr | (((Mr + Y) ^ Mr) & Mr) | Y) & Hr;
@@ -1169,12 +853,12 @@ __device__ __forceinline__ Ctx16 chunk_context(uint32_t h, uint32_t r, uint32_t 
 }
 
 template <int EBWT, int MODE>
-__global__ __launch_bounds__(SCANK_WG) __attribute__((amdgpu_waves_per_eu(LIME_SCAN_WAVES, LIME_SCAN_WAVES))) void k_scan2(ScanArgs a)
+__global__ __launch_bounds__(SCANK_WG) __attribute__((amdgpu_waves_per_eu(LIME_SCAN_WAVES, LIME_SCAN_WAVES))) void k_scan(ScanArgs a)
 {
-    __shared__ ScanLds2 lds[SCANK_WG / 64];
+    __shared__ ScanLds lds[SCANK_WG / 64];
     __shared__ WgTables T;
     const uint32_t lane = lane_id(), wave = (uint32_t)__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));   // wave-uniform: LDS bases stay scalar
-    ScanLds2 &L = lds[wave];
+    ScanLds &L = lds[wave];
     tables_init(T);                                        // the only workgroup barrier of the kernel
     const uint32_t n_win = a.n_tiles, stride = gridDim.x * (SCANK_WG / 64);
     uint32_t win = blockIdx.x * (SCANK_WG / 64) + wave;
@@ -1240,6 +924,7 @@ __global__ __launch_bounds__(SCANK_WG) __attribute__((amdgpu_waves_per_eu(LIME_S
         const uint32_t next = win + stride;
         if (next < n_win) window_load<EBWT>(regs, a, (uint64_t)next * WIN);
 
+        if (a.ablate != 1) {                               // LIME_ABLATE: timing experiments, cut after a phase
         const Ctx16 c = chunk_context(hb, rb, gb, H64, R64, G64, own_lim);
         // ---- window summary for the segment that is still open after the read-ahead ------------
         {
@@ -1268,6 +953,7 @@ __global__ __launch_bounds__(SCANK_WG) __attribute__((amdgpu_waves_per_eu(LIME_S
                 }
             }
         }
+        if (a.ablate != 3) {
         // ---- every lane lists the accepted clusters of its chunk: slots from a wave prefix sum ---------
         const uint32_t cnt = (uint32_t)__popc(c.ah);
         const uint32_t incl = wave_incl_scan(cnt), total = rl32(incl, 63);
@@ -1288,6 +974,7 @@ __global__ __launch_bounds__(SCANK_WG) __attribute__((amdgpu_waves_per_eu(LIME_S
                 }
             }
             uint32_t nM = 0, nX = 0;
+            if (a.ablate != 4)
             for (uint32_t base = 0; base < total; base += 64u) {
                 const uint32_t t = base + lane;
                 const bool on = t < total;
@@ -1321,9 +1008,9 @@ __global__ __launch_bounds__(SCANK_WG) __attribute__((amdgpu_waves_per_eu(LIME_S
                     nM += (uint32_t)__popcll(mM);
                 }
                 const bool sm4 = on && len <= 4u;
-                acc_upd += score_small<EBWT>(L, T, qu, ms, n_dup, a, lo, sm4, sm4 ? p : 0u, sm4 ? len : 0u);
+                if (a.ablate != 10) acc_upd += score_small<EBWT>(L, T, qu, ms, n_dup, a, lo, sm4, sm4 ? p : 0u, sm4 ? len : 0u);
             }
-            if (nM) acc_upd += score_medium<EBWT>(L, T, qu, ms, n_dup, a, lo, nM);
+            if (nM && a.ablate != 10 && a.ablate != 11) acc_upd += score_medium<EBWT>(L, T, qu, ms, n_dup, a, lo, nM);
             // 17..64 symbols: the whole wave is one lane group on the staged window
 #pragma unroll 1
             for (uint32_t k = 0; k < nX; ++k) {
@@ -1345,6 +1032,8 @@ __global__ __launch_bounds__(SCANK_WG) __attribute__((amdgpu_waves_per_eu(LIME_S
                 const uint32_t e = hi ? p + 1u + (uint32_t)__builtin_ctz(hi) : c.e_suf;
                 acc_max = e - p > acc_max ? e - p : acc_max;
             }
+        }
+        }
         }
         if (next >= n_win) break;
         win = next;
@@ -1824,14 +1513,9 @@ template <typename K> static void launch_scan_kernel(K kernel, const ScanArgs &a
 void launch_tile(int ebwt, int mode, const ScanArgs &a, uint32_t max_blocks, hipStream_t st)
 {
     if (mode == 0) {
-#ifdef LIME_OLD_FRONT
         if (ebwt) launch_scan_kernel(k_scan<1, 0>, a, max_blocks, st);
         else      launch_scan_kernel(k_scan<0, 0>, a, max_blocks, st);
-#else
-        if (ebwt) launch_scan_kernel(k_scan2<1, 0>, a, max_blocks, st);
-        else      launch_scan_kernel(k_scan2<0, 0>, a, max_blocks, st);
-#endif
-    } else launch_scan_kernel(k_scan2<0, 1>, a, max_blocks, st);
+    } else launch_scan_kernel(k_scan<0, 1>, a, max_blocks, st);
 }
 
 void launch_emit(const ScanArgs &a, hipStream_t st)
