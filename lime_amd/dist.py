@@ -66,7 +66,9 @@ def combine_counters(n_clusters, max_len, device, group=None):
 
 
 def check_uint8_sum_wraps(device, group=None):
-    """Self-check that the backend's uint8 SUM wraps modulo 256 (200 + 100 -> 44 for 2 ranks)."""
+    """Self-check that the backend's uint8 SUM wraps modulo 256 (200 + 100 -> 44 for 2 ranks) in the
+    all-reduce; returns True if the reduce-scatter form passes the same check too (else the caller
+    falls back to allreduce_tables)."""
     import torch
     import torch.distributed as dist
     w = dist.get_world_size(group)
@@ -75,8 +77,14 @@ def check_uint8_sum_wraps(device, group=None):
     want = (200 * w) % 256
     if not bool((t == want).all()):
         raise RuntimeError(f"uint8 all-reduce does not wrap modulo 256: got {int(t[0])}, want {want}")
-    src = torch.full((64 * w,), 200, dtype=torch.uint8, device=device)
-    blk = torch.empty(64, dtype=torch.uint8, device=device)
-    reduce_scatter_tables(src, blk, group)
-    if not bool((blk == want).all()):
-        raise RuntimeError(f"uint8 reduce-scatter does not wrap modulo 256: got {int(blk[0])}, want {want}")
+    ok = torch.ones(1, dtype=torch.int32, device=device)
+    try:
+        src = torch.full((64 * w,), 200, dtype=torch.uint8, device=device)
+        blk = torch.empty(64, dtype=torch.uint8, device=device)
+        reduce_scatter_tables(src, blk, group)
+        if not bool((blk == want).all()):
+            ok.zero_()
+    except Exception:
+        ok.zero_()
+    dist.all_reduce(ok, op=dist.ReduceOp.MIN, group=group)      # every rank takes the same decision
+    return bool(ok.item())
