@@ -181,26 +181,37 @@ struct UpdQueue { uint32_t *qr, *qg; uint32_t n, cap;
     // and value it returned in registers.
     bool async = false;
     uint32_t *fr = nullptr, *fg = nullptr, *fe = nullptr;   // entry (read, genome | t) and the word value its CAS expected
-    uint32_t f_old[4], f_pend = 0;
+    uint32_t f_old[4], f_pend = 0;               // f_pend: bit j = slot j occupied, bit 4+j = its word was only LOADED so far
+    // dense tables: once 1 in 8 of the first tries (which expect an empty word) has lost, new entries first load
+    // their word (a load is much cheaper than a lost compare-and-swap) and try with what they saw one drain later
+    uint32_t f_first = 0, f_lost = 0; bool load_first = false;
 #ifdef LIME_PHASE_TIMING
     uint64_t t_drain = 0; uint32_t n_drain = 0;
 #endif
 };
 
 // Split-phase drain: (1) settle the slots issued last time: a CAS that found the expected word is
-// done, one that lost keeps its slot with the word it saw; (2) free slots take entries from the
-// queue's tail; (3) every occupied slot issues its CAS.  Entries that found no free slot stay
-// queued (q.n > 0 afterwards): callers loop while they need more room.
+// done, one that lost keeps its slot with the word it saw, a slot that only loaded its word now knows
+// what to expect; (2) free slots take entries from the queue's tail; (3) every occupied slot issues
+// its CAS (or, for a new entry in load-first mode, the load of its word).  Entries that found no free
+// slot stay queued (q.n > 0 afterwards): callers loop while they need more room.
 __device__ __forceinline__ void drain_async(UpdQueue &q, const ScanArgs &a)
 {
     const uint32_t lane = lane_id();
     const uint64_t lt = (1ull << lane) - 1ull;
 #pragma unroll
-    for (int j = 0; j < 4; ++j)
-        if ((q.f_pend >> j) & 1u) {
-            if (q.f_old[j] == q.fe[64u * (uint32_t)j + lane]) q.f_pend &= ~(1u << j);
-            else q.fe[64u * (uint32_t)j + lane] = q.f_old[j];
+    for (int j = 0; j < 4; ++j) {
+        const bool pend = (q.f_pend >> j) & 1u, fresh = (q.f_pend >> (4 + j)) & 1u;
+        const uint32_t e = pend ? q.fe[64u * (uint32_t)j + lane] : 0u;
+        const bool tried = pend && !fresh, lost = tried && q.f_old[j] != e;
+        if (!q.load_first) {                               // statistics of the "expect an empty word" first tries
+            const uint64_t mf = __ballot(tried && e == 0u);
+            q.f_first += (uint32_t)__popcll(mf); q.f_lost += (uint32_t)__popcll(mf & __ballot(lost));
         }
+        if (tried && !lost) q.f_pend &= ~(1u << j);
+        if (fresh || lost) { q.fe[64u * (uint32_t)j + lane] = q.f_old[j]; q.f_pend &= ~(16u << j); }
+    }
+    if (!q.load_first && q.f_first >= 128u && 8u * q.f_lost >= q.f_first) q.load_first = true;
     uint32_t n = q.n;
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
@@ -210,7 +221,8 @@ __device__ __forceinline__ void drain_async(UpdQueue &q, const ScanArgs &a)
         if (fre && r < n) {
             const uint32_t k = n - 1u - r;
             q.fr[64u * (uint32_t)j + lane] = q.qr[k]; q.fg[64u * (uint32_t)j + lane] = q.qg[k];
-            q.fe[64u * (uint32_t)j + lane] = 0u; q.f_pend |= 1u << j;
+            q.fe[64u * (uint32_t)j + lane] = 0u;
+            q.f_pend |= (q.load_first ? 17u : 1u) << j;
         }
         n -= c < n ? c : n;
     }
@@ -221,9 +233,14 @@ __device__ __forceinline__ void drain_async(UpdQueue &q, const ScanArgs &a)
         if ((q.f_pend >> j) & 1u) {
             const uint32_t gt = q.fg[64u * (uint32_t)j + lane];
             const uint64_t cell = (uint64_t)q.fr[64u * (uint32_t)j + lane] * a.n_refs + (gt & ((1u << T_SHIFT) - 1u));
-            const uint32_t sh = (uint32_t)(cell & 3ull) * 8u, e = q.fe[64u * (uint32_t)j + lane];
-            const uint32_t b = ((e >> sh) + (gt >> T_SHIFT)) & 255u;
-            q.f_old[j] = atomicCAS(reinterpret_cast<uint32_t *>(a.sim + (cell & ~3ull)), e, (e & ~(255u << sh)) | (b << sh));
+            uint32_t *w = reinterpret_cast<uint32_t *>(a.sim + (cell & ~3ull));
+            if ((q.f_pend >> (4 + j)) & 1u) {
+                q.f_old[j] = __hip_atomic_load(w, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // device-coherent: not a stale L2 line
+            } else {
+                const uint32_t sh = (uint32_t)(cell & 3ull) * 8u, e = q.fe[64u * (uint32_t)j + lane];
+                const uint32_t b = ((e >> sh) + (gt >> T_SHIFT)) & 255u;
+                q.f_old[j] = atomicCAS(w, e, (e & ~(255u << sh)) | (b << sh));
+            }
         }
 }
 
