@@ -182,7 +182,7 @@ struct UpdQueue { uint32_t *qr, *qg; uint32_t n, cap;
     bool async = false;
     uint32_t *fr = nullptr, *fg = nullptr, *fe = nullptr;   // entry (read, genome | t) and the word value its CAS expected
     uint32_t f_old[4], f_pend = 0;               // f_pend: bit j = slot j occupied, bit 4+j = its word was only LOADED so far
-    // dense tables: once 1 in 8 of the first tries (which expect an empty word) has lost, new entries first load
+    // dense tables: once 1 in 4 of the first tries (which expect an empty word) has lost, new entries first load
     // their word (a load is much cheaper than a lost compare-and-swap) and try with what they saw one drain later
     uint32_t f_first = 0, f_lost = 0; bool load_first = false;
 #ifdef LIME_PHASE_TIMING
@@ -204,14 +204,14 @@ __device__ __forceinline__ void drain_async(UpdQueue &q, const ScanArgs &a)
         const bool pend = (q.f_pend >> j) & 1u, fresh = (q.f_pend >> (4 + j)) & 1u;
         const uint32_t e = pend ? q.fe[64u * (uint32_t)j + lane] : 0u;
         const bool tried = pend && !fresh, lost = tried && q.f_old[j] != e;
-        if (!q.load_first) {                               // statistics of the "expect an empty word" first tries
+        if (j == 0 && !q.load_first) {                     // statistics of the "expect an empty word" first tries (slot 0 as a sample)
             const uint64_t mf = __ballot(tried && e == 0u);
             q.f_first += (uint32_t)__popcll(mf); q.f_lost += (uint32_t)__popcll(mf & __ballot(lost));
         }
         if (tried && !lost) q.f_pend &= ~(1u << j);
         if (fresh || lost) { q.fe[64u * (uint32_t)j + lane] = q.f_old[j]; q.f_pend &= ~(16u << j); }
     }
-    if (!q.load_first && q.f_first >= 128u && 8u * q.f_lost >= q.f_first) q.load_first = true;
+    if (!q.load_first && q.f_first >= 64u && 4u * q.f_lost >= q.f_first) q.load_first = true;
     uint32_t n = q.n;
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
