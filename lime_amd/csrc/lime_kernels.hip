@@ -888,7 +888,9 @@ __global__ __launch_bounds__(SCANK_WG) __attribute__((amdgpu_waves_per_eu(LIME_S
     uint32_t acc_n = 0, acc_max = 0, acc_upd = 0;          // per-lane partial counters, reduced once at the end
     uint32_t n_dup = 0;                                    // clusters waiting in the wave's dup store
     const uint64_t lt = (1ull << lane) - 1ull;
+    PT_DECL
     for (;;) {
+        PT_WAITVM PT(0)
         const uint64_t lo = (uint64_t)win * WIN;
         const uint32_t own_lim = (uint32_t)(a.n_own > lo ? (a.n_own - lo < WIN ? a.n_own - lo : (uint64_t)WIN) : 0ull);
         const uint64_t lim64 = a.n_avail - lo;             // valid positions of the window + read-ahead: [0, lim)
@@ -941,6 +943,7 @@ __global__ __launch_bounds__(SCANK_WG) __attribute__((amdgpu_waves_per_eu(LIME_S
         const uint32_t next = win + stride;
         if (next < n_win) window_load<EBWT>(regs, a, (uint64_t)next * WIN);
 
+        PT(1)
         if (a.ablate != 1) {                               // LIME_ABLATE: timing experiments, cut after a phase
         const Ctx16 c = chunk_context(hb, rb, gb, H64, R64, G64, own_lim);
         // ---- window summary for the segment that is still open after the read-ahead ------------
@@ -970,6 +973,7 @@ __global__ __launch_bounds__(SCANK_WG) __attribute__((amdgpu_waves_per_eu(LIME_S
                 }
             }
         }
+        PT(2)
         if (a.ablate != 3) {
         // ---- every lane lists the accepted clusters of its chunk: slots from a wave prefix sum ---------
         const uint32_t cnt = (uint32_t)__popc(c.ah);
@@ -991,6 +995,7 @@ __global__ __launch_bounds__(SCANK_WG) __attribute__((amdgpu_waves_per_eu(LIME_S
                 }
             }
             uint32_t nM = 0, nX = 0;
+            PT(3)
             if (a.ablate != 4)
             for (uint32_t base = 0; base < total; base += 64u) {
                 const uint32_t t = base + lane;
@@ -1025,9 +1030,17 @@ __global__ __launch_bounds__(SCANK_WG) __attribute__((amdgpu_waves_per_eu(LIME_S
                     nM += (uint32_t)__popcll(mM);
                 }
                 const bool sm4 = on && len <= 4u;
+                PT(4)
                 if (a.ablate != 10) acc_upd += score_small<EBWT>(L, T, qu, ms, n_dup, a, lo, sm4, sm4 ? p : 0u, sm4 ? len : 0u);
+                PT(5)
             }
-            if (nM && a.ablate != 10 && a.ablate != 11) acc_upd += score_medium<EBWT>(L, T, qu, ms, n_dup, a, lo, nM);
+            if (nM && a.ablate != 10 && a.ablate != 11) {
+#ifdef LIME_PHASE_TIMING
+                acc_upd += score_medium<EBWT>(L, T, qu, ms, n_dup, a, lo, nM, pt_m); ++pt_nwin;
+#else
+                acc_upd += score_medium<EBWT>(L, T, qu, ms, n_dup, a, lo, nM);
+#endif
+            }
             // 17..64 symbols: the whole wave is one lane group on the staged window
 #pragma unroll 1
             for (uint32_t k = 0; k < nX; ++k) {
@@ -1036,6 +1049,7 @@ __global__ __launch_bounds__(SCANK_WG) __attribute__((amdgpu_waves_per_eu(LIME_S
                 acc_upd += group_score<EBWT, 64>(a, T, qu, hvv ? L.da[p0 + lane] : 0u, (EBWT && hvv) ? L.fl[p0 + lane] : 0u, len0);
             }
             if (n_dup >= DUP_SLOTS / 2u) acc_upd += dup_flush<EBWT>(L, n_dup, a, T, qu);
+            PT(6)
         } else {
             // ---- count: records of the window, its masks for k_emit, the longest record -----------
             if (lane == 0) a.tile_cnt[win] = total;
@@ -1060,6 +1074,13 @@ __global__ __launch_bounds__(SCANK_WG) __attribute__((amdgpu_waves_per_eu(LIME_S
         do drain(qu, a); while (qu.n != 0u || __ballot(qu.f_pend != 0u));      // until every update has landed
         med_fill(a, ms, 0u); med_fill(a, ms, 1u);
     }
+#ifdef LIME_PHASE_TIMING
+    PT(7)
+    if (MODE == 0 && lane == 0 && wave == 0 && blockIdx.x % 181u == 0u)
+        printf("blk %u: wait %llu stage %llu ctx %llu list %llu book %llu small %llu medium %llu tail %llu\n", blockIdx.x,
+               (unsigned long long)pt_acc[0], (unsigned long long)pt_acc[1], (unsigned long long)pt_acc[2], (unsigned long long)pt_acc[3],
+               (unsigned long long)pt_acc[4], (unsigned long long)pt_acc[5], (unsigned long long)pt_acc[6], (unsigned long long)pt_acc[7]);
+#endif
     {
         const uint32_t tn = wave_sum(acc_n), tm = wave_max(acc_max), tu = wave_sum(acc_upd);
         if (lane == 0) {
