@@ -681,10 +681,10 @@ __device__ __forceinline__ uint32_t score_medium(LDS &L, const WgTables &T, UpdQ
                 // the cluster are read too (the arrays are padded) and masked afterwards.
                 uint32_t dupb = 0, cb16 = EBWT ? 0u : 0xFFFFu;
 #pragma unroll
-                for (int k0 = 1; k0 < (int)SMALL_MAX; k0 += 4) {
-                    if (__ballot(rem >= (uint32_t)k0)) {              // wave-uniform
+                for (int k0 = 1; k0 < (int)SMALL_MAX; k0 += 8) {      // positions 1..8 always (one batch of loads), 9..15 if any row needs them
+                    if (k0 == 1 || __ballot(rem >= (uint32_t)k0)) {   // wave-uniform
 #pragma unroll
-                        for (int k = k0; k < k0 + 4 && k < (int)SMALL_MAX; ++k) {
+                        for (int k = k0; k < k0 + 8 && k < (int)SMALL_MAX; ++k) {
                             dupb |= (uint32_t)(L.da[q + (uint32_t)k] == di) << k;
                             if (EBWT) cb16 |= ((ci >> T.symidx[L.fl[q + (uint32_t)k]]) & 1u) << k;
                         }
@@ -702,12 +702,17 @@ __device__ __forceinline__ uint32_t score_medium(LDS &L, const WgTables &T, UpdQ
                         const uint32_t incl = wave_incl_scan(take), tot = rl32(incl, 63);
                         while (qu.n + tot > qu.cap) drain(qu, a);
                         uint32_t slot = qu.n + incl - take, bad = 0;
+                        uint32_t djs[4];                             // the partners' documents: four loads issued together
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) {
+                            const uint32_t k = hits ? (uint32_t)__builtin_ctz(hits) : 0u;
+                            hits &= hits - 1u;
+                            djs[e] = L.da[q + k];
+                        }
 #pragma unroll
                         for (int e = 0; e < 4; ++e)
                             if ((uint32_t)e < take) {
-                                const uint32_t k = (uint32_t)__builtin_ctz(hits);
-                                hits &= hits - 1u;
-                                const uint32_t dj = L.da[q + k];
+                                const uint32_t dj = djs[e];
                                 uint32_t gd = (ri ? dj : di) - a.n_reads;
                                 if (gd >= a.n_refs) { bad = 1u; gd = 0u; }   // reported below; the result is void anyway
                                 qu.qr[slot] = ri ? di : dj; qu.qg[slot] = gd | (1u << T_SHIFT);
