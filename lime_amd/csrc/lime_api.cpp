@@ -49,7 +49,6 @@ struct lime_ctx {
     // cluster lists
     lime_cluster_t *d_small = nullptr; uint32_t small_cap = 0;
     lime_cluster_t *d_big = nullptr; uint32_t big_cap = 0;
-    uint64_t *d_med = nullptr; uint32_t med_cap = 0;
     lime_cluster_t *d_out = nullptr; size_t out_cap = 0;
     uint32_t *d_big_scratch = nullptr;
     uint32_t max_blocks = 0;                // persistent grid of the scan kernel; 0 = as many workgroups as fit the device (LIME_MAX_BLOCKS)
@@ -105,7 +104,7 @@ extern "C" void lime_shutdown(lime_ctx *c)
     for (hipEvent_t e : c->ev) (void)hipEventDestroy(e);
     (void)hipFree(c->d_stats); (void)hipFree(c->d_total); (void)hipFree(c->d_summ);
     (void)hipFree(c->d_tile_cnt); (void)hipFree(c->d_tile_off); (void)hipFree(c->d_cross); (void)hipFree(c->d_wmask);
-    (void)hipFree(c->d_small); (void)hipFree(c->d_big); (void)hipFree(c->d_med); (void)hipFree(c->d_out);
+    (void)hipFree(c->d_small); (void)hipFree(c->d_big); (void)hipFree(c->d_out);
     (void)hipFree(c->d_big_scratch);
     delete c;
 }
@@ -137,13 +136,6 @@ static int ensure_scratch(lime_ctx *c, uint64_t n_avail, bool detect, bool score
         if (want_big > 0xFFFFFFF0ull) return fail(LIME_ERR_ARG, "array too long for one shard: %llu", (unsigned long long)n_avail);
         if (want_small > c->small_cap) { HIP_TRY(hipStreamSynchronize(st)); if ((rc = regrow(c->d_small, want_small))) return rc; c->small_cap = (uint32_t)want_small; }
         if (want_big > c->big_cap) { HIP_TRY(hipStreamSynchronize(st)); if ((rc = regrow(c->d_big, want_big))) return rc; c->big_cap = (uint32_t)want_big; }
-        // every cluster the scan does not score itself (5..16 symbols, or a repeated document): at most one
-        // per two positions, plus the chunk each wave keeps reserved
-        const uint64_t want_med = n_avail / 2u + 1048576u;
-        if (want_med > c->med_cap) {
-            if (want_med > 0xFFFFFFF0ull) return fail(LIME_ERR_ARG, "array too long for one shard: %llu", (unsigned long long)n_avail);
-            HIP_TRY(hipStreamSynchronize(st)); if ((rc = regrow(c->d_med, 2u * (size_t)want_med))) return rc; c->med_cap = (uint32_t)want_med;
-        }
         if (!c->d_big_scratch) {
             const size_t words = (size_t)BIG_GRID * BIG_SCRATCH_WORDS;
             HIP_TRY(hipMalloc(&c->d_big_scratch, words * sizeof(uint32_t)));
@@ -182,7 +174,6 @@ static ScanArgs base_args(lime_ctx *c, const uint32_t *lcp, const uint32_t *da, 
     a.n_tiles = (uint32_t)((n_avail + WIN - 1) / WIN);
     a.sim = sim; a.summ = c->d_summ; a.stats = c->d_stats;
     a.small = c->d_small; a.cross_cap = c->small_cap; a.big = c->d_big; a.big_cap = c->big_cap;
-    a.med = c->d_med; a.med_cap = c->med_cap;
     a.tile_cnt = c->d_tile_cnt; a.tile_off = c->d_tile_off; a.cross = c->d_cross; a.out = c->d_out;
     a.wmask = c->d_wmask;
     a.ablate = c->ablate;
@@ -242,12 +233,11 @@ static int fused_dev_impl(lime_ctx *c, const uint32_t *d_lcp, const uint32_t *d_
     if (misaligned(d_lcp, 16) || misaligned(d_da, 16) || misaligned(d_ebwt, 8) || misaligned(d_sim, 4))
         return fail(LIME_ERR_ARG, "lime_fused_dev: device arrays must be 16-byte aligned (ebwt: 8, sim: 4)");
     if (!n_reads || !n_refs) return fail(LIME_ERR_ARG, "lime_fused_dev: n_reads and n_refs must be > 0");
-    if (n_refs >= (1u << 27) || (uint64_t)n_reads + n_refs > 0xFFFFFFF0ull)
-        return fail(LIME_ERR_ARG, "lime_fused_dev: n_refs must be < 2^27 and n_reads + n_refs <= 2^32 - 16");
+    if (n_refs >= MAX_REFS || (uint64_t)n_reads + n_refs > 0xFFFFFFF0ull)
+        return fail(LIME_ERR_ARG, "lime_fused_dev: n_refs must be < 2^%u and n_reads + n_refs <= 2^32 - 16", T_SHIFT);
     if ((rc = ensure_scratch(c, n_avail, false, true, st))) return rc;
     if (keep_stats) {
         HIP_TRY(hipMemsetAsync(&c->d_stats->n_cross, 0, 2 * sizeof(uint32_t), st));      // n_cross, n_big
-        HIP_TRY(hipMemsetAsync(&c->d_stats->n_med[0], 0, 2 * sizeof(uint32_t), st));
     } else {
         HIP_TRY(hipMemsetAsync(c->d_stats, 0, sizeof(DevStats), st));
     }
@@ -259,7 +249,6 @@ static int fused_dev_impl(lime_ctx *c, const uint32_t *d_lcp, const uint32_t *d_
     launch_tile(ebwt, 0, a, c->max_blocks, st);
     if ((rc = timing_mark(c, st))) return rc;
     launch_resolve(0, a, st);
-    launch_score_med(ebwt, a, 256, st);
     launch_score_big(ebwt, a, c->d_big_scratch, st);
     HIP_TRY(hipGetLastError());
     return LIME_OK;
@@ -339,8 +328,8 @@ extern "C" int lime_score_dev(lime_ctx *c, const uint32_t *d_da, const uint8_t *
     if (!d_sim || (n && !d_da) || (n_clusters && !d_clusters)) return fail(LIME_ERR_ARG, "lime_score_dev: NULL array");
     if (misaligned(d_sim, 4)) return fail(LIME_ERR_ARG, "lime_score_dev: d_sim must be 4-byte aligned");
     if (!n_reads || !n_refs) return fail(LIME_ERR_ARG, "lime_score_dev: n_reads and n_refs must be > 0");
-    if (n_refs >= (1u << 27) || (uint64_t)n_reads + n_refs > 0xFFFFFFF0ull)
-        return fail(LIME_ERR_ARG, "lime_score_dev: n_refs must be < 2^27 and n_reads + n_refs <= 2^32 - 16");
+    if (n_refs >= MAX_REFS || (uint64_t)n_reads + n_refs > 0xFFFFFFF0ull)
+        return fail(LIME_ERR_ARG, "lime_score_dev: n_refs must be < 2^%u and n_reads + n_refs <= 2^32 - 16", T_SHIFT);
     if ((rc = ensure_scratch(c, n, false, true, st))) return rc;
     // every listed cluster longer than the in-tile limit lands in the big list
     if (n_clusters + 16 > c->big_cap) {

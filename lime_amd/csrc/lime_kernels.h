@@ -16,6 +16,8 @@ constexpr int SCAN_WG = 256;                 // 4 independent waves per workgrou
 constexpr int WGSZ = 512;                    // workgroup of the helper kernels (big clusters, choose, synth)
 constexpr uint32_t SMALL_MAX = 16;           // longest cluster scored inside a window
 constexpr uint32_t NONE32 = 0xFFFFFFFFu;
+constexpr uint32_t T_SHIFT = 25;             // update-queue entry: genome | t << T_SHIFT
+constexpr uint32_t MAX_REFS = 1u << T_SHIFT; // so n_refs must stay below this
 constexpr uint32_t HT_BITS = 17;             // >= 2 x LIME_MAX_CLUSTER slots: the table never fills
 constexpr uint32_t HT_SIZE = 1u << HT_BITS;
 constexpr uint32_t HT_EMPTY = 0xFFFFFFFFu;
@@ -45,7 +47,6 @@ struct ScanArgs {
     DevStats *stats;
     lime_cluster_t *small; uint32_t cross_cap;   // tile-crossing clusters <= SMALL_MAX
     lime_cluster_t *big; uint32_t big_cap;       // clusters > SMALL_MAX
-    uint64_t *med; uint32_t med_cap;             // 2 lists of med_cap records for k_score_med: pStart | (len-1) << 48
     uint32_t *tile_cnt; uint64_t *tile_off; CrossRec *cross; lime_cluster_t *out;   // detect only
     WinMasks *wmask;                             // detect only: count pass -> emit pass
     int ablate;                                  // timing experiments only (LIME_ABLATE): 0 = full kernel
@@ -58,7 +59,6 @@ void launch_scan_tiles(const uint32_t *cnt, uint64_t *off, uint32_t n, unsigned 
 void launch_score_list(int ebwt, const ScanArgs &a, const lime_cluster_t *list, uint64_t count, uint32_t blocks, hipStream_t st);
 void launch_gather_pairs(const uint8_t *sim, uint32_t n_reads, uint32_t n_refs, const uint64_t *row_off,
                          lime_pair_t *pairs, hipStream_t st);
-void launch_score_med(int ebwt, const ScanArgs &a, uint32_t blocks, hipStream_t st);
 void launch_score_big(int ebwt, const ScanArgs &a, uint32_t *scratch, hipStream_t st);
 void launch_choose(const uint8_t *sim, uint32_t n_reads, uint32_t n_refs, uint8_t *row_max,
                    uint32_t *row_nnz, hipStream_t st);

@@ -27,10 +27,10 @@ constexpr uint32_t F_SYM = 0x0F;
 constexpr uint32_t F_READ = 0x20;
 constexpr uint32_t F_GEN = 0x40;
 
-constexpr uint32_t MID_MAX = 64;      // clusters of SMALL_MAX+1 .. MID_MAX symbols: one 64-lane group each (k_score_med)
+constexpr uint32_t MID_MAX = 64;      // clusters of SMALL_MAX+1 .. MID_MAX symbols: scored by the scan as one 64-lane group each
 constexpr uint32_t QCAP = 320;        // pending table updates per wave (a batch of 64 small clusters adds <= 256)
-constexpr uint32_t MED_CHUNK = 8;     // slots of the repeated-document list a wave reserves at a time
-constexpr uint32_t T_SHIFT = 27;      // queue entry: genome | t << 27 (t <= SMALL_MAX < 32)
+// queue entry: genome | t << T_SHIFT (lime_kernels.h): 7 bits of t; a cluster scored in the scan has <= MID_MAX symbols, so t <= MID_MAX / 2
+static_assert(MID_MAX / 2u < (1u << (32u - T_SHIFT)), "the queue's t field must hold the largest in-scan pair score");
 constexpr uint32_t CAP_A = 256;       // clusters (2..SMALL_MAX symbols) a window can own
 constexpr uint32_t CAP_D = 256;       // of those, clusters with a repeated document (general routine)
 
@@ -56,6 +56,14 @@ struct alignas(16) WaveLds {
     uint16_t listA[CAP_A], listD[CAP_D];   // entry: start | (len-1) << 12
     uint32_t q_read[QCAP], q_gen[QCAP];
 };
+
+// timing experiments (tools/quick.sh): a build with -DLIME_ABLATE_BUILD cuts the scan after phase k when the
+// environment says LIME_ABLATE=k (results invalid); the release library has no such switch
+#ifdef LIME_ABLATE_BUILD
+#define ABL(k) (a.ablate == (k))
+#else
+#define ABL(k) false
+#endif
 
 #ifdef LIME_PHASE_TIMING     // debug build: per-wave cycle counts of the scan's phases, printed by a few waves
 #define PT_DECL uint64_t pt_t = __builtin_readcyclecounter(), pt_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0}, pt_m[4] = {0, 0, 0, 0}; uint32_t pt_nwin = 0;
@@ -227,7 +235,7 @@ __device__ __forceinline__ void drain_async(UpdQueue &q, const ScanArgs &a)
         n -= c < n ? c : n;
     }
     q.n = n;
-    if (a.ablate == 5) { q.f_pend = 0; return; }
+    if (ABL(5)) { q.f_pend = 0; return; }
 #pragma unroll
     for (int j = 0; j < 4; ++j)
         if ((q.f_pend >> j) & 1u) {
@@ -252,7 +260,7 @@ __device__ __forceinline__ void drain(UpdQueue &q, const ScanArgs &a)
 #endif
     // four queue entries per lane and round: their compare-and-swaps are issued together (first
     // try: word still zero, tables are sparse) and only the ones that lost are tried again
-    if (a.ablate != 5)
+    if (!ABL(5))
         for (uint32_t k0 = 0; k0 < q.n; k0 += 256u) {
             uint32_t *w[4], sh[4], t[4], expect[4], pend = 0;
 #pragma unroll
@@ -303,44 +311,6 @@ __device__ __forceinline__ uint32_t emit(UpdQueue &q, const ScanArgs &a, bool on
     }
     q.n += (uint32_t)__popcll(m);
     return on ? 1u : 0u;
-}
-
-// ---- the scan's list of clusters it does not score itself (5..SMALL_MAX symbols, or a repeated
-// document): packed records pStart | (len-1) << 48.  Slots come from a chunk the wave reserved
-// with ONE atomic (a shared counter bumped per cluster would serialise the grid on one address);
-// the unused tail of a chunk is filled with empty (zero) records.
-struct MedState { uint32_t base[2], used[2], cap[2]; };   // per list: the wave's reserved chunk, slots used, chunk size
-
-__device__ __forceinline__ void med_fill(const ScanArgs &a, const MedState &ms, uint32_t which)
-{
-    for (uint32_t i = ms.used[which] + lane_id(); i < ms.cap[which]; i += 64u)
-        if (ms.base[which] + i < a.med_cap) a.med[(size_t)which * a.med_cap + ms.base[which] + i] = 0ull;
-}
-
-__device__ __forceinline__ void med_push1(const ScanArgs &a, MedState &ms, uint32_t which, bool on, uint64_t rec)
-{
-    const uint64_t m = __ballot(on);
-    if (m == 0ull) return;
-    const uint32_t cnt = (uint32_t)__popcll(m);
-    if (ms.used[which] + cnt > ms.cap[which]) {
-        med_fill(a, ms, which);
-        const uint32_t want = cnt > MED_CHUNK ? cnt : MED_CHUNK;
-        uint32_t b = 0;
-        if (lane_id() == 0) b = atomicAdd(&a.stats->n_med[which], want);
-        ms.base[which] = __builtin_amdgcn_readfirstlane(b); ms.used[which] = 0; ms.cap[which] = want;
-    }
-    if (on) {
-        const uint32_t slot = ms.base[which] + ms.used[which] + (uint32_t)__popcll(m & ((1ull << lane_id()) - 1ull));
-        if (slot < a.med_cap) a.med[(size_t)which * a.med_cap + slot] = rec;
-        else atomicOr(&a.stats->flags, LIME_FLAG_OVERFLOW);
-    }
-    ms.used[which] += cnt;
-}
-
-// clusters with a repeated document: list 1, record pStart | (len-1) << 48   (len in 2..SMALL_MAX)
-__device__ __forceinline__ void med_push(const ScanArgs &a, MedState &ms, bool on, uint64_t pos, uint32_t len)
-{
-    med_push1(a, ms, 1u, on, pos | ((uint64_t)(len - 1u) << 48));
 }
 
 // ---- general score of short clusters by lane groups ------------------------------------------
@@ -399,24 +369,8 @@ __device__ __forceinline__ uint32_t group_score(const ScanArgs &a, const WgTable
 
 // ---- clusters with a repeated document, kept by the wave that found them: copies of up to
 // DUP_SLOTS clusters (<= SMALL_MAX elements each) in LDS, scored four at a time by 16-lane groups
-// when enough have gathered (and at the end).  A batch that does not fit goes to global list 1
-// for k_score_med instead.
-template <int EBWT, typename LDS>
-__device__ __forceinline__ void dup_push(LDS &L, uint32_t &n_dup, const ScanArgs &a, MedState &ms,
-                                         bool on, uint64_t lo, uint32_t p, uint32_t len)
-{
-    const uint64_t m = __ballot(on);
-    if (m == 0ull) return;
-    const uint32_t cnt = (uint32_t)__popcll(m);
-    if (n_dup + cnt > DUP_SLOTS) { med_push(a, ms, on, lo + p, len); return; }
-    if (on) {
-        const uint32_t slot = n_dup + (uint32_t)__popcll(m & ((1ull << lane_id()) - 1ull));
-        for (uint32_t k = 0; k < len; ++k) { L.g_doc[slot][k] = L.da[p + k]; if (EBWT) L.g_sym[slot][k] = L.fl[p + k]; }
-        L.g_len[slot] = (uint8_t)len;
-    }
-    n_dup += cnt;
-}
-
+// when enough have gathered (and at the end).  A full store is scored on the spot, so no cluster
+// ever leaves the wave.
 template <int EBWT, typename LDS>
 __device__ __forceinline__ uint32_t dup_flush(LDS &L, uint32_t &n_dup, const ScanArgs &a, const WgTables &T, UpdQueue &qu)
 {
@@ -430,6 +384,30 @@ __device__ __forceinline__ uint32_t dup_flush(LDS &L, uint32_t &n_dup, const Sca
         nupd += group_score<EBWT, 16>(a, T, qu, L.g_doc[cc][sub], EBWT ? L.g_sym[cc][sub] : 0u, len);
     }
     n_dup = 0;
+    return nupd;
+}
+
+// lanes with `on` hand over the cluster staged at L.da / L.fl[p .. p+len); returns the table updates of
+// the flushes it had to make (per lane, like the scoring routines)
+template <int EBWT, typename LDS>
+__device__ __forceinline__ uint32_t dup_push(LDS &L, uint32_t &n_dup, const ScanArgs &a, const WgTables &T, UpdQueue &qu,
+                                             bool on, uint32_t p, uint32_t len)
+{
+    uint64_t m = __ballot(on);
+    uint32_t nupd = 0;
+    while (m) {                                            // wave-uniform; one round unless the store fills up
+        if (n_dup == DUP_SLOTS) nupd += dup_flush<EBWT>(L, n_dup, a, T, qu);
+        const uint32_t rank = (uint32_t)__popcll(m & ((1ull << lane_id()) - 1ull));
+        const bool take = on && rank < DUP_SLOTS - n_dup;
+        if (take) {
+            const uint32_t slot = n_dup + rank;
+            for (uint32_t k = 0; k < len; ++k) { L.g_doc[slot][k] = L.da[p + k]; if (EBWT) L.g_sym[slot][k] = L.fl[p + k]; }
+            L.g_len[slot] = (uint8_t)len;
+        }
+        const uint64_t mt = __ballot(take);
+        n_dup += (uint32_t)__popcll(mt);
+        m &= ~mt; on = on && !take;
+    }
     return nupd;
 }
 
@@ -561,8 +539,8 @@ __device__ __forceinline__ uint32_t score_lists(LDS &L, const ScanArgs &a, uint3
 // 6 position pairs that joins a read with a genome scores 1 if their symbols are compatible.
 // Hits go straight into the update queue at slots from one wave prefix sum.
 template <int EBWT, typename LDS>
-__device__ __forceinline__ uint32_t score_small(LDS &L, const WgTables &T, UpdQueue &qu, MedState &ms, uint32_t &n_dup, const ScanArgs &a,
-                                                uint64_t lo, bool on, uint32_t p, uint32_t len)
+__device__ __forceinline__ uint32_t score_small(LDS &L, const WgTables &T, UpdQueue &qu, uint32_t &n_dup, const ScanArgs &a,
+                                                bool on, uint32_t p, uint32_t len)
 {
     const uint32_t kb = p >> 3, sh = p & 7u;
     const uint32_t rbits = (uint32_t)L.rb[kb] | ((uint32_t)L.rb[kb + 1u] << 8);
@@ -581,7 +559,7 @@ __device__ __forceinline__ uint32_t score_small(LDS &L, const WgTables &T, UpdQu
     d[2] = len > 2u ? d[2] : 0xFFFFFFFEu;
     d[3] = len > 3u ? d[3] : 0xFFFFFFFFu;
     const bool dup = on && ((d[0] == d[1]) | (d[0] == d[2]) | (d[0] == d[3]) | (d[1] == d[2]) | (d[1] == d[3]) | (d[2] == d[3]));
-    dup_push<EBWT>(L, n_dup, a, ms, dup, lo, p, len);
+    const uint32_t nflush = dup_push<EBWT>(L, n_dup, a, T, qu, dup, p, len);
     uint32_t compat6 = 0;
     {
         int pi = 0;
@@ -613,7 +591,7 @@ __device__ __forceinline__ uint32_t score_small(LDS &L, const WgTables &T, UpdQu
     }
     if (__ballot(bad != 0u)) { if (bad) atomicOr(&a.stats->flags, LIME_FLAG_DOCID); }
     qu.n += total;
-    return nh;
+    return nh + nflush;
 }
 
 // position pair (i < j) number t of a cluster of L symbols, rows i = 0.. of lengths L-1-i (L <= 16)
@@ -635,8 +613,8 @@ __host__ __device__ __forceinline__ void tri_decode(uint32_t t, uint32_t L, uint
 // cluster.  A chunk normally holds all rows of the window: one pass; else a first pass over all
 // chunks settles the repeated-document marks before hits are emitted.
 template <int EBWT, typename LDS>
-__device__ __forceinline__ uint32_t score_medium(LDS &L, const WgTables &T, UpdQueue &qu, MedState &ms, uint32_t &n_dup, const ScanArgs &a,
-                                                 uint64_t lo, uint32_t nM, uint64_t *ptm = nullptr)
+__device__ __forceinline__ uint32_t score_medium(LDS &L, const WgTables &T, UpdQueue &qu, uint32_t &n_dup, const ScanArgs &a,
+                                                 uint32_t nM, uint64_t *ptm = nullptr)
 {
 #ifdef LIME_PHASE_TIMING
     uint64_t pt_t = __builtin_readcyclecounter(); uint64_t *pt_acc = ptm;
@@ -725,7 +703,7 @@ __device__ __forceinline__ uint32_t score_medium(LDS &L, const WgTables &T, UpdQ
                 PT(2)
             }
         }
-        dup_push<EBWT>(L, n_dup, a, ms, valid && dupf[lane] != 0, lo, item & 0xFFFu, len);
+        nupd += dup_push<EBWT>(L, n_dup, a, T, qu, valid && dupf[lane] != 0, item & 0xFFFu, len);
         PT(3)
     }
     return nupd;
@@ -887,7 +865,6 @@ __global__ __launch_bounds__(SCANK_WG) __attribute__((amdgpu_waves_per_eu(LIME_S
     if (win >= n_win) return;
     UpdQueue qu; qu.qr = L.q_read; qu.qg = L.q_gen; qu.n = 0; qu.cap = QCAP_SCAN;
     qu.async = true; qu.fr = L.f_read; qu.fg = L.f_gen; qu.fe = L.f_exp;
-    MedState ms = {{0u, 0u}, {0u, 0u}, {0u, 0u}};          // no chunk reserved yet
     WinRegs regs;
     window_load<EBWT>(regs, a, (uint64_t)win * WIN);
     uint32_t acc_n = 0, acc_max = 0, acc_upd = 0;          // per-lane partial counters, reduced once at the end
@@ -949,7 +926,7 @@ __global__ __launch_bounds__(SCANK_WG) __attribute__((amdgpu_waves_per_eu(LIME_S
         if (next < n_win) window_load<EBWT>(regs, a, (uint64_t)next * WIN);
 
         PT(1)
-        if (a.ablate != 1) {                               // LIME_ABLATE: timing experiments, cut after a phase
+        if (!ABL(1)) {                               // LIME_ABLATE: timing experiments, cut after a phase
         const Ctx16 c = chunk_context(hb, rb, gb, H64, R64, G64, own_lim);
         // ---- window summary for the segment that is still open after the read-ahead ------------
         {
@@ -979,7 +956,7 @@ __global__ __launch_bounds__(SCANK_WG) __attribute__((amdgpu_waves_per_eu(LIME_S
             }
         }
         PT(2)
-        if (a.ablate != 3) {
+        if (!ABL(3)) {
         // ---- every lane lists the accepted clusters of its chunk: slots from a wave prefix sum ---------
         const uint32_t cnt = (uint32_t)__popc(c.ah);
         const uint32_t incl = wave_incl_scan(cnt), total = rl32(incl, 63);
@@ -1001,7 +978,7 @@ __global__ __launch_bounds__(SCANK_WG) __attribute__((amdgpu_waves_per_eu(LIME_S
             }
             uint32_t nM = 0, nX = 0;
             PT(3)
-            if (a.ablate != 4)
+            if (!ABL(4))
             for (uint32_t base = 0; base < total; base += 64u) {
                 const uint32_t t = base + lane;
                 const bool on = t < total;
@@ -1036,14 +1013,14 @@ __global__ __launch_bounds__(SCANK_WG) __attribute__((amdgpu_waves_per_eu(LIME_S
                 }
                 const bool sm4 = on && len <= 4u;
                 PT(4)
-                if (a.ablate != 10) acc_upd += score_small<EBWT>(L, T, qu, ms, n_dup, a, lo, sm4, sm4 ? p : 0u, sm4 ? len : 0u);
+                if (!ABL(10)) acc_upd += score_small<EBWT>(L, T, qu, n_dup, a, sm4, sm4 ? p : 0u, sm4 ? len : 0u);
                 PT(5)
             }
-            if (nM && a.ablate != 10 && a.ablate != 11) {
+            if (nM && !ABL(10) && !ABL(11)) {
 #ifdef LIME_PHASE_TIMING
-                acc_upd += score_medium<EBWT>(L, T, qu, ms, n_dup, a, lo, nM, pt_m); ++pt_nwin;
+                acc_upd += score_medium<EBWT>(L, T, qu, n_dup, a, nM, pt_m); ++pt_nwin;
 #else
-                acc_upd += score_medium<EBWT>(L, T, qu, ms, n_dup, a, lo, nM);
+                acc_upd += score_medium<EBWT>(L, T, qu, n_dup, a, nM);
 #endif
             }
             // 17..64 symbols: the whole wave is one lane group on the staged window
@@ -1077,7 +1054,6 @@ __global__ __launch_bounds__(SCANK_WG) __attribute__((amdgpu_waves_per_eu(LIME_S
     if (MODE == 0) {
         if (n_dup) acc_upd += dup_flush<EBWT>(L, n_dup, a, T, qu);
         do drain(qu, a); while (qu.n != 0u || __ballot(qu.f_pend != 0u));      // until every update has landed
-        med_fill(a, ms, 0u); med_fill(a, ms, 1u);
     }
 #ifdef LIME_PHASE_TIMING
     PT(7)
@@ -1262,70 +1238,6 @@ __global__ __launch_bounds__(SCAN_WG) void k_score_list(ScanArgs a, const lime_c
         if (cA) L.listA[(uint32_t)__popcll(mA & lt)] = item;
         acc_upd += score_lists<EBWT>(L, a, (uint32_t)__popcll(mA));
     }
-    const uint32_t tu = wave_sum(acc_upd);
-    if (lane == 0 && tu) atomicAdd(&a.stats->n_updates, (unsigned long long)tu);
-}
-
-// =========================================================================================
-// k_score_med: the clusters the scan listed instead of scoring: list 1 = 2..SMALL_MAX symbols
-// with a repeated document (G = 16 lanes per cluster), list 0 = SMALL_MAX+1..64 symbols (G = 64).
-// Element i of a cluster sits on sub-lane i, read straight from global memory; XOR-ing the
-// sub-lane with 1..R (R + 1 = the power of two covering the longest cluster of the wave) shows
-// every lane every other element of its cluster.  General score, element per lane.  Pass 1: is
-// this element the first of its document, and the document's count / 16-bin histogram over the
-// cluster (counts <= 64: no wrap, no saturation).  Pass 2: every first-occurrence read meets
-// every first-occurrence genome once (pair_score; ClusterBWT_DA.cpp:107-190 / :192-252).
-// =========================================================================================
-template <int EBWT, int G>
-__device__ __forceinline__ uint32_t score_groups(const ScanArgs &a, const WgTables &T, UpdQueue &qu,
-                                                 const uint64_t *med, uint32_t n)
-{
-    constexpr uint32_t PER = 64u / G;
-    const uint32_t lane = lane_id(), wave = threadIdx.x >> 6, sub = lane & (G - 1u), grp = lane / G;
-    const uint32_t n_it = (n + PER - 1u) / PER, stride = gridDim.x * (SCAN_WG / 64);
-    uint32_t acc_upd = 0;
-    // software pipeline over the wave's iterations: the record of iteration i+2 and the elements
-    // of iteration i+1 are in flight while iteration i is scored
-    auto load_rec = [&](uint32_t it) -> uint64_t {
-        const uint32_t idx = it * PER + grp;
-        return (it < n_it && idx < n) ? med[idx] : 0ull;           // 0: empty slot
-    };
-    const uint32_t it0 = blockIdx.x * (SCAN_WG / 64) + wave;
-    uint64_t rec1 = load_rec(it0), rec2 = load_rec(it0 + stride);
-    uint32_t d1 = 0, b1 = 0;
-    {
-        const uint32_t l1 = rec1 ? (uint32_t)(rec1 >> 48) + 1u : 0u;
-        if (sub < l1) { const uint64_t q = (rec1 & 0xFFFFFFFFFFFFull) + sub; d1 = a.da[q]; if (EBWT) b1 = a.ebwt[q]; }
-    }
-    for (uint32_t it = it0; it < n_it; it += stride) {
-        const uint64_t rec = rec1;
-        const uint32_t d = d1, bb = b1;
-        rec1 = rec2;
-        rec2 = load_rec(it + 2u * stride);
-        d1 = 0; b1 = 0;
-        {
-            const uint32_t l1 = rec1 ? (uint32_t)(rec1 >> 48) + 1u : 0u;
-            if (sub < l1) { const uint64_t q = (rec1 & 0xFFFFFFFFFFFFull) + sub; d1 = a.da[q]; if (EBWT) b1 = a.ebwt[q]; }
-        }
-        if (__ballot(rec != 0ull) == 0ull || a.ablate == 6) continue;
-        acc_upd += group_score<EBWT, G>(a, T, qu, d, bb, rec ? (uint32_t)(rec >> 48) + 1u : 0u);
-    }
-    return acc_upd;
-}
-
-template <int EBWT>
-__global__ __launch_bounds__(SCAN_WG) void k_score_med(ScanArgs a)
-{
-    __shared__ WgTables T;
-    __shared__ uint32_t s_qr[SCAN_WG / 64][QCAP], s_qg[SCAN_WG / 64][QCAP];
-    const uint32_t lane = lane_id(), wave = (uint32_t)__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));   // wave-uniform: LDS bases stay scalar
-    tables_init(T);
-    UpdQueue qu; qu.qr = s_qr[wave]; qu.qg = s_qg[wave]; qu.n = 0; qu.cap = QCAP;
-    const uint32_t n1 = a.stats->n_med[1] < a.med_cap ? a.stats->n_med[1] : a.med_cap;
-    const uint32_t n0 = a.stats->n_med[0] < a.med_cap ? a.stats->n_med[0] : a.med_cap;
-    uint32_t acc_upd = score_groups<EBWT, 16>(a, T, qu, a.med + (size_t)a.med_cap, n1);
-    if (n0) acc_upd += score_groups<EBWT, 64>(a, T, qu, a.med, n0);
-    drain(qu, a);
     const uint32_t tu = wave_sum(acc_upd);
     if (lane == 0 && tu) atomicAdd(&a.stats->n_updates, (unsigned long long)tu);
 }
@@ -1582,18 +1494,6 @@ void launch_score_list(int ebwt, const ScanArgs &a, const lime_cluster_t *list, 
 {
     if (ebwt) hipLaunchKernelGGL((k_score_list<1>), dim3(blocks), dim3(SCAN_WG), 0, st, a, list, count);
     else      hipLaunchKernelGGL((k_score_list<0>), dim3(blocks), dim3(SCAN_WG), 0, st, a, list, count);
-}
-
-void launch_score_med(int ebwt, const ScanArgs &a, uint32_t blocks, hipStream_t st)
-{
-    static uint32_t res[2] = {0, 0};                 // workgroups that fit the device at once, per instantiation
-    if (!res[0]) { res[0] = resident_blocks(k_score_med<1>, SCAN_WG); res[1] = resident_blocks(k_score_med<0>, SCAN_WG); }
-    // the lists are normally empty (the scan scores these clusters itself unless its per-wave store
-    // overflows): a small grid keeps the empty launch short
-    const uint32_t cap = blocks ? blocks : 256u;
-    const uint32_t g1 = res[0] < cap ? res[0] : cap, g0 = res[1] < cap ? res[1] : cap;
-    if (ebwt) hipLaunchKernelGGL((k_score_med<1>), dim3(g1), dim3(SCAN_WG), 0, st, a);
-    else      hipLaunchKernelGGL((k_score_med<0>), dim3(g0), dim3(SCAN_WG), 0, st, a);
 }
 
 void launch_score_big(int ebwt, const ScanArgs &a, uint32_t *scratch, hipStream_t st)

@@ -422,16 +422,58 @@ def test_full_size_paths_agree(ctx, shape):
 @pytest.mark.parametrize("nr,ng,mode", [(1, 1, 0), (2, 2, 1), (3, 5, 1), (2, 40, 0)])
 def test_repeated_documents_everywhere(ctx, nr, ng, mode):
     """very few documents: nearly every cluster holds a repeated document, far more per window than a wave's
-    LDS store takes, so the overflow lists and the fallback kernel (k_score_med) carry most of the scoring;
-    counts wrap modulo 256 many times"""
+    LDS store takes at once (it is flushed again and again inside a scoring round); counts wrap modulo 256
+    many times"""
     n = 400003
     lcp, da, eb = O.synth(1234 + nr, 0, n, nr, ng, 16, mode)
     cl, nc, ml = O.detect(lcp, da, nr, 16)
     for e in (eb, None):
         exp = O.score(da, e, cl, nr, ng, threads=4)
         sim, gnc, gml = ctx.fused(lcp, da, e, nr, ng, 16)
-        s, rc = ctx.stats()
-        assert rc == 0 and (ng > 5 or s.n_med[1] > 0), "the overflow list was not used"
+        assert (gnc, gml) == (nc, ml) and np.array_equal(sim, exp)
+        assert np.array_equal(ctx.score(da, e, cl, nr, ng), exp)
+
+
+@pytest.mark.parametrize("layout", ["blocks", "interleaved", "genomes_first"])
+def test_pair_score_of_32_in_a_64_symbol_cluster(ctx, layout):
+    """one cluster of 64 symbols holding ONE read x32 and ONE genome x32: t = 32, the largest score a cluster
+    scored inside the scan can give (ClusterBWT_DA.cpp:232-250 adds 32; a 5-bit field would drop it)"""
+    n = 3000
+    lcp = np.zeros(n, np.uint32); da = np.full(n, 1, np.uint32)          # filler: genome-only, no runs
+    s0 = 1000
+    lcp[s0 + 1:s0 + 64] = 20
+    docs = {"blocks": [0] * 32 + [1] * 32, "interleaved": [0, 1] * 32, "genomes_first": [1] * 32 + [0] * 32}[layout]
+    da[s0:s0 + 64] = docs
+    eb = np.full(n, ord("A"), np.uint8)                                  # EBWT=1: one repeated base
+    cl, nc, ml = O.detect(lcp, da, 1, 16)
+    assert nc == 1 and ml == 64
+    for e in (eb, None):
+        exp = O.score(da, e, cl, 1, 1)
+        assert int(exp[0, 0]) == 32
+        sim, gnc, gml = ctx.fused(lcp, da, e, 1, 1, 16)
+        assert (gnc, gml) == (1, 64) and np.array_equal(sim, exp)
+        sim, gnc, gml = ctx.fused_stream(lcp, da, e, 1, 1, 16, chunk=4096)
+        assert (gnc, gml) == (1, 64) and np.array_equal(sim, exp)
+        assert np.array_equal(ctx.score(da, e, cl, 1, 1), exp)
+
+
+@pytest.mark.parametrize("length", [33, 48, 60, 61, 62, 63, 64, 65, 66])
+@pytest.mark.parametrize("nr,ng", [(1, 1), (2, 1), (2, 3)])
+def test_clusters_of_up_to_64_symbols_with_few_documents(ctx, length, nr, ng):
+    """clusters just below / at / above the 64-symbol in-scan limit with very few documents (large pair scores),
+    at many window offsets, both builds"""
+    rng = np.random.default_rng(length * 131 + nr * 7 + ng)
+    n = 60000
+    lcp = np.zeros(n, np.uint32)
+    for s0 in range(50, n - 200, 173):                                  # cluster starts at every window phase
+        lcp[s0 + 1:s0 + length] = 17
+    da = np.where(rng.random(n) < 0.5, rng.integers(0, nr, n), nr + rng.integers(0, ng, n)).astype(np.uint32)
+    eb = rng.choice(np.frombuffer(b"AACN", np.uint8), n).astype(np.uint8)
+    cl, nc, ml = O.detect(lcp, da, nr, 16)
+    assert ml == length
+    for e in (eb, None):
+        exp = O.score(da, e, cl, nr, ng)
+        sim, gnc, gml = ctx.fused(lcp, da, e, nr, ng, 16)
         assert (gnc, gml) == (nc, ml) and np.array_equal(sim, exp)
         assert np.array_equal(ctx.score(da, e, cl, nr, ng), exp)
 
