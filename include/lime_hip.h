@@ -56,7 +56,8 @@ typedef struct {
     uint32_t n_cross;      /* clusters that crossed a tile edge (scored by the list kernel)  */
     uint32_t n_big;        /* clusters longer than the in-tile limit (scored by the big kernel) */
     uint32_t flags;        /* LIME_FLAG_* */
-    uint32_t n_med[2];     /* slots of the two lists (<= 8 / 9..16 symbols) the scan hands to k_score_med */
+    uint32_t wave_records_max; /* binned table updates: most update records one wave produced    */
+    uint32_t edge;         /* LIME_EDGE_* of a shard (see lime_fused_dev)                        */
     uint32_t reserved;
 } lime_stats_t;
 
@@ -65,6 +66,7 @@ typedef struct {
 #define LIME_FLAG_DOCID  4u
 #define LIME_FLAG_BADCLUSTER 8u
 #define LIME_FLAG_OVERFLOW 16u   /* an internal cluster list was too small (cannot happen with the default sizing) */
+#define LIME_FLAG_POOL_FULL 32u  /* binned table updates: the record pool was too small; lime_get_stats repeats the pass */
 
 /* ---- lifecycle ------------------------------------------------------------------------ */
 /* device < 0: keep the process's current HIP device.  Replaces the reference's
@@ -171,13 +173,18 @@ int lime_synth_dev(lime_ctx *ctx, uint64_t seed, uint64_t i0, uint64_t count,
                    uint32_t *d_lcp, uint32_t *d_da, uint8_t *d_ebwt, void *stream);
 
 /* Waits for `stream`, returns the counters of the last *_dev scan, and maps flags to an
- * error code (LIME_ERR_MAXLEN / _HALO / _DOCID) -- stats are filled either way. */
+ * error code (LIME_ERR_MAXLEN / _HALO / _DOCID) -- stats are filled either way.  The results of a
+ * lime_fused_dev pass are final only once this has returned: a pass on the binned update path whose record
+ * pool proved too small is repeated here with a larger one (the caller's arrays must still be in place). */
 int lime_get_stats(lime_ctx *ctx, lime_stats_t *out, void *stream);
 
 /* Average device time (ms) of the main scan kernel over the launches since the last call,
  * measured with HIP events on the launch stream; enabled by lime_set_timing(ctx, 1). */
 int lime_set_timing(lime_ctx *ctx, int on);
 int lime_get_timing(lime_ctx *ctx, double *scan_ms_avg, uint64_t *launches);
+/* the same with the parts of a lime_fused_dev pass: ms_avg[0] the scan kernel, [1] the whole pass (table clear or
+ * table build included), [2] everything after the scan kernel, [3] everything before it */
+int lime_get_timing_ex(lime_ctx *ctx, double ms_avg[4], uint64_t *launches);
 
 /* ---- pure host helpers (no device work; used by the CLIs and by CPU-side tests) -------- */
 uint8_t lime_sym_index(uint8_t byte);                              /* ClusterBWT_DA.cpp:455-470 */

@@ -23,7 +23,7 @@ class Cluster(C.Structure):
 
 class Stats(C.Structure):
     _fields_ = [("n_clusters", C.c_uint64), ("max_len", C.c_uint64), ("n_updates", C.c_uint64),
-                ("n_cross", C.c_uint32), ("n_big", C.c_uint32), ("flags", C.c_uint32), ("n_med", C.c_uint32 * 2), ("reserved", C.c_uint32)]
+                ("n_cross", C.c_uint32), ("n_big", C.c_uint32), ("flags", C.c_uint32), ("wave_records_max", C.c_uint32), ("edge", C.c_uint32), ("reserved", C.c_uint32)]
 
 
 class LimeError(RuntimeError):
@@ -56,6 +56,7 @@ SYMBOLS = {
     "lime_get_stats": (_i, [_vp, C.POINTER(Stats), _vp]),
     "lime_set_timing": (_i, [_vp, _i]),
     "lime_get_timing": (_i, [_vp, C.POINTER(C.c_double), _pu64]),
+    "lime_get_timing_ex": (_i, [_vp, C.POINTER(C.c_double), _pu64]),
     "lime_sym_index": (C.c_uint8, [C.c_uint8]),
     "lime_pair_score": (C.c_uint8, [_vp, _vp]),
     "lime_write_clrs": (_i, [C.c_char_p, _vp, _u64]),

@@ -170,6 +170,12 @@ class Context:
         check(self.lib.lime_get_timing(self.h, C.byref(ms), C.byref(n)))
         return ms.value, int(n.value)
 
+    def get_timing_ex(self):
+        """-> ({scan, pass, after_scan, before_scan} average ms per lime_fused_dev pass, passes timed)"""
+        ms, n = (C.c_double * 4)(), C.c_uint64(0)
+        check(self.lib.lime_get_timing_ex(self.h, ms, C.byref(n)))
+        return {"scan": ms[0], "pass": ms[1], "after_scan": ms[2], "before_scan": ms[3]}, int(n.value)
+
 
 def _ptr(t):
     if t is None:

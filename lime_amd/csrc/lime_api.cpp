@@ -53,10 +53,25 @@ struct lime_ctx {
     uint32_t *d_big_scratch = nullptr;
     uint32_t max_blocks = 0;                // persistent grid of the scan kernel; 0 = as many workgroups as fit the device (LIME_MAX_BLOCKS)
     uint32_t list_blocks = 8192;
-    int ablate = 0;                         // LIME_ABLATE: kernel timing experiments (results invalid when != 0)
-    // timing of the scan kernel with HIP events on the launch stream
+    int ablate = 0;                         // LIME_ABLATE (only in a -DLIME_ABLATE_BUILD library): kernel timing experiments, results invalid when != 0
+    // binned table updates (bin-then-apply): record pool, per-bin counters, binned records
+    uint64_t *d_pool = nullptr; size_t pool_cap = 0;          // records
+    uint32_t *d_recs = nullptr; size_t recs_cap = 0;
+    uint32_t *d_wave_cnt = nullptr; size_t wave_cap = 0;
+    uint32_t *d_counts = nullptr; size_t counts_cap = 0;
+    uint32_t *d_totals = nullptr; uint64_t *d_binbase = nullptr;
+    int upd_pref = -1;                      // LIME_UPDATE_PATH: -1 auto, 0 compare-and-swap on the table, 1 binned
+    bool density_known = false; double density = 0.0;          // table updates per owned symbol of the last pass read back
+    double pool_density = 0.20;             // records per owned symbol the pool is sized for (grows on LIME_FLAG_POOL_FULL)
+    struct Last {                           // the last lime_fused_dev call, so that lime_get_stats can repeat it with a larger pool
+        bool valid = false, binned = false;
+        const uint32_t *lcp = nullptr, *da = nullptr; const uint8_t *ebwt = nullptr;
+        uint64_t n_own = 0, n_avail = 0; int eof = 0; uint32_t n_reads = 0, n_refs = 0, alpha = 0;
+        uint8_t *sim = nullptr; int zero_sim = 0; hipStream_t st = nullptr; uint32_t n_waves = 0;
+    } last;
+    // timing with HIP events on the launch stream: per pass {pass start, scan start, scan end, pass end}
     bool timing = false;
-    std::vector<hipEvent_t> ev;             // pairs
+    std::vector<hipEvent_t> ev;
     size_t ev_used = 0;
 };
 
@@ -90,7 +105,11 @@ extern "C" int lime_init(int device, lime_ctx **out)
     HIP_TRY(hipMalloc(&c->d_stats, sizeof(DevStats)));
     HIP_TRY(hipMalloc(&c->d_total, sizeof(unsigned long long)));
     HIP_TRY(hipMemset(c->d_stats, 0, sizeof(DevStats)));
+#ifdef LIME_ABLATE_BUILD
     if (const char *s = getenv("LIME_ABLATE")) c->ablate = atoi(s);
+#endif
+    if (const char *s = getenv("LIME_UPDATE_PATH")) c->upd_pref = !strcmp(s, "cas") ? 0 : !strcmp(s, "bin") ? 1 : -1;
+    if (const char *s = getenv("LIME_POOL_DENSITY")) { const double v = atof(s); if (v > 0) c->pool_density = v; }   // tests: force a small pool
     if (const char *s = getenv("LIME_MAX_BLOCKS")) { long v = atol(s); if (v > 0) c->max_blocks = (uint32_t)v; }
     *out = c;
     return LIME_OK;
@@ -106,6 +125,8 @@ extern "C" void lime_shutdown(lime_ctx *c)
     (void)hipFree(c->d_tile_cnt); (void)hipFree(c->d_tile_off); (void)hipFree(c->d_cross); (void)hipFree(c->d_wmask);
     (void)hipFree(c->d_small); (void)hipFree(c->d_big); (void)hipFree(c->d_out);
     (void)hipFree(c->d_big_scratch);
+    (void)hipFree(c->d_pool); (void)hipFree(c->d_recs); (void)hipFree(c->d_wave_cnt); (void)hipFree(c->d_counts);
+    (void)hipFree(c->d_totals); (void)hipFree(c->d_binbase);
     delete c;
 }
 
@@ -184,6 +205,7 @@ static int flags_to_rc(uint32_t flags)
 {
     if (flags & LIME_FLAG_BADCLUSTER) return fail(LIME_ERR_ARG, "a cluster record lies outside the arrays");
     if (flags & LIME_FLAG_OVERFLOW) return fail(LIME_ERR_NOMEM, "internal cluster list overflow");
+    if (flags & LIME_FLAG_POOL_FULL) return fail(LIME_ERR_NOMEM, "update record pool too small (the pass could not be repeated)");
     if (flags & LIME_FLAG_MAXLEN) return fail(LIME_ERR_MAXLEN, "maximum cluster size is greater than %u (sizeMaxBuf)", LIME_MAX_CLUSTER);
     if (flags & LIME_FLAG_HALO) return fail(LIME_ERR_HALO, "a run owned by this shard does not close inside its halo");
     if (flags & LIME_FLAG_DOCID) return fail(LIME_ERR_DOCID, "a da value >= n_reads + n_refs was met while scoring");
@@ -205,22 +227,73 @@ static int timing_mark(lime_ctx *c, hipStream_t st)
     return LIME_OK;
 }
 
-extern "C" int lime_get_timing(lime_ctx *c, double *scan_ms_avg, uint64_t *launches)
+extern "C" int lime_get_timing_ex(lime_ctx *c, double ms_avg[4], uint64_t *launches)
 {
-    int rc = check_ctx(c, "lime_get_timing"); if (rc) return rc;
-    double sum = 0; uint64_t n = 0;
-    for (size_t i = 0; i + 1 < c->ev_used; i += 2) {
-        HIP_TRY(hipEventSynchronize(c->ev[i + 1]));
-        float ms = 0; HIP_TRY(hipEventElapsedTime(&ms, c->ev[i], c->ev[i + 1]));
-        sum += ms; ++n;
+    int rc = check_ctx(c, "lime_get_timing_ex"); if (rc) return rc;
+    double sum[4] = {0, 0, 0, 0}; uint64_t n = 0;
+    for (size_t i = 0; i + 3 < c->ev_used; i += 4) {
+        HIP_TRY(hipEventSynchronize(c->ev[i + 3]));
+        float ms = 0;
+        HIP_TRY(hipEventElapsedTime(&ms, c->ev[i + 1], c->ev[i + 2])); sum[0] += ms;     // the scan kernel
+        HIP_TRY(hipEventElapsedTime(&ms, c->ev[i], c->ev[i + 3])); sum[1] += ms;         // the whole pass
+        HIP_TRY(hipEventElapsedTime(&ms, c->ev[i + 2], c->ev[i + 3])); sum[2] += ms;     // after the scan
+        HIP_TRY(hipEventElapsedTime(&ms, c->ev[i], c->ev[i + 1])); sum[3] += ms;         // before the scan (table clear)
+        ++n;
     }
     c->ev_used = 0;
-    if (scan_ms_avg) *scan_ms_avg = n ? sum / (double)n : 0.0;
+    if (ms_avg) for (int k = 0; k < 4; ++k) ms_avg[k] = n ? sum[k] / (double)n : 0.0;
     if (launches) *launches = n;
     return LIME_OK;
 }
 
+extern "C" int lime_get_timing(lime_ctx *c, double *scan_ms_avg, uint64_t *launches)
+{
+    double ms[4];
+    int rc = lime_get_timing_ex(c, ms, launches);
+    if (!rc && scan_ms_avg) *scan_ms_avg = ms[0];
+    return rc;
+}
+
 // ---- device-pointer API -----------------------------------------------------------------
+// Which way the scan's table updates go.  Binned (records -> bins -> table regions built in LDS, the table
+// written once and never cleared) pays for update-dense passes over tables beyond the caches; compare-and-swap
+// on the table for sparse ones and wherever the table must be added to (zero_sim == 0, streaming chunks).
+static bool want_binned(const lime_ctx *c, uint64_t n_own, size_t sim_bytes, int zero_sim, bool keep_stats)
+{
+    if (!zero_sim || keep_stats || !n_own) return false;
+    if (sim_bytes > ((size_t)BIN_MAX << BIN_SHIFT_MAX) || sim_bytes >= (1ull << CELL_BITS)) return false;
+    if (c->upd_pref >= 0) return c->upd_pref == 1;
+    if (n_own < (1u << 24)) return false;                 // short passes: the extra launches cost more than they save
+    if (c->density_known) return c->density >= 0.06;
+    return sim_bytes > (256u << 20);                      // nothing known yet: tables beyond the Infinity Cache
+}
+
+static int ensure_binned(lime_ctx *c, uint64_t n_own, uint32_t n_waves, uint32_t n_prod, uint32_t n_bins, uint32_t *cap_w,
+                         hipStream_t st)
+{
+    int rc;
+    const double per_wave = (double)n_own * c->pool_density / (double)n_waves;
+    uint64_t cw = (uint64_t)(per_wave * 1.10) + 512u;
+    if (c->pool_cap / n_waves > cw) cw = c->pool_cap / n_waves;           // grow-only: use all of what is there
+    if (cw > 0xFFFFFFF0ull) return fail(LIME_ERR_ARG, "update record pool too large for one shard");
+    const size_t want = (size_t)cw * n_waves;
+    if (want > c->pool_cap) {
+        HIP_TRY(hipStreamSynchronize(st));
+        if ((rc = regrow(c->d_pool, want))) return rc;
+        if ((rc = regrow(c->d_recs, want))) return rc;
+        c->pool_cap = want; c->recs_cap = want;
+    }
+    if (n_waves > c->wave_cap) { HIP_TRY(hipStreamSynchronize(st)); if ((rc = regrow(c->d_wave_cnt, (size_t)n_waves))) return rc; c->wave_cap = n_waves; }
+    const size_t want_counts = (size_t)n_bins * n_prod;
+    if (want_counts > c->counts_cap) { HIP_TRY(hipStreamSynchronize(st)); if ((rc = regrow(c->d_counts, want_counts))) return rc; c->counts_cap = want_counts; }
+    if (!c->d_totals) {
+        HIP_TRY(hipMalloc(&c->d_totals, (BIN_MAX + 1) * sizeof(uint32_t)));
+        HIP_TRY(hipMalloc(&c->d_binbase, (BIN_MAX + 2) * sizeof(uint64_t)));
+    }
+    *cap_w = (uint32_t)cw;
+    return LIME_OK;
+}
+
 // keep_stats: this call continues a position-range sequence on the same table (lime_fused_stream):
 // cluster / update counters and flags accumulate, only the per-call list counters restart.
 static int fused_dev_impl(lime_ctx *c, const uint32_t *d_lcp, const uint32_t *d_da, const uint8_t *d_ebwt,
@@ -230,27 +303,56 @@ static int fused_dev_impl(lime_ctx *c, const uint32_t *d_lcp, const uint32_t *d_
     int rc;
     if (n_own > n_avail) return fail(LIME_ERR_ARG, "lime_fused_dev: n_own > n_avail");
     if (n_avail && (!d_lcp || !d_da || !d_sim)) return fail(LIME_ERR_ARG, "lime_fused_dev: NULL array");
-    if (misaligned(d_lcp, 16) || misaligned(d_da, 16) || misaligned(d_ebwt, 8) || misaligned(d_sim, 4))
-        return fail(LIME_ERR_ARG, "lime_fused_dev: device arrays must be 16-byte aligned (ebwt: 8, sim: 4)");
+    if (misaligned(d_lcp, 16) || misaligned(d_da, 16) || misaligned(d_ebwt, 8) || misaligned(d_sim, 16))
+        return fail(LIME_ERR_ARG, "lime_fused_dev: device arrays must be 16-byte aligned (ebwt: 8)");
     if (!n_reads || !n_refs) return fail(LIME_ERR_ARG, "lime_fused_dev: n_reads and n_refs must be > 0");
     if (n_refs >= MAX_REFS || (uint64_t)n_reads + n_refs > 0xFFFFFFF0ull)
         return fail(LIME_ERR_ARG, "lime_fused_dev: n_refs must be < 2^%u and n_reads + n_refs <= 2^32 - 16", T_SHIFT);
+    if ((n_avail + WIN - 1) / WIN > 0xFFFFFFF0ull) return fail(LIME_ERR_ARG, "array too long for one shard: %llu", (unsigned long long)n_avail);
     if ((rc = ensure_scratch(c, n_avail, false, true, st))) return rc;
+    const size_t sim_bytes = lime_sim_bytes(n_reads, n_refs);
+    const int ebwt = d_ebwt != nullptr;
+    const uint32_t n_tiles = (uint32_t)((n_avail + WIN - 1) / WIN);
+    const bool binned = n_avail && want_binned(c, n_own, sim_bytes, zero_sim, keep_stats);
+    uint32_t grid = 0, cap_w = 0, n_bins = 0, bin_shift = REGION_SHIFT;
+    if (binned) {
+        grid = scan_grid(ebwt, 0, 1, n_tiles, c->max_blocks);
+        while (((sim_bytes + ((size_t)1 << bin_shift) - 1) >> bin_shift) > BIN_MAX) ++bin_shift;
+        n_bins = (uint32_t)((sim_bytes + ((size_t)1 << bin_shift) - 1) >> bin_shift);
+        if ((rc = ensure_binned(c, n_own, grid * (SCAN_WG / 64), grid, n_bins, &cap_w, st))) return rc;
+    }
+    if ((rc = timing_mark(c, st))) return rc;
     if (keep_stats) {
         HIP_TRY(hipMemsetAsync(&c->d_stats->n_cross, 0, 2 * sizeof(uint32_t), st));      // n_cross, n_big
     } else {
         HIP_TRY(hipMemsetAsync(c->d_stats, 0, sizeof(DevStats), st));
     }
-    if (zero_sim) HIP_TRY(hipMemsetAsync(d_sim, 0, lime_sim_bytes(n_reads, n_refs), st));
-    if (!n_avail) return LIME_OK;
+    if (zero_sim && !binned) HIP_TRY(hipMemsetAsync(d_sim, 0, sim_bytes, st));           // the binned path writes every byte itself
+    if (!n_avail) { if ((rc = timing_mark(c, st)) || (rc = timing_mark(c, st)) || (rc = timing_mark(c, st))) return rc; return LIME_OK; }
     ScanArgs a = base_args(c, d_lcp, d_da, d_ebwt, n_own, n_avail, eof, n_reads, n_refs, alpha, d_sim);
-    const int ebwt = d_ebwt != nullptr;
+    if (binned) {
+        a.upd_mode = 1; a.pool = c->d_pool; a.cap_w = cap_w; a.wave_cnt = c->d_wave_cnt; a.counts = c->d_counts;
+        a.n_bins = n_bins; a.bin_shift = bin_shift;
+    }
     if ((rc = timing_mark(c, st))) return rc;
     launch_tile(ebwt, 0, a, c->max_blocks, st);
     if ((rc = timing_mark(c, st))) return rc;
     launch_resolve(0, a, st);
-    launch_score_big(ebwt, a, c->d_big_scratch, st);
+    if (binned) {
+        launch_bin_rowscan(c->d_counts, c->d_totals, n_bins, grid, st);
+        launch_scan_tiles(c->d_totals, c->d_binbase, n_bins, reinterpret_cast<unsigned long long *>(c->d_binbase + n_bins), st);
+        launch_part(a, grid, c->d_binbase, c->d_recs, st);
+        launch_apply(d_sim, sim_bytes, c->d_recs, c->d_binbase, n_bins, bin_shift, st);
+    }
+    launch_score_big(ebwt, a, c->d_big_scratch, st);      // after k_apply: its compare-and-swaps add to the finished table
+    if ((rc = timing_mark(c, st))) return rc;
     HIP_TRY(hipGetLastError());
+    if (!keep_stats) {
+        lime_ctx::Last &l = c->last;
+        l.valid = true; l.binned = binned; l.lcp = d_lcp; l.da = d_da; l.ebwt = d_ebwt; l.n_own = n_own; l.n_avail = n_avail;
+        l.eof = eof; l.n_reads = n_reads; l.n_refs = n_refs; l.alpha = alpha; l.sim = d_sim; l.zero_sim = zero_sim; l.st = st;
+        l.n_waves = grid * (SCAN_WG / 64);
+    }
     return LIME_OK;
 }
 
@@ -263,13 +365,36 @@ extern "C" int lime_fused_dev(lime_ctx *c, const uint32_t *d_lcp, const uint32_t
                           (hipStream_t)stream);
 }
 
+static int read_stats(lime_ctx *c, lime_stats_t *s, hipStream_t st)
+{
+    HIP_TRY(hipMemcpyAsync(s, c->d_stats, sizeof *s, hipMemcpyDeviceToHost, st));
+    HIP_TRY(hipStreamSynchronize(st));
+    return LIME_OK;
+}
+
 extern "C" int lime_get_stats(lime_ctx *c, lime_stats_t *out, void *stream)
 {
     int rc = check_ctx(c, "lime_get_stats"); if (rc) return rc;
     hipStream_t st = (hipStream_t)stream;
     lime_stats_t s;
-    HIP_TRY(hipMemcpyAsync(&s, c->d_stats, sizeof s, hipMemcpyDeviceToHost, st));
-    HIP_TRY(hipStreamSynchronize(st));
+    if ((rc = read_stats(c, &s, st))) return rc;
+    // binned table updates: the record pool was too small for this pass -> the table is incomplete.  The pass
+    // told how many records its busiest wave produced: repeat it with a pool sized for that (the caller's arrays
+    // are still in place: nothing was reported to it yet), at most twice; then on the compare-and-swap path.
+    lime_ctx::Last &l = c->last;
+    for (int attempt = 0; (s.flags & LIME_FLAG_POOL_FULL) && l.valid && l.binned && attempt < 3; ++attempt) {
+        const int pref = c->upd_pref;
+        if (attempt == 2) c->upd_pref = 0;
+        const double need = (double)s.wave_records_max * (double)l.n_waves / (double)(l.n_own ? l.n_own : 1);
+        c->pool_density = need * 1.08 > c->pool_density * 1.5 ? need * 1.08 : c->pool_density * 1.5;
+        const bool timing = c->timing; c->timing = false;
+        rc = fused_dev_impl(c, l.lcp, l.da, l.ebwt, l.n_own, l.n_avail, l.eof, l.n_reads, l.n_refs, l.alpha, l.sim, l.zero_sim,
+                            false, l.st);
+        c->timing = timing; c->upd_pref = pref;
+        if (rc) return rc;
+        if ((rc = read_stats(c, &s, l.st))) return rc;
+    }
+    if (l.valid && l.n_own) { c->density = (double)s.n_updates / (double)l.n_own; c->density_known = true; }
     if (out) *out = s;
     if (c->big_cap && s.n_big > c->big_cap)
         return fail(LIME_ERR_NOMEM, "more clusters longer than %u symbols (%u) than the list holds (%u)", SMALL_MAX, s.n_big, c->big_cap);
@@ -291,6 +416,7 @@ extern "C" int lime_detect_dev(lime_ctx *c, const uint32_t *d_lcp, const uint32_
         return fail(LIME_ERR_ARG, "lime_detect_dev: device arrays must be 16-byte aligned");
     if (!n_avail) return LIME_OK;
     if ((rc = ensure_scratch(c, n_avail, true, false, st))) return rc;
+    c->last.valid = false;
     HIP_TRY(hipMemsetAsync(c->d_stats, 0, sizeof(DevStats), st));
     ScanArgs a = base_args(c, d_lcp, d_da, nullptr, n_own, n_avail, eof, n_reads, 1, alpha, nullptr);
     a.pos_base = pos_base;
@@ -338,6 +464,7 @@ extern "C" int lime_score_dev(lime_ctx *c, const uint32_t *d_da, const uint8_t *
         if ((rc = regrow(c->d_big, (size_t)n_clusters + 16))) return rc;
         c->big_cap = (uint32_t)(n_clusters + 16);
     }
+    c->last.valid = false;
     HIP_TRY(hipMemsetAsync(c->d_stats, 0, sizeof(DevStats), st));
     if (zero_sim) HIP_TRY(hipMemsetAsync(d_sim, 0, lime_sim_bytes(n_reads, n_refs), st));
     if (!n_clusters) return LIME_OK;

@@ -21,6 +21,15 @@ constexpr uint32_t MAX_REFS = 1u << T_SHIFT; // so n_refs must stay below this
 constexpr uint32_t HT_BITS = 17;             // >= 2 x LIME_MAX_CLUSTER slots: the table never fills
 constexpr uint32_t HT_SIZE = 1u << HT_BITS;
 constexpr uint32_t HT_EMPTY = 0xFFFFFFFFu;
+// ---- binned table updates (bin-then-apply): the scan appends (cell, t) records to per-wave regions of a
+// pool and counts them per table bin; k_part moves them into their bins; k_apply builds each 128 KB region
+// of the table in LDS from its bin's records and writes it out once
+constexpr uint32_t BIN_MAX = 3072;           // bins: one u32 counter each in the 12 KB of LDS the CAS slots use otherwise
+constexpr uint32_t REGION_SHIFT = 17;        // k_apply builds 2^17 = 128 KB of the table per workgroup
+constexpr uint32_t BIN_SHIFT_MAX = 25;       // bin-relative cell offset + 7 bits of t must fit 32 bits
+constexpr uint32_t CELL_BITS = 40;           // pool record: cell | t << 40
+constexpr int APPLY_WG = 1024;
+
 constexpr uint32_t BIG_GRID = 32;            // workgroups of k_score_big (each owns a scratch table)
 constexpr size_t BIG_SCRATCH_WORDS = (size_t)HT_SIZE + (size_t)HT_SIZE * 16u + 2u * LIME_MAX_CLUSTER;
 
@@ -29,7 +38,7 @@ struct CrossRec { uint64_t start, len; };                          // len == 0: 
 
 struct DevStats {                            // same layout as lime_stats_t
     unsigned long long n_clusters, max_len, n_updates;
-    uint32_t n_cross, n_big, flags, n_med[2], reserved;
+    uint32_t n_cross, n_big, flags, wave_records_max, edge, reserved;
 };
 static_assert(sizeof(DevStats) == sizeof(lime_stats_t), "DevStats must mirror lime_stats_t");
 
@@ -49,10 +58,23 @@ struct ScanArgs {
     lime_cluster_t *big; uint32_t big_cap;       // clusters > SMALL_MAX
     uint32_t *tile_cnt; uint64_t *tile_off; CrossRec *cross; lime_cluster_t *out;   // detect only
     WinMasks *wmask;                             // detect only: count pass -> emit pass
-    int ablate;                                  // timing experiments only (LIME_ABLATE): 0 = full kernel
+    int ablate;                                  // timing experiments only (LIME_ABLATE_BUILD): 0 = full kernel
+    // binned table updates (upd_mode 1; 0 = compare-and-swap on the table)
+    int upd_mode;
+    uint64_t *pool; uint32_t cap_w;              // records of wave w: pool[w * cap_w ..), at most cap_w
+    uint32_t *wave_cnt;                          // records wave w wrote
+    uint32_t *counts;                            // [n_bins][gridDim.x]: records of bin b counted by workgroup p
+    uint32_t n_bins, bin_shift;                  // bin of a cell = cell >> bin_shift
 };
 
 void launch_tile(int ebwt, int mode, const ScanArgs &a, uint32_t max_blocks, hipStream_t st);
+uint32_t scan_grid(int ebwt, int mode, int binned, uint32_t n_tiles, uint32_t max_blocks);   // workgroups launch_tile will use
+// binned updates: after the scan (n_prod = its grid) -- per-bin prefix over the producers and bin totals,
+// records into bins, table regions from bins
+void launch_bin_rowscan(uint32_t *counts, uint32_t *totals, uint32_t n_bins, uint32_t n_prod, hipStream_t st);
+void launch_part(const ScanArgs &a, uint32_t n_prod, const uint64_t *binbase, uint32_t *out, hipStream_t st);
+void launch_apply(uint8_t *sim, size_t sim_bytes, const uint32_t *recs, const uint64_t *binbase, uint32_t n_bins,
+                  uint32_t bin_shift, hipStream_t st);
 void launch_resolve(int mode, const ScanArgs &a, hipStream_t st);
 void launch_emit(const ScanArgs &a, hipStream_t st);
 void launch_scan_tiles(const uint32_t *cnt, uint64_t *off, uint32_t n, unsigned long long *total, hipStream_t st);

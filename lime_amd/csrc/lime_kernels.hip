@@ -193,6 +193,9 @@ struct UpdQueue { uint32_t *qr, *qg; uint32_t n, cap;
     // dense tables: once 1 in 4 of the first tries (which expect an empty word) has lost, new entries first load
     // their word (a load is much cheaper than a lost compare-and-swap) and try with what they saw one drain later
     uint32_t f_first = 0, f_lost = 0; bool load_first = false;
+    // binned mode (ScanArgs::upd_mode): drains append (cell, t) records to the wave's region of the pool and count
+    // them per table bin in the workgroup's LDS histogram; no table access from the scan at all
+    bool binned = false; uint64_t *out = nullptr; uint32_t out_n = 0; uint32_t *hist = nullptr;
 #ifdef LIME_PHASE_TIMING
     uint64_t t_drain = 0; uint32_t n_drain = 0;
 #endif
@@ -252,9 +255,29 @@ __device__ __forceinline__ void drain_async(UpdQueue &q, const ScanArgs &a)
         }
 }
 
+// Binned mode: the queue's entries become pool records cell | t << CELL_BITS, written 64 at a time to the wave's
+// own region (coalesced 512-byte stores); records beyond the region's capacity are only counted (the host
+// repeats the pass with a larger pool: LIME_FLAG_POOL_FULL).
+__device__ __forceinline__ void drain_bin(UpdQueue &q, const ScanArgs &a)
+{
+    const uint32_t lane = lane_id();
+    for (uint32_t k0 = 0; k0 < q.n; k0 += 64u) {
+        const uint32_t k = k0 + lane;
+        const bool on = k < q.n;
+        const uint32_t gt = q.qg[on ? k : 0u];
+        const uint64_t cell = (uint64_t)q.qr[on ? k : 0u] * a.n_refs + (gt & (MAX_REFS - 1u));
+        const uint32_t slot = q.out_n + k;
+        if (on && slot < a.cap_w) {
+            atomicAdd(&q.hist[(uint32_t)(cell >> a.bin_shift)], 1u);
+            __builtin_nontemporal_store(cell | ((uint64_t)(gt >> T_SHIFT) << CELL_BITS), &q.out[slot]);
+        }
+    }
+    q.out_n += q.n; q.n = 0;
+}
+
 __device__ __forceinline__ void drain(UpdQueue &q, const ScanArgs &a)
 {
-    if (q.async) { drain_async(q, a); return; }
+    if (q.async) { if (q.binned) drain_bin(q, a); else drain_async(q, a); return; }     // both flags are compile-time constants of the kernel
 #ifdef LIME_PHASE_TIMING
     const uint64_t t0 = __builtin_readcyclecounter();
 #endif
@@ -793,7 +816,6 @@ struct alignas(16) ScanLds {
     uint16_t m_tstart[64];
     uint8_t m_flag[64], m_dup[64];
     uint32_t q_read[QCAP_SCAN], q_gen[QCAP_SCAN];
-    uint32_t f_read[256], f_gen[256], f_exp[256];
     uint32_t g_doc[DUP_SLOTS][SMALL_MAX];
     uint8_t g_sym[DUP_SLOTS][SMALL_MAX], g_len[DUP_SLOTS];
 };
@@ -852,19 +874,50 @@ __device__ __forceinline__ Ctx16 chunk_context(uint32_t h, uint32_t r, uint32_t 
     return c;
 }
 
-template <int EBWT, int MODE>
+// BIN 1 (MODE 0 only): table updates leave the kernel as records (binned update path) instead of compare-and-swaps.
+template <int EBWT, int MODE, int BIN>
 __global__ __launch_bounds__(SCANK_WG) __attribute__((amdgpu_waves_per_eu(LIME_SCAN_WAVES, LIME_SCAN_WAVES))) void k_scan(ScanArgs a)
 {
+    static_assert(BIN == 0 || MODE == 0, "records are made by the scoring scan only");
     __shared__ ScanLds lds[SCANK_WG / 64];
     __shared__ WgTables T;
+    // per wave the in-flight compare-and-swap slots (entry read, genome | t, expected word: 3 x 256 words); in
+    // binned mode the same 12 KB are the workgroup's histogram of update records per table bin
+    __shared__ uint32_t fslots[SCANK_WG / 64][768];
+    __shared__ uint32_t wg_done;
+    static_assert(sizeof(fslots) / 4 >= BIN_MAX, "the bin histogram lives in the CAS slots' LDS");
     const uint32_t lane = lane_id(), wave = (uint32_t)__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));   // wave-uniform: LDS bases stay scalar
     ScanLds &L = lds[wave];
+    constexpr bool binned = BIN != 0;
+    if (binned) {
+        for (uint32_t i = threadIdx.x; i < (uint32_t)(sizeof(fslots) / 4); i += SCANK_WG) (&fslots[0][0])[i] = 0u;
+        if (threadIdx.x == 0) wg_done = 0u;
+    }
     tables_init(T);                                        // the only workgroup barrier of the kernel
     const uint32_t n_win = a.n_tiles, stride = gridDim.x * (SCANK_WG / 64);
     uint32_t win = blockIdx.x * (SCANK_WG / 64) + wave;
-    if (win >= n_win) return;
     UpdQueue qu; qu.qr = L.q_read; qu.qg = L.q_gen; qu.n = 0; qu.cap = QCAP_SCAN;
-    qu.async = true; qu.fr = L.f_read; qu.fg = L.f_gen; qu.fe = L.f_exp;
+    qu.async = true; qu.fr = fslots[wave]; qu.fg = fslots[wave] + 256; qu.fe = fslots[wave] + 512;
+    const uint32_t wave_gid = blockIdx.x * (SCANK_WG / 64) + wave;
+    qu.binned = binned;
+    if (binned) { qu.out = a.pool + (size_t)wave_gid * a.cap_w; qu.hist = &fslots[0][0]; }
+    // binned mode, end of a wave: its record count; the workgroup's last wave writes the bin histogram
+    auto finish_binned = [&]() {
+        if (lane == 0) {
+            a.wave_cnt[wave_gid] = qu.out_n < a.cap_w ? qu.out_n : a.cap_w;
+            atomicMax(&a.stats->wave_records_max, qu.out_n);
+            if (qu.out_n > a.cap_w) atomicOr(&a.stats->flags, LIME_FLAG_POOL_FULL);
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+        uint32_t old = 0;
+        if (lane == 0) old = atomicAdd(&wg_done, 1u);
+        old = (uint32_t)__builtin_amdgcn_readfirstlane((int)old);
+        if (old == SCANK_WG / 64 - 1) {
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+            for (uint32_t b = lane; b < a.n_bins; b += 64u) a.counts[(size_t)b * gridDim.x + blockIdx.x] = qu.hist[b];
+        }
+    };
+    if (win >= n_win) { if (binned) finish_binned(); return; }
     WinRegs regs;
     window_load<EBWT>(regs, a, (uint64_t)win * WIN);
     uint32_t acc_n = 0, acc_max = 0, acc_upd = 0;          // per-lane partial counters, reduced once at the end
@@ -1054,6 +1107,7 @@ __global__ __launch_bounds__(SCANK_WG) __attribute__((amdgpu_waves_per_eu(LIME_S
     if (MODE == 0) {
         if (n_dup) acc_upd += dup_flush<EBWT>(L, n_dup, a, T, qu);
         do drain(qu, a); while (qu.n != 0u || __ballot(qu.f_pend != 0u));      // until every update has landed
+        if (binned) finish_binned();
     }
 #ifdef LIME_PHASE_TIMING
     PT(7)
@@ -1183,6 +1237,121 @@ __global__ __launch_bounds__(1024) void k_scan_tiles(const uint32_t *cnt, uint64
         __syncthreads();
     }
     if (tid == 0) *total = carry;
+}
+
+// =========================================================================================
+// Binned table updates, after the scan (upd_mode 1).  The scan left, per producer workgroup p and table
+// bin b, the number of update records p's waves wrote to the pool (counts[b][p]) and the records
+// themselves in per-wave regions.  Reference site of the updates: ClusterBWT_DA.cpp:178-184, 243-248.
+//
+// k_bin_rowscan: one wave per bin: counts[b][.] becomes its exclusive prefix over the producers (where p's
+// records of bin b start inside the bin) and totals[b] the bin's size; k_scan_tiles turns the totals into
+// bin bases.
+// =========================================================================================
+__global__ __launch_bounds__(256) void k_bin_rowscan(uint32_t *counts, uint32_t *totals, uint32_t n_bins, uint32_t n_prod)
+{
+    const uint32_t lane = lane_id();
+    const uint32_t b = blockIdx.x * 4u + (threadIdx.x >> 6);
+    if (b >= n_bins) return;
+    uint32_t *row = counts + (size_t)b * n_prod;
+    uint32_t run = 0;
+    for (uint32_t p0 = 0; p0 < n_prod; p0 += 64u) {
+        const uint32_t p = p0 + lane;
+        const uint32_t v = p < n_prod ? row[p] : 0u;
+        const uint32_t incl = wave_incl_scan(v);
+        if (p < n_prod) row[p] = run + incl - v;
+        run += rl32(incl, 63);
+    }
+    if (lane == 0) totals[b] = run;
+}
+
+// k_part: workgroup p moves the records of producer workgroup p (wave w those of producer wave 4p + w) from the
+// pool into their bins.  Cursors of all bins sit in LDS (start = the prefix k_bin_rowscan left); a record takes
+// its slot with one returning LDS add and goes out as 4 bytes: cell offset inside the bin | t << bin_shift.
+__global__ __launch_bounds__(SCANK_WG) void k_part(ScanArgs a, const uint64_t *binbase, uint32_t *out)
+{
+    __shared__ uint32_t cur[BIN_MAX];
+    __shared__ uint64_t base[BIN_MAX];
+    const uint32_t lane = lane_id(), wave = threadIdx.x >> 6;
+    for (uint32_t b = threadIdx.x; b < a.n_bins; b += SCANK_WG) {
+        cur[b] = a.counts[(size_t)b * gridDim.x + blockIdx.x];
+        base[b] = binbase[b];
+    }
+    __syncthreads();
+    const uint32_t wave_gid = blockIdx.x * (SCANK_WG / 64) + wave;
+    const uint64_t *src = a.pool + (size_t)wave_gid * a.cap_w;
+    const uint32_t cnt = a.wave_cnt[wave_gid];
+    const uint64_t cmask = (1ull << CELL_BITS) - 1ull;
+    const uint32_t omask = (1u << a.bin_shift) - 1u;
+    constexpr uint32_t U = 4;                                   // records per lane in flight
+    for (uint32_t i0 = 0; i0 < cnt; i0 += 64u * U) {
+        uint64_t rec[U];
+#pragma unroll
+        for (uint32_t u = 0; u < U; ++u) {
+            const uint32_t i = i0 + 64u * u + lane;
+            rec[u] = i < cnt ? __builtin_nontemporal_load(src + i) : ~0ull;
+        }
+#pragma unroll
+        for (uint32_t u = 0; u < U; ++u)
+            if (rec[u] != ~0ull) {
+                const uint64_t cell = rec[u] & cmask;
+                const uint32_t b = (uint32_t)(cell >> a.bin_shift);
+                const uint32_t k = atomicAdd(&cur[b], 1u);
+                out[base[b] + k] = ((uint32_t)cell & omask) | ((uint32_t)(rec[u] >> CELL_BITS) << a.bin_shift);
+            }
+    }
+}
+
+// k_apply: one workgroup builds one 128 KB region of the table in LDS -- zero, add the records of the region
+// (its bin's records whose offset falls into it: a bin spans 2^(bin_shift - 17) regions, whose workgroups run on
+// one XCD next to each other so that the bin's records are fetched from HBM once and re-read from that L2),
+// exact modulo 256 per byte cell with an LDS compare-and-swap on the containing word -- and writes it out once
+// with 16-byte stores.  The table needs no clearing beforehand: every byte of it is written here.
+__global__ __launch_bounds__(APPLY_WG) void k_apply(uint8_t *sim, size_t sim_bytes, const uint32_t *recs, const uint64_t *binbase,
+                                                    uint32_t n_bins, uint32_t bin_shift)
+{
+    constexpr uint32_t RW = (1u << REGION_SHIFT) / 4u;           // words per region
+    __shared__ uint4 reg4[RW / 4];
+    uint32_t *reg = reinterpret_cast<uint32_t *>(reg4);
+    const uint32_t amp_shift = bin_shift - REGION_SHIFT, amp = 1u << amp_shift;
+    // blocks b and b + 8 share an XCD (round-robin dispatch; a speed matter only)
+    const uint32_t x = blockIdx.x & 7u, j = blockIdx.x >> 3;
+    const uint32_t bin = (j >> amp_shift) * 8u + x, sub = j & (amp - 1u);
+    if (bin >= n_bins) return;
+    const size_t reg_base = ((size_t)bin << bin_shift) + ((size_t)sub << REGION_SHIFT);
+    if (reg_base >= sim_bytes) return;
+    for (uint32_t i = threadIdx.x; i < RW / 4; i += APPLY_WG) reg4[i] = make_uint4(0u, 0u, 0u, 0u);
+    __syncthreads();
+    const uint64_t lo = binbase[bin], hi = binbase[bin + 1];
+    const uint32_t omask = (1u << bin_shift) - 1u, rmask = (1u << REGION_SHIFT) - 1u;
+    constexpr uint32_t U = 4;
+    for (uint64_t i0 = lo; i0 < hi; i0 += (uint64_t)APPLY_WG * U) {
+        uint32_t r[U];
+#pragma unroll
+        for (uint32_t u = 0; u < U; ++u) {
+            const uint64_t i = i0 + (uint64_t)APPLY_WG * u + threadIdx.x;
+            r[u] = i < hi ? recs[i] : 0u;                        // t == 0: no record
+        }
+#pragma unroll
+        for (uint32_t u = 0; u < U; ++u) {
+            const uint32_t off = r[u] & omask, t = r[u] >> bin_shift;
+            if (t != 0u && (off >> REGION_SHIFT) == sub) {
+                const uint32_t o = off & rmask, sh = (o & 3u) * 8u;
+                uint32_t *w = &reg[o >> 2];
+                uint32_t seen = *w;
+                for (;;) {
+                    const uint32_t b = ((seen >> sh) + t) & 255u;
+                    const uint32_t old = atomicCAS(w, seen, (seen & ~(255u << sh)) | (b << sh));
+                    if (old == seen) break;
+                    seen = old;
+                }
+            }
+        }
+    }
+    __syncthreads();
+    uint4 *dst = reinterpret_cast<uint4 *>(sim + reg_base);
+    const size_t left = (sim_bytes - reg_base) / 16u;            // sim_bytes is a multiple of 16
+    for (uint32_t i = threadIdx.x; i < RW / 4 && i < left; i += APPLY_WG) dst[i] = reg4[i];
 }
 
 // =========================================================================================
@@ -1455,22 +1624,57 @@ template <typename K> static uint32_t resident_blocks(K kernel, int block)
     return (uint32_t)per_cu * (uint32_t)prop.multiProcessorCount;
 }
 
-template <typename K> static void launch_scan_kernel(K kernel, const ScanArgs &a, uint32_t max_blocks, hipStream_t st)
+// ID: one per instantiation of k_scan (they share one function type, so K alone would share the static)
+template <int ID, typename K> static uint32_t scan_grid_of(K kernel, uint32_t n_tiles, uint32_t max_blocks)
 {
-    static uint32_t resident = 0;                 // per instantiation: blocks that fit the device at once
+    static uint32_t resident = 0;
     if (!resident) resident = resident_blocks(kernel, SCANK_WG);
-    uint32_t want = (a.n_tiles + SCANK_WG / 64 - 1) / (SCANK_WG / 64);
-    uint32_t cap = max_blocks ? max_blocks : resident;
-    uint32_t grid = want < cap ? want : cap;
-    hipLaunchKernelGGL(kernel, dim3(grid ? grid : 1u), dim3(SCANK_WG), 0, st, a);
+    const uint32_t want = (n_tiles + SCANK_WG / 64 - 1) / (SCANK_WG / 64), cap = max_blocks ? max_blocks : resident;
+    const uint32_t grid = want < cap ? want : cap;
+    return grid ? grid : 1u;
+}
+
+template <int ID, typename K> static void launch_scan_kernel(K kernel, const ScanArgs &a, uint32_t max_blocks, hipStream_t st)
+{
+    // persistent grid: as many workgroups as fit the device at once (per instantiation), or fewer for short inputs
+    hipLaunchKernelGGL(kernel, dim3(scan_grid_of<ID>(kernel, a.n_tiles, max_blocks)), dim3(SCANK_WG), 0, st, a);
+}
+
+uint32_t scan_grid(int ebwt, int mode, int binned, uint32_t n_tiles, uint32_t max_blocks)
+{
+    if (mode != 0) return scan_grid_of<2>(k_scan<0, 1, 0>, n_tiles, max_blocks);
+    if (binned) return ebwt ? scan_grid_of<4>(k_scan<1, 0, 1>, n_tiles, max_blocks) : scan_grid_of<3>(k_scan<0, 0, 1>, n_tiles, max_blocks);
+    return ebwt ? scan_grid_of<1>(k_scan<1, 0, 0>, n_tiles, max_blocks) : scan_grid_of<0>(k_scan<0, 0, 0>, n_tiles, max_blocks);
+}
+
+void launch_bin_rowscan(uint32_t *counts, uint32_t *totals, uint32_t n_bins, uint32_t n_prod, hipStream_t st)
+{
+    hipLaunchKernelGGL(k_bin_rowscan, dim3((n_bins + 3u) / 4u), dim3(256), 0, st, counts, totals, n_bins, n_prod);
+}
+
+void launch_part(const ScanArgs &a, uint32_t n_prod, const uint64_t *binbase, uint32_t *out, hipStream_t st)
+{
+    hipLaunchKernelGGL(k_part, dim3(n_prod), dim3(SCANK_WG), 0, st, a, binbase, out);
+}
+
+void launch_apply(uint8_t *sim, size_t sim_bytes, const uint32_t *recs, const uint64_t *binbase, uint32_t n_bins,
+                  uint32_t bin_shift, hipStream_t st)
+{
+    const uint32_t amp = 1u << (bin_shift - REGION_SHIFT);
+    const uint32_t grid = (n_bins + 7u) / 8u * 8u * amp;
+    hipLaunchKernelGGL(k_apply, dim3(grid), dim3(APPLY_WG), 0, st, sim, sim_bytes, recs, binbase, n_bins, bin_shift);
 }
 
 void launch_tile(int ebwt, int mode, const ScanArgs &a, uint32_t max_blocks, hipStream_t st)
 {
-    if (mode == 0) {
-        if (ebwt) launch_scan_kernel(k_scan<1, 0>, a, max_blocks, st);
-        else      launch_scan_kernel(k_scan<0, 0>, a, max_blocks, st);
-    } else launch_scan_kernel(k_scan<0, 1>, a, max_blocks, st);
+    if (mode != 0) launch_scan_kernel<2>(k_scan<0, 1, 0>, a, max_blocks, st);
+    else if (a.upd_mode) {
+        if (ebwt) launch_scan_kernel<4>(k_scan<1, 0, 1>, a, max_blocks, st);
+        else      launch_scan_kernel<3>(k_scan<0, 0, 1>, a, max_blocks, st);
+    } else {
+        if (ebwt) launch_scan_kernel<1>(k_scan<1, 0, 0>, a, max_blocks, st);
+        else      launch_scan_kernel<0>(k_scan<0, 0, 0>, a, max_blocks, st);
+    }
 }
 
 void launch_emit(const ScanArgs &a, hipStream_t st)

@@ -1,0 +1,123 @@
+"""The binned table-update path (records -> bins -> table regions built in LDS) against the
+oracle and the reference's golden vectors, bit-exact, through the C ABI.  LIME_UPDATE_PATH=bin forces the path for
+inputs of any size (by default it is chosen for update-dense passes over large tables only)."""
+import numpy as np
+import pytest
+
+from oracle import oracle_py as O
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def bctx():
+    import os
+    import lime_amd
+    old = os.environ.get("LIME_UPDATE_PATH")
+    os.environ["LIME_UPDATE_PATH"] = "bin"
+    c = lime_amd.Context()
+    if old is None:
+        del os.environ["LIME_UPDATE_PATH"]
+    else:
+        os.environ["LIME_UPDATE_PATH"] = old
+    yield c
+    c.close()
+
+
+@pytest.mark.parametrize("ebwt_mode", [1, 0])
+def test_binned_fused_golden(bctx, golden, ebwt_mode):
+    eb = golden["ebwt"] if ebwt_mode else None
+    sim, nc, ml = bctx.fused(golden["lcp"], golden["da"], eb, golden["n_reads"], golden["n_refs"], golden["alpha"])
+    assert nc == len(golden["clrs"])
+    assert np.array_equal(sim, golden[f"sim_e{ebwt_mode}"])
+
+
+@pytest.mark.parametrize("n,nr,ng,mode", [
+    (1, 3, 2, 0), (63, 3, 2, 0), (4097, 5, 4, 0), (12289, 40, 7, 1), (300000, 1000, 50, 0), (300001, 200, 9, 1),
+    (2000003, 5000, 120, 0),          # 600 KB table: 5 regions, the last one partial
+    (1500000, 1, 1, 1),               # one cell: every update collides (LDS compare-and-swap retries), wraps many times
+    (1500000, 2, 131072, 0),          # rows as long as a region
+    (3000000, 40000, 700, 1),         # 28 MB table, 214 regions
+])
+def test_binned_fused_vs_oracle(bctx, n, nr, ng, mode):
+    lcp, da, eb = O.synth(2000 + n, 0, n, nr, ng, 16, mode)
+    cl, nc, ml = O.detect(lcp, da, nr, 16)
+    for e in (eb, None):
+        exp = O.score(da, e, cl, nr, ng, threads=4)
+        sim, gnc, gml = bctx.fused(lcp, da, e, nr, ng, 16)
+        s, rc = bctx.stats()
+        assert rc == 0 and s.wave_records_max > 0 or nc == 0
+        assert (gnc, gml) == (nc, ml)
+        assert np.array_equal(sim, exp)
+
+
+def test_binned_bins_wider_than_a_region(bctx):
+    """a table of more than 3072 x 128 KB: bins of 256 KB, two region workgroups share each bin's records"""
+    n, nr, ng = 3000000, 150000, 3000                      # 450 MB
+    lcp, da, _ = O.synth(31, 0, n, nr, ng, 16, 0)
+    cl, nc, ml = O.detect(lcp, da, nr, 16)
+    exp = O.score(da, None, cl, nr, ng, threads=4)
+    sim, gnc, gml = bctx.fused(lcp, da, None, nr, ng, 16)
+    assert (gnc, gml) == (nc, ml)
+    assert np.array_equal(sim, exp)
+
+
+def test_binned_with_long_clusters(bctx):
+    """clusters longer than 64 go to k_score_big, whose compare-and-swaps must land on the table k_apply built"""
+    rng = np.random.default_rng(11)
+    n = 200000
+    lcp = np.where(rng.random(n) < 0.97, 20, 3).astype(np.uint32)
+    lcp[0] = 0
+    lcp[20000:45000] = 30
+    lcp[45000] = 1
+    da = np.where(rng.random(n) < 0.5, rng.integers(0, 3, n), 3 + rng.integers(0, 4, n)).astype(np.uint32)
+    eb = rng.choice(np.frombuffer(b"ACGTNRY\x00", np.uint8), n).astype(np.uint8)
+    cl, nc, ml = O.detect(lcp, da, 3, 16)
+    for e in (eb, None):
+        exp = O.score(da, e, cl, 3, 4, threads=4)
+        sim, gnc, gml = bctx.fused(lcp, da, e, 3, 4, 16)
+        assert (gnc, gml) == (nc, ml) and np.array_equal(sim, exp)
+
+
+def test_binned_pool_too_small_is_repeated(monkeypatch):
+    """a record pool sized for 1 update per 1000 symbols: the pass overflows it, lime_get_stats repeats the pass with
+    a pool sized from what the first attempt counted, and the result is the oracle's"""
+    import lime_amd
+    monkeypatch.setenv("LIME_UPDATE_PATH", "bin")
+    monkeypatch.setenv("LIME_POOL_DENSITY", "0.001")
+    c = lime_amd.Context()
+    try:
+        n, nr, ng = 2500000, 3000, 300
+        lcp, da, eb = O.synth(77, 0, n, nr, ng, 16, 1)
+        cl, nc, ml = O.detect(lcp, da, nr, 16)
+        for e in (None, eb):
+            exp = O.score(da, e, cl, nr, ng, threads=4)
+            sim, gnc, gml = c.fused(lcp, da, e, nr, ng, 16)
+            assert (gnc, gml) == (nc, ml) and np.array_equal(sim, exp)
+    finally:
+        c.close()
+
+
+@pytest.mark.parametrize("n_shards", [2, 3])
+def test_binned_shards_sum_to_whole(bctx, n_shards):
+    import torch
+    import lime_amd
+    from lime_amd.dist import shard_ranges
+    n, nr, ng = 700001, 200, 1300
+    lcp, da, eb = O.synth(9, 0, n, nr, ng, 16, 1)
+    cl, nc, ml = O.detect(lcp, da, nr, 16)
+    exp = O.score(da, eb, cl, nr, ng, threads=4)
+    total = np.zeros((nr, ng), np.uint8)
+    tot_c = 0
+    for lo, hi, hi_halo in shard_ranges(n, n_shards, halo=65536 + 4096):
+        tl = torch.from_numpy(lcp[lo:hi_halo].view(np.int32)).cuda()
+        td = torch.from_numpy(da[lo:hi_halo].view(np.int32)).cuda()
+        te = torch.from_numpy(eb[lo:hi_halo]).cuda()
+        sim = torch.full((lime_amd.sim_bytes(nr, ng),), 7, dtype=torch.uint8, device="cuda")   # not cleared: the path writes every byte
+        bctx.fused_dev(tl, td, te, hi - lo, hi_halo - lo, hi_halo == n, nr, ng, 16, sim)
+        s, rc = bctx.stats()
+        assert rc == 0
+        tot_c += s.n_clusters
+        total = (total + sim[:nr * ng].cpu().numpy().reshape(nr, ng)).astype(np.uint8)
+    assert tot_c == nc
+    assert np.array_equal(total, exp)

@@ -16,4 +16,4 @@ sim = torch.zeros(sim_bytes(nr, ng), dtype=torch.uint8, device=dev)
 ctx.fused_dev(lcp, da, eb, n, n, 1, nr, ng, alpha, sim, True)
 torch.cuda.synchronize()
 st, rc = ctx.stats()
-print({k: (list(getattr(st, k)) if k == "n_med" else getattr(st, k)) for k, _ in st._fields_})
+print({k: getattr(st, k) for k, _ in st._fields_})
