@@ -60,8 +60,10 @@ struct lime_ctx {
     uint32_t *d_wave_cnt = nullptr; size_t wave_cap = 0;
     uint32_t *d_counts = nullptr; size_t counts_cap = 0;
     uint32_t *d_totals = nullptr; uint64_t *d_binbase = nullptr;
+    uint64_t *d_regbase = nullptr; size_t regbase_cap = 0;
     int upd_pref = -1;                      // LIME_UPDATE_PATH: -1 auto, 0 compare-and-swap on the table, 1 binned
     bool density_known = false; double density = 0.0;          // table updates per owned symbol of the last pass read back
+    uint32_t bin_one_level = BIN_ONE_LEVEL, bin_two_level = BIN_TWO_LEVEL;   // LIME_BIN_LEVELS="a,b" (tests: force the second level on small tables)
     double pool_density = 0.20;             // records per owned symbol the pool is sized for (grows on LIME_FLAG_POOL_FULL)
     struct Last {                           // the last lime_fused_dev call, so that lime_get_stats can repeat it with a larger pool
         bool valid = false, binned = false;
@@ -109,6 +111,10 @@ extern "C" int lime_init(int device, lime_ctx **out)
     if (const char *s = getenv("LIME_ABLATE")) c->ablate = atoi(s);
 #endif
     if (const char *s = getenv("LIME_UPDATE_PATH")) c->upd_pref = !strcmp(s, "cas") ? 0 : !strcmp(s, "bin") ? 1 : -1;
+    if (const char *s = getenv("LIME_BIN_LEVELS")) {
+        unsigned a1 = 0, a2 = 0;
+        if (sscanf(s, "%u,%u", &a1, &a2) == 2 && a1 >= 1 && a2 >= 1 && a1 <= BIN_MAX && a2 <= BIN_MAX) { c->bin_one_level = a1; c->bin_two_level = a2; }
+    }
     if (const char *s = getenv("LIME_POOL_DENSITY")) { const double v = atof(s); if (v > 0) c->pool_density = v; }   // tests: force a small pool
     if (const char *s = getenv("LIME_MAX_BLOCKS")) { long v = atol(s); if (v > 0) c->max_blocks = (uint32_t)v; }
     *out = c;
@@ -126,7 +132,7 @@ extern "C" void lime_shutdown(lime_ctx *c)
     (void)hipFree(c->d_small); (void)hipFree(c->d_big); (void)hipFree(c->d_out);
     (void)hipFree(c->d_big_scratch);
     (void)hipFree(c->d_pool); (void)hipFree(c->d_recs); (void)hipFree(c->d_wave_cnt); (void)hipFree(c->d_counts);
-    (void)hipFree(c->d_totals); (void)hipFree(c->d_binbase);
+    (void)hipFree(c->d_totals); (void)hipFree(c->d_binbase); (void)hipFree(c->d_regbase);
     delete c;
 }
 
@@ -268,13 +274,13 @@ static bool want_binned(const lime_ctx *c, uint64_t n_own, size_t sim_bytes, int
     return sim_bytes > (256u << 20);                      // nothing known yet: tables beyond the Infinity Cache
 }
 
-static int ensure_binned(lime_ctx *c, uint64_t n_own, uint32_t n_waves, uint32_t n_prod, uint32_t n_bins, uint32_t *cap_w,
-                         hipStream_t st)
+static int ensure_binned(lime_ctx *c, uint64_t n_own, uint32_t n_waves, uint32_t n_prod, uint32_t n_bins, uint32_t bin_shift,
+                         uint32_t *cap_w, hipStream_t st)
 {
     int rc;
     const double per_wave = (double)n_own * c->pool_density / (double)n_waves;
-    uint64_t cw = (uint64_t)(per_wave * 1.10) + 512u;
-    if (c->pool_cap / n_waves > cw) cw = c->pool_cap / n_waves;           // grow-only: use all of what is there
+    uint64_t cw = ((uint64_t)(per_wave * 1.10) + 512u) & ~1ull;           // even: a wave's region starts 16-byte aligned
+    if (c->pool_cap / n_waves > cw) cw = (c->pool_cap / n_waves) & ~1ull;  // grow-only: use all of what is there
     if (cw > 0xFFFFFFF0ull) return fail(LIME_ERR_ARG, "update record pool too large for one shard");
     const size_t want = (size_t)cw * n_waves;
     if (want > c->pool_cap) {
@@ -289,6 +295,10 @@ static int ensure_binned(lime_ctx *c, uint64_t n_own, uint32_t n_waves, uint32_t
     if (!c->d_totals) {
         HIP_TRY(hipMalloc(&c->d_totals, (BIN_MAX + 1) * sizeof(uint32_t)));
         HIP_TRY(hipMalloc(&c->d_binbase, (BIN_MAX + 2) * sizeof(uint64_t)));
+    }
+    const size_t want_reg = ((size_t)n_bins << (bin_shift - REGION_SHIFT)) + 2;
+    if (bin_shift > REGION_SHIFT && want_reg > c->regbase_cap) {
+        HIP_TRY(hipStreamSynchronize(st)); if ((rc = regrow(c->d_regbase, want_reg))) return rc; c->regbase_cap = want_reg;
     }
     *cap_w = (uint32_t)cw;
     return LIME_OK;
@@ -317,9 +327,14 @@ static int fused_dev_impl(lime_ctx *c, const uint32_t *d_lcp, const uint32_t *d_
     uint32_t grid = 0, cap_w = 0, n_bins = 0, bin_shift = REGION_SHIFT;
     if (binned) {
         grid = scan_grid(ebwt, 0, 1, n_tiles, c->max_blocks);
-        while (((sim_bytes + ((size_t)1 << bin_shift) - 1) >> bin_shift) > BIN_MAX) ++bin_shift;
-        n_bins = (uint32_t)((sim_bytes + ((size_t)1 << bin_shift) - 1) >> bin_shift);
-        if ((rc = ensure_binned(c, n_own, grid * (SCAN_WG / 64), grid, n_bins, &cap_w, st))) return rc;
+        // one bin per 64 KB region for small tables; else as few levels of fan-out as fit: at most 1024 bins of 2^k
+        // regions (the bins' open output lines then merge in the L2), more bins only when k would pass its limit
+        auto bins_at = [&](uint32_t sh) { return (sim_bytes + ((size_t)1 << sh) - 1) >> sh; };
+        if (bins_at(bin_shift) > c->bin_one_level) {
+            while ((bins_at(bin_shift) > c->bin_two_level && bin_shift < BIN_SHIFT_MAX) || bins_at(bin_shift) > BIN_MAX) ++bin_shift;
+        }
+        n_bins = (uint32_t)bins_at(bin_shift);           // <= BIN_MAX: want_binned checked the table size
+        if ((rc = ensure_binned(c, n_own, grid * (SCAN_WG / 64), grid, n_bins, bin_shift, &cap_w, st))) return rc;
     }
     if ((rc = timing_mark(c, st))) return rc;
     if (keep_stats) {
@@ -342,7 +357,16 @@ static int fused_dev_impl(lime_ctx *c, const uint32_t *d_lcp, const uint32_t *d_
         launch_bin_rowscan(c->d_counts, c->d_totals, n_bins, grid, st);
         launch_scan_tiles(c->d_totals, c->d_binbase, n_bins, reinterpret_cast<unsigned long long *>(c->d_binbase + n_bins), st);
         launch_part(a, grid, c->d_binbase, c->d_recs, st);
-        launch_apply(d_sim, sim_bytes, c->d_recs, c->d_binbase, n_bins, bin_shift, st);
+        if (bin_shift > REGION_SHIFT) {                   // second level into the (by now free) pool, then regions from there
+            uint32_t *recs2 = reinterpret_cast<uint32_t *>(c->d_pool);
+            launch_part2(c->d_recs, c->d_binbase, n_bins, bin_shift, c->d_regbase, recs2, st);
+            // the base after the last region = the total (regions past the table's end hold no records)
+            HIP_TRY(hipMemcpyAsync(c->d_regbase + ((size_t)n_bins << (bin_shift - REGION_SHIFT)), c->d_binbase + n_bins, sizeof(uint64_t),
+                                   hipMemcpyDeviceToDevice, st));
+            launch_apply(d_sim, sim_bytes, recs2, c->d_regbase, bin_shift, st);
+        } else {
+            launch_apply(d_sim, sim_bytes, c->d_recs, c->d_binbase, bin_shift, st);
+        }
     }
     launch_score_big(ebwt, a, c->d_big_scratch, st);      // after k_apply: its compare-and-swaps add to the finished table
     if ((rc = timing_mark(c, st))) return rc;

@@ -22,13 +22,16 @@ constexpr uint32_t HT_BITS = 17;             // >= 2 x LIME_MAX_CLUSTER slots: t
 constexpr uint32_t HT_SIZE = 1u << HT_BITS;
 constexpr uint32_t HT_EMPTY = 0xFFFFFFFFu;
 // ---- binned table updates (bin-then-apply): the scan appends (cell, t) records to per-wave regions of a
-// pool and counts them per table bin; k_part moves them into their bins; k_apply builds each 128 KB region
-// of the table in LDS from its bin's records and writes it out once
+// pool and counts them per table bin; k_part moves them into their bins, k_part2 (bins wider than a region)
+// on into their regions; k_apply builds each 64 KB region of the table in LDS from its records and writes it
+// out once
 constexpr uint32_t BIN_MAX = 3072;           // bins: one u32 counter each in the 12 KB of LDS the CAS slots use otherwise
-constexpr uint32_t REGION_SHIFT = 17;        // k_apply builds 2^17 = 128 KB of the table per workgroup
+constexpr uint32_t REGION_SHIFT = 16;        // k_apply builds 2^16 = 64 KB of the table per workgroup
+constexpr uint32_t BIN_ONE_LEVEL = 1024;     // tables of up to this many regions: one bin per region, no second level
+constexpr uint32_t BIN_TWO_LEVEL = 1024;     // larger tables: at most this many bins of 2^k regions each (while k allows); measured best of 256..2048 on configs[2]
 constexpr uint32_t BIN_SHIFT_MAX = 25;       // bin-relative cell offset + 7 bits of t must fit 32 bits
 constexpr uint32_t CELL_BITS = 40;           // pool record: cell | t << 40
-constexpr int APPLY_WG = 1024;
+constexpr int APPLY_WG = 512;
 
 constexpr uint32_t BIG_GRID = 32;            // workgroups of k_score_big (each owns a scratch table)
 constexpr size_t BIG_SCRATCH_WORDS = (size_t)HT_SIZE + (size_t)HT_SIZE * 16u + 2u * LIME_MAX_CLUSTER;
@@ -73,8 +76,9 @@ uint32_t scan_grid(int ebwt, int mode, int binned, uint32_t n_tiles, uint32_t ma
 // records into bins, table regions from bins
 void launch_bin_rowscan(uint32_t *counts, uint32_t *totals, uint32_t n_bins, uint32_t n_prod, hipStream_t st);
 void launch_part(const ScanArgs &a, uint32_t n_prod, const uint64_t *binbase, uint32_t *out, hipStream_t st);
-void launch_apply(uint8_t *sim, size_t sim_bytes, const uint32_t *recs, const uint64_t *binbase, uint32_t n_bins,
-                  uint32_t bin_shift, hipStream_t st);
+void launch_part2(const uint32_t *recs, const uint64_t *binbase, uint32_t n_bins, uint32_t bin_shift, uint64_t *regbase,
+                  uint32_t *out, hipStream_t st);
+void launch_apply(uint8_t *sim, size_t sim_bytes, const uint32_t *recs, const uint64_t *regbase, uint32_t bin_shift, hipStream_t st);
 void launch_resolve(int mode, const ScanArgs &a, hipStream_t st);
 void launch_emit(const ScanArgs &a, hipStream_t st);
 void launch_scan_tiles(const uint32_t *cnt, uint64_t *off, uint32_t n, unsigned long long *total, hipStream_t st);

@@ -1265,13 +1265,15 @@ __global__ __launch_bounds__(256) void k_bin_rowscan(uint32_t *counts, uint32_t 
     if (lane == 0) totals[b] = run;
 }
 
+// (bins as wide as a region: the bin bases are the region bases; wider bins go through k_part2 first)
 // k_part: workgroup p moves the records of producer workgroup p (wave w those of producer wave 4p + w) from the
 // pool into their bins.  Cursors of all bins sit in LDS (start = the prefix k_bin_rowscan left); a record takes
 // its slot with one returning LDS add and goes out as 4 bytes: cell offset inside the bin | t << bin_shift.
 __global__ __launch_bounds__(SCANK_WG) void k_part(ScanArgs a, const uint64_t *binbase, uint32_t *out)
 {
-    __shared__ uint32_t cur[BIN_MAX];
-    __shared__ uint64_t base[BIN_MAX];
+    extern __shared__ uint64_t part_lds[];                      // base[n_bins] (u64), then cur[n_bins] (u32)
+    uint64_t *base = part_lds;
+    uint32_t *cur = reinterpret_cast<uint32_t *>(part_lds + a.n_bins);
     const uint32_t lane = lane_id(), wave = threadIdx.x >> 6;
     for (uint32_t b = threadIdx.x; b < a.n_bins; b += SCANK_WG) {
         cur[b] = a.counts[(size_t)b * gridDim.x + blockIdx.x];
@@ -1279,51 +1281,130 @@ __global__ __launch_bounds__(SCANK_WG) void k_part(ScanArgs a, const uint64_t *b
     }
     __syncthreads();
     const uint32_t wave_gid = blockIdx.x * (SCANK_WG / 64) + wave;
-    const uint64_t *src = a.pool + (size_t)wave_gid * a.cap_w;
+    typedef unsigned long long u64x2 __attribute__((ext_vector_type(2)));
+    const u64x2 *src = reinterpret_cast<const u64x2 *>(a.pool + (size_t)wave_gid * a.cap_w);   // cap_w is even: 16-byte aligned
     const uint32_t cnt = a.wave_cnt[wave_gid];
     const uint64_t cmask = (1ull << CELL_BITS) - 1ull;
     const uint32_t omask = (1u << a.bin_shift) - 1u;
-    constexpr uint32_t U = 4;                                   // records per lane in flight
-    for (uint32_t i0 = 0; i0 < cnt; i0 += 64u * U) {
-        uint64_t rec[U];
+    constexpr uint32_t U = 4;                                   // 16-byte loads (2 records) per lane in flight, one batch ahead
+    const uint32_t n_batch = (cnt + 128u * U - 1u) / (128u * U);
+    u64x2 nxt[U];
+    auto load = [&](uint32_t bt, u64x2 (&r)[U]) {
 #pragma unroll
         for (uint32_t u = 0; u < U; ++u) {
-            const uint32_t i = i0 + 64u * u + lane;
-            rec[u] = i < cnt ? __builtin_nontemporal_load(src + i) : ~0ull;
+            const uint32_t i = bt * 128u * U + 128u * u + 2u * lane;
+            r[u] = i < cnt ? __builtin_nontemporal_load(src + (i >> 1)) : u64x2{~0ull, ~0ull};
+            if (i + 1u >= cnt) r[u].y = ~0ull;                   // odd count: the pair's second record is not data
         }
+    };
+    if (n_batch) load(0, nxt);
+    for (uint32_t bt = 0; bt < n_batch; ++bt) {
+        u64x2 r[U];
 #pragma unroll
-        for (uint32_t u = 0; u < U; ++u)
-            if (rec[u] != ~0ull) {
-                const uint64_t cell = rec[u] & cmask;
-                const uint32_t b = (uint32_t)(cell >> a.bin_shift);
-                const uint32_t k = atomicAdd(&cur[b], 1u);
-                out[base[b] + k] = ((uint32_t)cell & omask) | ((uint32_t)(rec[u] >> CELL_BITS) << a.bin_shift);
+        for (uint32_t u = 0; u < U; ++u) r[u] = nxt[u];
+        if (bt + 1u < n_batch) load(bt + 1u, nxt);
+#pragma unroll
+        for (uint32_t u = 0; u < U; ++u) {
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {
+                const uint64_t rec = h ? r[u].y : r[u].x;
+                if (rec != ~0ull) {
+                    const uint64_t cell = rec & cmask;
+                    const uint32_t b = (uint32_t)(cell >> a.bin_shift);
+                    const uint32_t k = atomicAdd(&cur[b], 1u);
+                    out[base[b] + k] = ((uint32_t)cell & omask) | ((uint32_t)(rec >> CELL_BITS) << a.bin_shift);
+                }
             }
+        }
     }
 }
 
-// k_apply: one workgroup builds one 128 KB region of the table in LDS -- zero, add the records of the region
-// (its bin's records whose offset falls into it: a bin spans 2^(bin_shift - 17) regions, whose workgroups run on
-// one XCD next to each other so that the bin's records are fetched from HBM once and re-read from that L2),
-// exact modulo 256 per byte cell with an LDS compare-and-swap on the containing word -- and writes it out once
-// with 16-byte stores.  The table needs no clearing beforehand: every byte of it is written here.
-__global__ __launch_bounds__(APPLY_WG) void k_apply(uint8_t *sim, size_t sim_bytes, const uint32_t *recs, const uint64_t *binbase,
-                                                    uint32_t n_bins, uint32_t bin_shift)
+// k_part2: second level, one workgroup per bin (bins wider than a region only): the bin's records are counted per
+// 64 KB region of the table, the regions' bases go to regbase[bin * F2 + sub] (F2 = regions per bin), and a second
+// sweep (served by the L2: a bin's records are a few hundred KB) moves each record to its region's range of `out`.
+// Same cursor scheme as k_part; the few hundred open output lines of a bin merge in the L2.
+__global__ __launch_bounds__(1024) void k_part2(const uint32_t *recs, const uint64_t *binbase, uint32_t bin_shift,
+                                                uint64_t *regbase, uint32_t *out)
+{
+    constexpr uint32_t F2MAX = 1u << (BIN_SHIFT_MAX - REGION_SHIFT);
+    __shared__ uint32_t cnt[F2MAX], cur[F2MAX];
+    __shared__ uint32_t wsum[16];
+    const uint32_t tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
+    const uint32_t f2 = 1u << (bin_shift - REGION_SHIFT), omask = (1u << bin_shift) - 1u;
+    const uint32_t bin = blockIdx.x;
+    const uint64_t lo = binbase[bin], hi = binbase[bin + 1];
+    for (uint32_t i = tid; i < f2; i += 1024u) cnt[i] = 0u;
+    __syncthreads();
+    // the bin's records in aligned groups of four (16-byte loads); records outside [lo, hi) read as 0 = no record
+    const uint64_t q0 = lo >> 2, q1 = (hi + 3u) >> 2;
+    const uint4 *rq = reinterpret_cast<const uint4 *>(recs);
+    auto load4 = [&](uint64_t q) -> uint4 {
+        if (q >= q1) return make_uint4(0u, 0u, 0u, 0u);
+        uint4 v = rq[q];
+        const uint64_t i = q << 2;
+        if (i < lo || i + 3u >= hi) {
+            v.x = (i >= lo && i < hi) ? v.x : 0u; v.y = (i + 1u >= lo && i + 1u < hi) ? v.y : 0u;
+            v.z = (i + 2u >= lo && i + 2u < hi) ? v.z : 0u; v.w = (i + 3u >= lo && i + 3u < hi) ? v.w : 0u;
+        }
+        return v;
+    };
+    constexpr uint32_t U = 4;
+    for (uint64_t qb = q0; qb < q1; qb += 1024ull * U) {
+        uint4 r[U];
+#pragma unroll
+        for (uint32_t u = 0; u < U; ++u) r[u] = load4(qb + 1024ull * u + tid);
+#pragma unroll
+        for (uint32_t u = 0; u < U; ++u) {
+            const uint32_t w[4] = {r[u].x, r[u].y, r[u].z, r[u].w};
+#pragma unroll
+            for (int k = 0; k < 4; ++k) if (w[k] >> bin_shift) atomicAdd(&cnt[(w[k] & omask) >> REGION_SHIFT], 1u);
+        }
+    }
+    __syncthreads();
+    // exclusive prefix over the f2 <= 512 counters: thread i takes counter i
+    {
+        const uint32_t v = tid < f2 ? cnt[tid] : 0u;
+        const uint32_t incl = wave_incl_scan(v);
+        if (lane == 63u) wsum[wave] = incl;
+        __syncthreads();
+        uint32_t pre = 0;
+        for (uint32_t k = 0; k < wave; ++k) pre += wsum[k];
+        if (tid < f2) { cur[tid] = pre + incl - v; regbase[(size_t)bin * f2 + tid] = lo + pre + incl - v; }
+    }
+    __syncthreads();
+    for (uint64_t qb = q0; qb < q1; qb += 1024ull * U) {
+        uint4 r[U];
+#pragma unroll
+        for (uint32_t u = 0; u < U; ++u) r[u] = load4(qb + 1024ull * u + tid);
+#pragma unroll
+        for (uint32_t u = 0; u < U; ++u) {
+            const uint32_t w[4] = {r[u].x, r[u].y, r[u].z, r[u].w};
+#pragma unroll
+            for (int k = 0; k < 4; ++k)
+                if (w[k] >> bin_shift) {
+                    const uint32_t pos = atomicAdd(&cur[(w[k] & omask) >> REGION_SHIFT], 1u);
+                    out[lo + pos] = w[k];
+                }
+        }
+    }
+}
+
+// k_apply: one workgroup builds one 64 KB region of the table in LDS -- zero, add the region's records (exact
+// modulo 256 per byte cell: an LDS compare-and-swap on the containing word), write it out once with 16-byte
+// stores.  Two workgroups fit a CU, so one region's write-out overlaps the next one's accumulation.  The table
+// needs no clearing beforehand: every byte of it is written here.  Record: offset in its bin | t << bin_shift.
+__global__ __launch_bounds__(APPLY_WG) void k_apply(uint8_t *sim, size_t sim_bytes, const uint32_t *recs, const uint64_t *regbase,
+                                                    uint32_t bin_shift)
 {
     constexpr uint32_t RW = (1u << REGION_SHIFT) / 4u;           // words per region
     __shared__ uint4 reg4[RW / 4];
     uint32_t *reg = reinterpret_cast<uint32_t *>(reg4);
-    const uint32_t amp_shift = bin_shift - REGION_SHIFT, amp = 1u << amp_shift;
-    // blocks b and b + 8 share an XCD (round-robin dispatch; a speed matter only)
-    const uint32_t x = blockIdx.x & 7u, j = blockIdx.x >> 3;
-    const uint32_t bin = (j >> amp_shift) * 8u + x, sub = j & (amp - 1u);
-    if (bin >= n_bins) return;
-    const size_t reg_base = ((size_t)bin << bin_shift) + ((size_t)sub << REGION_SHIFT);
-    if (reg_base >= sim_bytes) return;
+    const uint32_t region = blockIdx.x;
+    const size_t reg_base = (size_t)region << REGION_SHIFT;      // grid = regions that start inside the table
     for (uint32_t i = threadIdx.x; i < RW / 4; i += APPLY_WG) reg4[i] = make_uint4(0u, 0u, 0u, 0u);
     __syncthreads();
-    const uint64_t lo = binbase[bin], hi = binbase[bin + 1];
-    const uint32_t omask = (1u << bin_shift) - 1u, rmask = (1u << REGION_SHIFT) - 1u;
+    const uint64_t lo = regbase[region], hi = regbase[region + 1];
+    const uint32_t rmask = (1u << REGION_SHIFT) - 1u;
     constexpr uint32_t U = 4;
     for (uint64_t i0 = lo; i0 < hi; i0 += (uint64_t)APPLY_WG * U) {
         uint32_t r[U];
@@ -1334,9 +1415,9 @@ __global__ __launch_bounds__(APPLY_WG) void k_apply(uint8_t *sim, size_t sim_byt
         }
 #pragma unroll
         for (uint32_t u = 0; u < U; ++u) {
-            const uint32_t off = r[u] & omask, t = r[u] >> bin_shift;
-            if (t != 0u && (off >> REGION_SHIFT) == sub) {
-                const uint32_t o = off & rmask, sh = (o & 3u) * 8u;
+            const uint32_t t = r[u] >> bin_shift;
+            if (t != 0u) {
+                const uint32_t o = r[u] & rmask, sh = (o & 3u) * 8u;
                 uint32_t *w = &reg[o >> 2];
                 uint32_t seen = *w;
                 for (;;) {
@@ -1654,15 +1735,19 @@ void launch_bin_rowscan(uint32_t *counts, uint32_t *totals, uint32_t n_bins, uin
 
 void launch_part(const ScanArgs &a, uint32_t n_prod, const uint64_t *binbase, uint32_t *out, hipStream_t st)
 {
-    hipLaunchKernelGGL(k_part, dim3(n_prod), dim3(SCANK_WG), 0, st, a, binbase, out);
+    hipLaunchKernelGGL(k_part, dim3(n_prod), dim3(SCANK_WG), (size_t)a.n_bins * 12u, st, a, binbase, out);
 }
 
-void launch_apply(uint8_t *sim, size_t sim_bytes, const uint32_t *recs, const uint64_t *binbase, uint32_t n_bins,
-                  uint32_t bin_shift, hipStream_t st)
+void launch_part2(const uint32_t *recs, const uint64_t *binbase, uint32_t n_bins, uint32_t bin_shift, uint64_t *regbase,
+                  uint32_t *out, hipStream_t st)
 {
-    const uint32_t amp = 1u << (bin_shift - REGION_SHIFT);
-    const uint32_t grid = (n_bins + 7u) / 8u * 8u * amp;
-    hipLaunchKernelGGL(k_apply, dim3(grid), dim3(APPLY_WG), 0, st, sim, sim_bytes, recs, binbase, n_bins, bin_shift);
+    hipLaunchKernelGGL(k_part2, dim3(n_bins), dim3(1024), 0, st, recs, binbase, bin_shift, regbase, out);
+}
+
+void launch_apply(uint8_t *sim, size_t sim_bytes, const uint32_t *recs, const uint64_t *regbase, uint32_t bin_shift, hipStream_t st)
+{
+    const uint32_t grid = (uint32_t)((sim_bytes + ((size_t)1 << REGION_SHIFT) - 1) >> REGION_SHIFT);
+    hipLaunchKernelGGL(k_apply, dim3(grid), dim3(APPLY_WG), 0, st, sim, sim_bytes, recs, regbase, bin_shift);
 }
 
 void launch_tile(int ebwt, int mode, const ScanArgs &a, uint32_t max_blocks, hipStream_t st)

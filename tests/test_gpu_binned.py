@@ -51,8 +51,28 @@ def test_binned_fused_vs_oracle(bctx, n, nr, ng, mode):
         assert np.array_equal(sim, exp)
 
 
+@pytest.mark.parametrize("levels,nr,ng", [("1,1", 3000, 300), ("2,3", 5000, 1200), ("4,7", 40000, 700), ("1,2", 1, 1)])
+def test_binned_two_levels_on_small_tables(monkeypatch, levels, nr, ng):
+    """LIME_BIN_LEVELS forces bins of several regions (second partition level, k_part2) on tables of a few regions:
+    1 bin for the whole table, 3 bins of 32 regions, ... ; one cell only"""
+    import lime_amd
+    monkeypatch.setenv("LIME_UPDATE_PATH", "bin")
+    monkeypatch.setenv("LIME_BIN_LEVELS", levels)
+    c = lime_amd.Context()
+    try:
+        n = 1200000
+        lcp, da, eb = O.synth(500 + nr, 0, n, nr, ng, 16, 1)
+        cl, nc, ml = O.detect(lcp, da, nr, 16)
+        for e in (eb, None):
+            exp = O.score(da, e, cl, nr, ng, threads=4)
+            sim, gnc, gml = c.fused(lcp, da, e, nr, ng, 16)
+            assert (gnc, gml) == (nc, ml) and np.array_equal(sim, exp)
+    finally:
+        c.close()
+
+
 def test_binned_bins_wider_than_a_region(bctx):
-    """a table of more than 3072 x 128 KB: bins of 256 KB, two region workgroups share each bin's records"""
+    """a table of more than 1024 regions of 64 KB: 430 bins of 16 regions, second level"""
     n, nr, ng = 3000000, 150000, 3000                      # 450 MB
     lcp, da, _ = O.synth(31, 0, n, nr, ng, 16, 0)
     cl, nc, ml = O.detect(lcp, da, nr, 16)
