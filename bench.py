@@ -2,25 +2,32 @@
 """bench.py -- throughput of the LiME hot path (ClusterLCP + ClusterBWT_DA) on MI355X.
 
 Metric (BASELINE.json): eBWT symbols/s processed by detect+score, arrays resident in HBM.
-Workload at N=1: BASELINE.json configs[1] -- synthetic S of 10^8 symbols, 10^5 reads x 500
-genomes, alpha=16, EBWT=1 (generator: SURVEY.md 8d, seed 42, identical on CPU and GPU).
-A step = zero the score table + one fused scan of the rank's shard (+ for N>1 the one
-exchange of the path: a reduce-scatter of the per-rank uint8 tables, sum mod 256, by read-row
-blocks -- SURVEY 8e -- issued asynchronously so that it runs under the next step's scan; two
-table buffers alternate).
-N>1 (launched by torch.distributed.run, one rank per GPU): WEAK scaling -- every rank owns
-10^8 symbols of a 10^8*N collection cut by contiguous tile-aligned position ranges with a
-read-ahead halo; no other data-path collective.
 
-Prints ONE JSON line on rank 0 (see the driver's contract) with two extra objects:
-  roofline     HBM bound: algorithmic bytes (9 B/symbol x symbols per launch) / average
-               duration of the scan kernel k_tile measured with HIP events on its stream
-  cpu_baseline the reference's own OpenMP programs (oracle/_ref, kind "reference") or the
-               oracle port, timed on this box's host cores on the same workload
+N=1 (default `python bench.py`): BASELINE.json configs[2], the largest single-GPU configuration -- synthetic S of
+10^9 symbols, 10^6 reads x 5000 genomes (5 GB table), alpha=16, EBWT=0 (8 B/symbol), generator of SURVEY.md 8d
+(seed 42, identical on CPU and GPU).  A step = one fused pass: scan + score + the finished score table (cleared or
+rebuilt every step).  The same JSON line carries, under "also", configs[1] (10^8, 10^5 x 500, EBWT=1), the
+"clustered" generator on that shape, and an N = 10^10 single-GPU pass (10^6 x 1000 table) -- the one-GPU point
+of the scaling series.
+
+N>1 (launched by torch.distributed.run, one rank per GPU): STRONG scaling of the north_star series -- a fixed
+collection of 10^10 symbols (10^6 reads x 1000 genomes, EBWT=0) cut into contiguous tile-aligned position ranges
+with a read-ahead halo; a step = every rank's pass over its range + the ONE exchange of the path, a reduce-scatter of
+the per-rank uint8 tables (sum modulo 256, by read-row blocks) issued through the C ABI (lime_comm_*: RCCL
+ncclReduceScatter(ncclUint8, ncclSum)); the step ends when the exchange has completed (exposed -- what a single pass
+pays).  `also.overlapped` repeats the series with the exchange of step k running under the scan of step k+1 (two
+table buffers), which is what the four passes of LiME_paired.sh allow.  `--scaling weak` keeps configs[2] per GPU.
+
+Prints ONE JSON line on rank 0 (the driver's contract) with two extra objects:
+  roofline     HBM bound: algorithmic bytes (8 or 9 B/symbol x symbols per launch) / average duration of the scan
+               kernel k_scan measured with HIP events on its stream; also the whole pass
+  cpu_baseline the reference's own OpenMP programs (oracle/_ref, kind "reference") on a bounded sample of the
+               same workload, all host cores and one thread, with the reference's own timer lines
 """
 import argparse
 import json
 import os
+import re
 import subprocess
 import sys
 import tempfile
@@ -29,59 +36,172 @@ import time
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
-N_PER_GPU = 100_000_000
-N_READS, N_REFS, ALPHA, SEED = 100_000, 500, 16, 42
-BYTES_PER_SYMBOL = 9            # lcp 4 + da 4 + ebwt 1 (EBWT=1), each input byte read once
+ALPHA, SEED = 16, 42
 HBM_PEAK_GBS = 8000.0           # MI355X_MICROARCH.md: 8.0 TB/s spec
+WORKLOADS = {
+    # name: symbols, reads, genomes, EBWT, generator mode, description
+    "c3": dict(n=1_000_000_000, nr=1_000_000, ng=5000, ebwt=0, mode=0, what="BASELINE.json configs[2]"),
+    "c2": dict(n=100_000_000, nr=100_000, ng=500, ebwt=1, mode=0, what="BASELINE.json configs[1]"),
+    "c2_clustered": dict(n=100_000_000, nr=100_000, ng=500, ebwt=1, mode=1, what="configs[1] shape, clustered generator (SURVEY 8d)"),
+    "n1e10": dict(n=10_000_000_000, nr=1_000_000, ng=1000, ebwt=0, mode=0, what="north_star scaling series, N = 10^10"),
+}
 
 
-def cpu_baseline(lcp_t, da_t, eb_t, n, sample_n):
-    """Reference binaries (or the oracle port) on the first `sample_n` symbols, all host cores."""
+def describe(wl, n_total, world):
+    return (f"synthetic S (seed {SEED}, generator mode {wl['mode']}): {n_total} symbols, {wl['nr']} reads x {wl['ng']} genomes "
+            f"({wl['nr'] * wl['ng'] / 1e9:.2f} GB table), alpha={ALPHA}, EBWT={wl['ebwt']} ({8 + wl['ebwt']} B/symbol) -- {wl['what']}"
+            + (f"; cut into {world} position ranges" if world > 1 else ""))
+
+
+def cpu_baseline(wl, lcp_t, da_t, eb_t, n, sample_n):
+    """The reference's programs on the first `sample_n` symbols (bounded: about 10-30 s of CPU work), all cores the
+    box gives this process and one thread; wall time of the two processes and the reference's own timer lines."""
     import numpy as np
-    # the GPU box gives one GPU's share of the host: at most 16 cores (the pool's sizing rule)
     try:
-        cores = len(os.sched_getaffinity(0))
+        aff = sorted(os.sched_getaffinity(0))
     except AttributeError:
-        cores = os.cpu_count() or 1
-    cores = max(1, min(cores, 16))
+        aff = list(range(os.cpu_count() or 1))
+    cores = max(1, min(len(aff), 16))          # the pool's sizing rule: 16 cores per GPU
     sample_n = min(sample_n, n)
+    ref = os.path.join(ROOT, "oracle", "_ref")
+    bwt = "ClusterBWT_DA" if wl["ebwt"] else "ClusterBWT_DA_e0"
+    sample = (f"first {sample_n} symbols of the bench workload (seed {SEED}, mode {wl['mode']}), {wl['nr']}x{wl['ng']}, "
+              f"alpha {ALPHA}, EBWT={wl['ebwt']}")
     lcp = lcp_t[:sample_n].cpu().numpy().view(np.uint32)
     da = da_t[:sample_n].cpu().numpy().view(np.uint32)
-    eb = eb_t[:sample_n].cpu().numpy()
-    ref = os.path.join(ROOT, "oracle", "_ref")
-    sample = f"first {sample_n} symbols of the bench workload (seed {SEED}), {N_READS}x{N_REFS}, alpha {ALPHA}, EBWT=1"
-    if os.path.exists(os.path.join(ref, "ClusterLCP")) and os.path.exists(os.path.join(ref, "ClusterBWT_DA")):
-        with tempfile.TemporaryDirectory(dir="/tmp") as td:
-            base = os.path.join(td, "S.fasta")
-            lcp.tofile(base + ".lcp"); da.tofile(base + ".da"); eb.tofile(base + ".ebwt")
+    eb = eb_t[:sample_n].cpu().numpy() if eb_t is not None else None
+    if not (os.path.exists(f"{ref}/ClusterLCP") and os.path.exists(f"{ref}/{bwt}")):
+        from oracle import oracle_py as O
+        t0 = time.perf_counter()
+        cl, nc, ml = O.detect(lcp, da, wl["nr"], ALPHA)
+        O.score(da, eb, cl, wl["nr"], wl["ng"], threads=cores)
+        t1 = time.perf_counter()
+        return {"value": sample_n / (t1 - t0), "unit": "symbols/s", "cores": cores, "kind": "port", "sample": sample}
+
+    def timers(text):
+        return [ln.strip() for ln in text.splitlines() if re.match(r"\s*(TIME (clusterAnalyze|clusterChoose)|Time:)", ln)]
+
+    runs = {}
+    with tempfile.TemporaryDirectory(dir="/tmp") as td:
+        base = os.path.join(td, "S.fasta")
+        lcp.tofile(base + ".lcp"); da.tofile(base + ".da")
+        if eb is not None:
+            eb.tofile(base + ".ebwt")
+        for label, thr in (("all_cores", cores), ("four_threads", min(4, cores)), ("one_thread", 1)):   # README.md:145 uses 4
             t0 = time.perf_counter()
-            subprocess.run([f"{ref}/ClusterLCP", base, str(N_READS), str(N_REFS), str(ALPHA), str(cores)],
-                           check=True, capture_output=True, cwd=td, timeout=900)
+            p1 = subprocess.run([f"{ref}/ClusterLCP", base, str(wl["nr"]), str(wl["ng"]), str(ALPHA), str(thr)],
+                                check=True, capture_output=True, cwd=td, timeout=1500)
             t1 = time.perf_counter()
-            subprocess.run([f"{ref}/ClusterBWT_DA", base, "100", "0.25", str(cores)],
-                           check=True, capture_output=True, cwd=td, timeout=900)
+            p2 = subprocess.run([f"{ref}/{bwt}", base, "100", "0.25", str(thr)],
+                                check=True, capture_output=True, cwd=td, timeout=1500)
             t2 = time.perf_counter()
-        return {"value": sample_n / (t2 - t0), "unit": "symbols/s", "cores": cores, "kind": "reference",
-                "sample": sample + "; wall time of the reference's ClusterLCP + ClusterBWT_DA processes, files in page cache",
-                "seconds": {"ClusterLCP": t1 - t0, "ClusterBWT_DA": t2 - t1}}
-    from oracle import oracle_py as O
+            runs[label] = {"threads": thr, "symbols_per_s": sample_n / (t2 - t0),
+                           "wall_s": {"ClusterLCP": t1 - t0, "ClusterBWT_DA": t2 - t1},
+                           "reference_timers": {"ClusterLCP": timers(p1.stdout.decode(errors="replace")),
+                                                "ClusterBWT_DA": timers(p2.stdout.decode(errors="replace") + p2.stderr.decode(errors="replace"))}}
+    best = max(runs.values(), key=lambda x: x["symbols_per_s"])      # the reference's best thread count on this box is the baseline
+    return {"value": best["symbols_per_s"], "unit": "symbols/s", "cores": best["threads"], "kind": "reference",
+            "sample": sample + "; wall time of the reference's ClusterLCP + ClusterBWT_DA processes (files in page cache; "
+                               "ClusterBWT_DA's wall includes allocating/zeroing the table and the single-threaded clusterChoose)",
+            "nproc": os.cpu_count(), "affinity_cpus": len(aff), "runs": runs}
+
+
+def run_pass_series(torch, lime_amd, ldist, wl, n_total, steps, warmup, world, rank, dev, comm, overlap):
+    """K timed steps of the workload on this rank's position range; returns (seconds, per-step parts, stats, n_own)."""
+    lo, hi, hi_halo = ldist.shard_ranges(n_total, world)[rank]
+    n_own, n_avail = hi - lo, hi_halo - lo
+    ctx = lime_amd.Context(dev.index)
+    lcp = torch.empty(n_avail, dtype=torch.int32, device=dev)
+    da = torch.empty(n_avail, dtype=torch.int32, device=dev)
+    eb = torch.empty(n_avail, dtype=torch.uint8, device=dev) if wl["ebwt"] else None
+    sim_bytes = lime_amd.sim_bytes(wl["nr"], wl["ng"])
+    blk_bytes = ldist.table_block_bytes(sim_bytes, world)
+    nbuf = 2 if (world > 1 and overlap) else 1
+    sims = [torch.zeros(blk_bytes * world, dtype=torch.uint8, device=dev) for _ in range(nbuf)]
+    blks = [torch.empty(blk_bytes, dtype=torch.uint8, device=dev) for _ in range(nbuf)] if world > 1 else []
+    stream = torch.cuda.current_stream().cuda_stream
+    ex_stream = torch.cuda.Stream(device=dev) if (world > 1 and overlap) else None
+    done = [None] * nbuf                       # event: the exchange that read sims[b] has completed
+    ctx.synth_dev(SEED, lo, n_avail, wl["nr"], wl["ng"], ALPHA, wl["mode"], lcp, da, eb, stream)
+    torch.cuda.synchronize()
+    counter = [0]
+
+    def step():
+        b = counter[0] % nbuf
+        counter[0] += 1
+        if done[b] is not None:                # the table buffer is free again (stream-side wait)
+            torch.cuda.current_stream().wait_event(done[b])
+            done[b] = None
+        ctx.fused_dev(lcp, da, eb, n_own, n_avail, hi_halo == n_total, wl["nr"], wl["ng"], ALPHA, sims[b], True, stream)
+        if world > 1:
+            if ex_stream is None:              # exposed: the exchange follows the pass on the same stream
+                comm.reduce_scatter_tables(sims[b], blks[b], blk_bytes, stream)
+            else:                              # overlapped: on its own stream, under the next step's scan
+                ev = torch.cuda.Event(); ev.record()
+                ex_stream.wait_event(ev)
+                comm.reduce_scatter_tables(sims[b], blks[b], blk_bytes, ex_stream.cuda_stream)
+                done[b] = torch.cuda.Event(); done[b].record(ex_stream)
+
+    def barrier():
+        torch.cuda.synchronize()
+        if world > 1:
+            comm.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(warmup):
+        step()
+    s, rc = ctx.stats(stream)                  # also settles the update path / pool size before the timed region
+    if rc:
+        sys.exit(f"scan failed: rc={rc}")
+    for _ in range(2 if warmup else 0):
+        step()
+    s, rc = ctx.stats(stream)
+    ctx.set_timing(True)
+    barrier()
     t0 = time.perf_counter()
-    cl, nc, ml = O.detect(lcp, da, N_READS, ALPHA)
-    O.score(da, eb, cl, N_READS, N_REFS, threads=cores)
-    t1 = time.perf_counter()
-    return {"value": sample_n / (t1 - t0), "unit": "symbols/s", "cores": cores, "kind": "port", "sample": sample}
+    for _ in range(steps):
+        step()
+    barrier()
+    dt = time.perf_counter() - t0
+    parts, launches = ctx.get_timing_ex()
+    ctx.set_timing(False)
+    s, rc = ctx.stats(stream)
+    if rc:
+        sys.exit(f"scan failed: rc={rc}")
+    res = {"dt": dt, "parts": parts, "launches": launches, "n_own": n_own, "n_clusters": int(s.n_clusters), "max_len": int(s.max_len),
+           "updates": int(s.n_updates), "binned": bool(s.wave_records_max > 0), "lcp": lcp, "da": da, "eb": eb}
+    ctx.close()
+    return res
+
+
+def summarize(wl, r, n_total, steps):
+    bps = 8 + wl["ebwt"]
+    scan_ms, pass_ms = r["parts"]["scan"], r["parts"]["pass"]
+    return {"workload": describe(wl, n_total, 1), "ms_per_step": r["dt"] / steps * 1e3, "symbols_per_s": n_total * steps / r["dt"],
+            "update_path": "binned (records -> bins -> table regions built in LDS)" if r["binned"] else "compare-and-swap on the table",
+            "kernel_ms_avg": scan_ms, "kernel_GBps": bps * r["n_own"] / scan_ms / 1e6 if scan_ms else None,
+            "frac_of_hbm_peak": bps * r["n_own"] / scan_ms / 1e6 / HBM_PEAK_GBS if scan_ms else None,
+            "pass_ms_avg": pass_ms, "pass_GBps": bps * r["n_own"] / pass_ms / 1e6 if pass_ms else None,
+            "parts_ms": r["parts"], "n_clusters": r["n_clusters"], "table_updates": r["updates"]}
 
 
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
-    ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--n", type=int, default=N_PER_GPU, help="symbols per GPU")
-    ap.add_argument("--mode", type=int, default=0, help="synthetic generator: 0 iid (configs[1]), 1 block-correlated")
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--workload", default=None, choices=sorted(WORKLOADS), help="default: c3 at N=1, n1e10 (strong) at N>1")
+    ap.add_argument("--scaling", default=None, choices=["strong", "weak"], help="N>1: strong (fixed --n-total, default) or weak (workload per GPU)")
+    ap.add_argument("--n-total", type=float, default=None, help="symbols of the whole collection (strong scaling)")
+    ap.add_argument("--n", type=float, default=None, help="symbols per GPU (overrides the workload's size)")
     ap.add_argument("--no-cpu", action="store_true", help="skip the cpu_baseline leg")
-    ap.add_argument("--cpu-sample", type=int, default=N_PER_GPU)
+    ap.add_argument("--no-also", action="store_true", help="skip the secondary workloads")
+    ap.add_argument("--cpu-sample", type=int, default=200_000_000)
     args = ap.parse_args()
+
+    for var in ("LIME_ABLATE", "LIME_MAX_BLOCKS", "LIME_POOL_DENSITY", "LIME_BIN_LEVELS"):
+        if os.environ.get(var):
+            sys.exit(f"bench.py refuses to run with {var} set: it changes what is measured")
 
     import torch
     import lime_amd
@@ -90,125 +210,108 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
-    if world != args.gpus:
-        if world == 1 and args.gpus > 1:
-            sys.exit("bench.py --gpus N>1 must be launched with torch.distributed.run (one rank per GPU)")
+    if world != args.gpus and world == 1 and args.gpus > 1:
+        sys.exit("bench.py --gpus N>1 must be launched with torch.distributed.run (one rank per GPU)")
     if not torch.cuda.is_available():
         sys.exit("bench.py needs an MI355X: there is no CPU path")
-    # rehearsal hooks for a one-GPU box (not used by the driver): LIME_BENCH_BACKEND=gloo runs the N>1 control
-    # flow with every rank on GPU 0 and the exchange staged through the host
+    # rehearsal hook for a one-GPU box (not used by the driver): LIME_BENCH_BACKEND=gloo runs the N>1 control flow
+    # with every rank on GPU 0 and the exchange staged through the host (RCCL wants one GPU per rank)
     backend = os.environ.get("LIME_BENCH_BACKEND", "nccl")
     if backend != "nccl":
         local = 0
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
-    use_rs = False
+    comm = None
     if world > 1:
         import torch.distributed as dist
         if backend == "nccl":
             dist.init_process_group("nccl", device_id=dev)
+            comm = ldist.Comm(rank, world, dev)             # RCCL through the C ABI (lime_comm_*); bootstrap over torch.distributed
         else:
             dist.init_process_group(backend)
-        use_rs = ldist.check_uint8_sum_wraps(dev)
+            comm = ldist.HostComm(rank, world, dev)
+        comm.check_uint8_sum_wraps()
 
-    n_total = args.n * world
-    lo, hi, hi_halo = ldist.shard_ranges(n_total, world)[rank]
-    n_own, n_avail = hi - lo, hi_halo - lo
-    ctx = lime_amd.Context(local)
-    lcp = torch.empty(n_avail, dtype=torch.int32, device=dev)
-    da = torch.empty(n_avail, dtype=torch.int32, device=dev)
-    eb = torch.empty(n_avail, dtype=torch.uint8, device=dev)
-    sim_bytes = lime_amd.sim_bytes(N_READS, N_REFS)
-    blk_bytes = ldist.table_block_bytes(sim_bytes, world)
-    nbuf = 2 if world > 1 else 1
-    sims = [torch.zeros(blk_bytes * world, dtype=torch.uint8, device=dev) for _ in range(nbuf)]
-    blks = [torch.empty(blk_bytes, dtype=torch.uint8, device=dev) for _ in range(nbuf)] if world > 1 else []
-    pending = [None] * nbuf
-    sim = sims[0]
-    stream = torch.cuda.current_stream().cuda_stream
-    ctx.synth_dev(SEED, lo, n_avail, N_READS, N_REFS, ALPHA, args.mode, lcp, da, eb, stream)
-    torch.cuda.synchronize()
-
-    counter = [0]
-
-    def step():
-        b = counter[0] % nbuf
-        counter[0] += 1
-        if pending[b] is not None:            # the exchange that read this buffer two steps ago (stream-side wait)
-            pending[b].wait()
-            pending[b] = None
-        ctx.fused_dev(lcp, da, eb, n_own, n_avail, hi_halo == n_total, N_READS, N_REFS, ALPHA, sims[b], True, stream)
-        if world > 1:
-            if use_rs:
-                pending[b] = ldist.reduce_scatter_tables(sims[b], blks[b], async_op=True)
-            else:                             # backend without a wrapping uint8 reduce-scatter: whole-table all-reduce
-                pending[b] = dist.all_reduce(sims[b], op=dist.ReduceOp.SUM, async_op=True)
-
-    def barrier():
-        for b in range(nbuf):
-            if pending[b] is not None:
-                pending[b].wait()
-                pending[b] = None
-        torch.cuda.synchronize()
-        if world > 1:
-            dist.barrier()
-        torch.cuda.synchronize()
-
-    for _ in range(args.warmup):
-        step()
-    s, rc = ctx.stats(stream)
-    if rc:
-        sys.exit(f"scan failed: rc={rc}")
-    ctx.set_timing(True)
-    barrier()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        step()
-    barrier()
-    dt = time.perf_counter() - t0
-    scan_ms, launches = ctx.get_timing()
-    ctx.set_timing(False)
-    s, rc = ctx.stats(stream)
-    n_clusters, max_len = s.n_clusters, s.max_len
+    scaling = args.scaling or ("strong" if world > 1 else "weak")
+    wname = args.workload or ("c3" if (world == 1 or scaling == "weak") else "n1e10")
+    wl = dict(WORKLOADS[wname])
+    if world > 1 and scaling == "strong":
+        n_total = int(args.n_total or wl["n"])
+    else:
+        n_total = int(args.n or wl["n"]) * world
+    r = run_pass_series(torch, lime_amd, ldist, wl, n_total, args.steps, args.warmup, world, rank, dev, comm, overlap=False)
+    dt, n_clusters, max_len = r["dt"], r["n_clusters"], r["max_len"]
     if world > 1:
-        t = torch.tensor([dt], dtype=torch.float64, device=dev)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        dt = float(t.item())
-        n_clusters, max_len = ldist.combine_counters(n_clusters, max_len, dev)
+        dt = comm.max_float(dt)
+        n_clusters, max_len = comm.combine_counters(n_clusters, max_len)
 
+    out = None
     if rank == 0:
-        value = n_total * args.steps / dt
-        achieved = BYTES_PER_SYMBOL * n_own / (scan_ms * 1e-3) / 1e9 if scan_ms > 0 else 0.0
-        traffic = None
-        tfile = os.path.join(ROOT, "profiles", "traffic.json")     # rocprofv3 --pmc result, see DESIGN.md
-        if os.path.exists(tfile) and args.n == N_PER_GPU and args.mode == 0:
+        bps = 8 + wl["ebwt"]
+        scan_ms, pass_ms = r["parts"]["scan"], r["parts"]["pass"]
+        achieved = bps * r["n_own"] / (scan_ms * 1e-3) / 1e9 if scan_ms > 0 else 0.0
+        traffic, tsrc = None, None
+        tfile = os.path.join(ROOT, "profiles", "traffic.json")        # rocprofv3 --pmc results, see DESIGN.md
+        if os.path.exists(tfile) and world == 1:
             try:
-                traffic = json.load(open(tfile)).get("hbm_bytes_per_launch")
+                t = json.load(open(tfile)).get(wname)
+                if t and t.get("symbols") == n_total:
+                    traffic, tsrc = t["hbm_bytes_per_launch"], f"profiles/traffic.json[{wname}] ({t.get('from', '')}); file, not measured in this run"
             except Exception:
                 traffic = None
+        kname = f"lime::k_scan<{wl['ebwt']}, 0, {1 if r['binned'] else 0}>"
         out = {
-            "metric": "eBWT symbols/s processed (ClusterLCP+ClusterBWT_DA)", "value": value, "unit": "symbols/s",
+            "metric": "eBWT symbols/s processed (ClusterLCP+ClusterBWT_DA)", "value": n_total * args.steps / dt, "unit": "symbols/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3,
-            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "u8", "data": "synthetic",
-            "config": {"workload": f"synthetic S (seed {SEED}, generator mode {args.mode}): {args.n} symbols per GPU, "
-                                   f"{N_READS} reads x {N_REFS} genomes, alpha={ALPHA}, EBWT=1 (BASELINE.json configs[1])",
-                       "symbols_total": n_total, "sharding": f"position ranges x{world}" + ((f"; tables combined by an asynchronous uint8 {'reduce-scatter' if use_rs else 'all-reduce'} per step") if world > 1 else ""), "n_clusters": int(n_clusters),
-                       "max_cluster_len": int(max_len), "table_updates": int(s.n_updates)},
-            "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "kernel": "lime::k_scan<1, 0>",
-                         "kernel_ms_avg": scan_ms, "launches_timed": launches,
-                         "algorithmic_bytes_per_launch": BYTES_PER_SYMBOL * n_own},
+            "higher_is_better": True, "scaling": scaling, "vs_baseline": None, "dtype": "u8", "data": "synthetic",
+            "config": {"workload": describe(wl, n_total, world), "symbols_total": n_total,
+                       "sharding": (f"position ranges x{world}; tables combined by one uint8 reduce-scatter per step through the C ABI "
+                                    f"(RCCL), exposed (the step waits for it)") if world > 1 else "one GPU",
+                       "update_path": "binned (records -> bins -> table regions built in LDS)" if r["binned"] else "compare-and-swap on the table",
+                       "n_clusters": int(n_clusters), "max_cluster_len": int(max_len), "table_updates_rank0": r["updates"]},
+            "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
+                         "traffic": traffic, "traffic_source": tsrc, "kernel": kname, "kernel_ms_avg": scan_ms,
+                         "launches_timed": r["launches"], "algorithmic_bytes_per_launch": bps * r["n_own"],
+                         "pass_ms_avg": pass_ms, "pass_achieved": bps * r["n_own"] / (pass_ms * 1e-3) / 1e9 if pass_ms else None,
+                         "pass_parts_ms": r["parts"]},
         }
-        if world == 1 and not args.no_cpu:
-            try:
-                out["cpu_baseline"] = cpu_baseline(lcp, da, eb, n_own, args.cpu_sample)
-            except Exception as e:   # a missing baseline must not hide the GPU number
-                out["cpu_baseline"] = {"value": None, "unit": "symbols/s", "cores": os.cpu_count(), "kind": "port",
-                                       "sample": f"failed: {e}"}
+    if world == 1 and rank == 0 and not args.no_cpu:
+        try:
+            out["cpu_baseline"] = cpu_baseline(wl, r["lcp"], r["da"], r["eb"], r["n_own"], args.cpu_sample)
+        except Exception as e:   # a missing baseline must not hide the GPU number
+            out["cpu_baseline"] = {"value": None, "unit": "symbols/s", "cores": os.cpu_count(), "kind": "port", "sample": f"failed: {e}"}
+    del r
+    torch.cuda.empty_cache()
+
+    if not args.no_also:
+        also = {}
+        if world == 1:
+            for name in ("c2", "c2_clustered", "n1e10"):
+                if name == wname:
+                    continue
+                w2 = WORKLOADS[name]
+                try:
+                    k = max(3, args.steps // 2) if name == "n1e10" else max(10, args.steps)
+                    r2 = run_pass_series(torch, lime_amd, ldist, w2, w2["n"], k, 2, 1, 0, dev, None, overlap=False)
+                    also[name] = summarize(w2, r2, w2["n"], k)
+                    del r2
+                except Exception as e:
+                    also[name] = {"failed": str(e)}
+                torch.cuda.empty_cache()
+        else:
+            r2 = run_pass_series(torch, lime_amd, ldist, wl, n_total, args.steps, args.warmup, world, rank, dev, comm, overlap=True)
+            dt2 = comm.max_float(r2["dt"])
+            also["overlapped"] = {"what": "the same series with the exchange of step k under the scan of step k+1 (two table buffers)",
+                                  "value": n_total * args.steps / dt2, "ms_per_step": dt2 / args.steps * 1e3}
+            del r2
+        if rank == 0:
+            out["also"] = also
+    if rank == 0:
         print(json.dumps(out), flush=True)
     if world > 1:
+        comm.close()
+        import torch.distributed as dist
         dist.destroy_process_group()
-    ctx.close()
 
 
 if __name__ == "__main__":

@@ -186,6 +186,33 @@ int lime_get_timing(lime_ctx *ctx, double *scan_ms_avg, uint64_t *launches);
  * table build included), [2] everything after the scan kernel, [3] everything before it */
 int lime_get_timing_ex(lime_ctx *ctx, double ms_avg[4], uint64_t *launches);
 
+/* ---- multi-GPU: the one exchange step of the path (RCCL over xGMI; librccl is loaded on first use) ---- *
+ * The reference partitions positions over OpenMP threads (ClusterLCP.cpp:150-161, skip :196-202, straddle
+ * :246-264) and adds into ONE shared table with `omp atomic` (ClusterBWT_DA.cpp:178-184, 243-248).  Here every
+ * GPU scans one position range (lime_fused_dev with n_own / n_avail / eof) into its own table and the tables are
+ * summed modulo 256 -- addition modulo 256 is associative, so the result is bit-identical.
+ * One process per GPU: rank 0 calls lime_comm_unique_id, carries the bytes to the others, all call lime_comm_init
+ * (the process's current HIP device is the rank's GPU).  Error text: lime_comm_error(). */
+#define LIME_COMM_ID_BYTES 128
+typedef struct lime_comm lime_comm;
+int  lime_comm_unique_id(uint8_t id[LIME_COMM_ID_BYTES]);
+int  lime_comm_init(const uint8_t id[LIME_COMM_ID_BYTES], int rank, int world, lime_comm **out);
+void lime_comm_destroy(lime_comm *comm);
+const char *lime_comm_error(void);
+/* d_sim: world * block_bytes bytes (the table, zero padded); rank r receives block r of the sum in d_block
+ * (ncclReduceScatter, ncclUint8, ncclSum).  Asynchronous on `stream`. */
+int  lime_comm_reduce_scatter_tables(lime_comm *comm, const uint8_t *d_sim, uint8_t *d_block, size_t block_bytes, void *stream);
+int  lime_comm_allreduce_tables(lime_comm *comm, uint8_t *d_sim, size_t bytes, void *stream);   /* whole table everywhere, in place */
+/* d_sum_max: device array of two u64: [0] summed over the ranks (cluster count), [1] maximum (longest cluster) */
+int  lime_comm_combine_counters(lime_comm *comm, uint64_t *d_sum_max, void *stream);
+
+/* One process, n_dev GPUs (devices == NULL: 0 .. n_dev-1): lime_fused of host arrays with the collection cut into
+ * n_dev position ranges, one reduce-scatter of the tables by read-row blocks, the blocks copied back into `sim`.
+ * What the drop-in ClusterBWT_DA-side programs use under LIME_GPUS=k. */
+int  lime_fused_multi(int n_dev, const int *devices, const uint32_t *lcp, const uint32_t *da, const uint8_t *ebwt,
+                      uint64_t n, uint32_t n_reads, uint32_t n_refs, uint32_t alpha, uint8_t *sim,
+                      uint64_t *n_clusters, uint64_t *max_len);
+
 /* ---- pure host helpers (no device work; used by the CLIs and by CPU-side tests) -------- */
 uint8_t lime_sym_index(uint8_t byte);                              /* ClusterBWT_DA.cpp:455-470 */
 uint8_t lime_pair_score(const uint8_t cr[16], const uint8_t cg[16]); /* :129-177, host build of the device routine */

@@ -69,6 +69,14 @@ SYMBOLS = {
     "lime_fused_stream": (_i, [_vp, _vp, _vp, _vp, _u64, _u32, _u32, _u32, _u64, _vp, _pu64, _pu64]),
     "lime_choose_pairs_dev": (_i, [_vp, _vp, _u32, _u32, _u32, C.c_float, _vp, _vp, _pp, _pu64, _vp]),
     "lime_score_choose": (_i, [_vp, _vp, _vp, _u64, _vp, _u64, _u32, _u32, _u32, C.c_float, _vp, _vp, _pp, _pu64, _vp]),
+    "lime_comm_unique_id": (_i, [_vp]),
+    "lime_comm_init": (_i, [_vp, _i, _i, _pp]),
+    "lime_comm_destroy": (None, [_vp]),
+    "lime_comm_error": (C.c_char_p, []),
+    "lime_comm_reduce_scatter_tables": (_i, [_vp, _vp, _vp, _sz, _vp]),
+    "lime_comm_allreduce_tables": (_i, [_vp, _vp, _sz, _vp]),
+    "lime_comm_combine_counters": (_i, [_vp, _vp, _vp]),
+    "lime_fused_multi": (_i, [_i, _vp, _vp, _vp, _vp, _u64, _u32, _u32, _u32, _vp, _pu64, _pu64]),
     "lime_write_res_txt_pairs": (_i, [C.c_char_p, _vp, _vp, _vp, _u32, _u32, C.c_float]),
     "lime_write_res_bin_pairs": (_i, [C.c_char_p, C.c_char_p, _vp, _vp, _vp, _u32, _u32, C.c_float]),
 }

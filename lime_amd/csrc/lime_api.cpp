@@ -270,6 +270,7 @@ static bool want_binned(const lime_ctx *c, uint64_t n_own, size_t sim_bytes, int
     if (sim_bytes > ((size_t)BIN_MAX << BIN_SHIFT_MAX) || sim_bytes >= (1ull << CELL_BITS)) return false;
     if (c->upd_pref >= 0) return c->upd_pref == 1;
     if (n_own < (1u << 24)) return false;                 // short passes: the extra launches cost more than they save
+    if (sim_bytes < (1u << 20)) return false;             // tiny tables: all updates would land in one or two bins
     if (c->density_known) return c->density >= 0.06;
     return sim_bytes > (256u << 20);                      // nothing known yet: tables beyond the Infinity Cache
 }
@@ -281,7 +282,7 @@ static int ensure_binned(lime_ctx *c, uint64_t n_own, uint32_t n_waves, uint32_t
     const double per_wave = (double)n_own * c->pool_density / (double)n_waves;
     uint64_t cw = ((uint64_t)(per_wave * 1.10) + 512u) & ~1ull;           // even: a wave's region starts 16-byte aligned
     if (c->pool_cap / n_waves > cw) cw = (c->pool_cap / n_waves) & ~1ull;  // grow-only: use all of what is there
-    if (cw > 0xFFFFFFF0ull) return fail(LIME_ERR_ARG, "update record pool too large for one shard");
+    if (cw * n_waves > 0xF0000000ull) return fail(LIME_ERR_ARG, "update record pool too large for one shard");   // per-bin record counts are 32-bit
     const size_t want = (size_t)cw * n_waves;
     if (want > c->pool_cap) {
         HIP_TRY(hipStreamSynchronize(st));
@@ -323,7 +324,8 @@ static int fused_dev_impl(lime_ctx *c, const uint32_t *d_lcp, const uint32_t *d_
     const size_t sim_bytes = lime_sim_bytes(n_reads, n_refs);
     const int ebwt = d_ebwt != nullptr;
     const uint32_t n_tiles = (uint32_t)((n_avail + WIN - 1) / WIN);
-    const bool binned = n_avail && want_binned(c, n_own, sim_bytes, zero_sim, keep_stats);
+    bool binned = n_avail && want_binned(c, n_own, sim_bytes, zero_sim, keep_stats);
+    if (binned && (double)n_own * c->pool_density * 1.10 + 512.0 * 4096.0 > 3.9e9) binned = false;   // more records than 32-bit counts hold: compare-and-swap path
     uint32_t grid = 0, cap_w = 0, n_bins = 0, bin_shift = REGION_SHIFT;
     if (binned) {
         grid = scan_grid(ebwt, 0, 1, n_tiles, c->max_blocks);

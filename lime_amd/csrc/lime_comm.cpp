@@ -1,0 +1,246 @@
+// lime_comm.cpp -- the one exchange step of the multi-GPU path, through the C ABI: the per-GPU uint8
+// score tables are summed modulo 256 over xGMI with RCCL (ncclReduceScatter / ncclAllReduce on
+// ncclUint8 with ncclSum; mod-256 addition is associative, so the result is bit-identical to the
+// reference's single table, ClusterBWT_DA.cpp:178-184 / 243-248 under OpenMP's range partition
+// ClusterLCP.cpp:150-161).  Two forms:
+//   * one process per GPU (torchrun / mpirun style): lime_comm_unique_id on rank 0, the caller carries
+//     the 128 bytes to the other ranks by whatever channel it has, lime_comm_init on every rank;
+//   * one process driving several GPUs (the drop-in ClusterBWT_DA with LIME_GPUS=k): lime_multi_*.
+// librccl is loaded on first use (dlopen), so single-GPU users of the library do not depend on it.
+#include <hip/hip_runtime.h>
+#include <dlfcn.h>
+#include <stdarg.h>
+#include <stdio.h>
+#include <string.h>
+#include <string>
+#include <vector>
+
+#include "lime_hip.h"
+
+// the part of rccl.h this file uses (rccl/rccl.h:40-64, 448-470), declared here so that building the
+// library does not need the RCCL headers' HIP-version checks
+extern "C" {
+typedef struct ncclComm *ncclComm_t;
+typedef struct { char internal[128]; } ncclUniqueId;
+typedef int ncclResult_t;
+enum { nccl_Sum = 0, nccl_Max = 2, nccl_Uint8 = 1, nccl_Uint64 = 5 };
+}
+
+namespace {
+struct Rccl {
+    void *h = nullptr;
+    ncclResult_t (*GetUniqueId)(ncclUniqueId *) = nullptr;
+    ncclResult_t (*CommInitRank)(ncclComm_t *, int, ncclUniqueId, int) = nullptr;
+    ncclResult_t (*CommInitAll)(ncclComm_t *, int, const int *) = nullptr;
+    ncclResult_t (*CommDestroy)(ncclComm_t) = nullptr;
+    ncclResult_t (*ReduceScatter)(const void *, void *, size_t, int, int, ncclComm_t, hipStream_t) = nullptr;
+    ncclResult_t (*AllReduce)(const void *, void *, size_t, int, int, ncclComm_t, hipStream_t) = nullptr;
+    ncclResult_t (*GroupStart)() = nullptr;
+    ncclResult_t (*GroupEnd)() = nullptr;
+    const char *(*GetErrorString)(ncclResult_t) = nullptr;
+};
+Rccl g_rccl;
+thread_local std::string g_comm_err;
+
+int cfail(int code, const char *fmt, ...)
+{
+    char buf[512];
+    va_list ap; va_start(ap, fmt); vsnprintf(buf, sizeof buf, fmt, ap); va_end(ap);
+    g_comm_err = buf;
+    return code;
+}
+
+int load_rccl()
+{
+    if (g_rccl.h) return LIME_OK;
+    const char *names[] = {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"};
+    void *h = nullptr;
+    for (const char *n : names) if ((h = dlopen(n, RTLD_NOW | RTLD_GLOBAL))) break;
+    if (!h) return cfail(LIME_ERR_HIP, "cannot load librccl: %s", dlerror());
+#define SYM(field, name) if (!(*(void **)(&g_rccl.field) = dlsym(h, name))) return cfail(LIME_ERR_HIP, "librccl lacks %s", name)
+    SYM(GetUniqueId, "ncclGetUniqueId"); SYM(CommInitRank, "ncclCommInitRank"); SYM(CommInitAll, "ncclCommInitAll");
+    SYM(CommDestroy, "ncclCommDestroy"); SYM(ReduceScatter, "ncclReduceScatter"); SYM(AllReduce, "ncclAllReduce");
+    SYM(GroupStart, "ncclGroupStart"); SYM(GroupEnd, "ncclGroupEnd"); SYM(GetErrorString, "ncclGetErrorString");
+#undef SYM
+    g_rccl.h = h;
+    return LIME_OK;
+}
+
+#define NCCL_TRY(expr)                                                                          \
+    do {                                                                                        \
+        ncclResult_t r_ = (expr);                                                               \
+        if (r_ != 0) return cfail(LIME_ERR_HIP, "%s: %s", #expr, g_rccl.GetErrorString(r_));    \
+    } while (0)
+#define HIP_TRYC(expr)                                                                          \
+    do {                                                                                        \
+        hipError_t e_ = (expr);                                                                 \
+        if (e_ != hipSuccess) return cfail(e_ == hipErrorOutOfMemory ? LIME_ERR_NOMEM : LIME_ERR_HIP, "%s: %s", #expr, hipGetErrorString(e_)); \
+    } while (0)
+}
+
+struct lime_comm {
+    ncclComm_t comm = nullptr;
+    int rank = 0, world = 1, device = 0;
+};
+
+extern "C" const char *lime_comm_error(void) { return g_comm_err.c_str(); }
+
+extern "C" int lime_comm_unique_id(uint8_t id[LIME_COMM_ID_BYTES])
+{
+    int rc = load_rccl(); if (rc) return rc;
+    if (!id) return cfail(LIME_ERR_ARG, "lime_comm_unique_id: id is NULL");
+    ncclUniqueId u;
+    NCCL_TRY(g_rccl.GetUniqueId(&u));
+    static_assert(sizeof u == LIME_COMM_ID_BYTES, "ncclUniqueId is 128 bytes");
+    memcpy(id, &u, sizeof u);
+    return LIME_OK;
+}
+
+extern "C" int lime_comm_init(const uint8_t id[LIME_COMM_ID_BYTES], int rank, int world, lime_comm **out)
+{
+    int rc = load_rccl(); if (rc) return rc;
+    if (!out || !id || world < 1 || rank < 0 || rank >= world) return cfail(LIME_ERR_ARG, "lime_comm_init: bad argument");
+    *out = nullptr;
+    lime_comm *c = new (std::nothrow) lime_comm();
+    if (!c) return cfail(LIME_ERR_NOMEM, "lime_comm_init: out of host memory");
+    c->rank = rank; c->world = world;
+    HIP_TRYC(hipGetDevice(&c->device));
+    ncclUniqueId u; memcpy(&u, id, sizeof u);
+    ncclResult_t r = g_rccl.CommInitRank(&c->comm, world, u, rank);
+    if (r != 0) { delete c; return cfail(LIME_ERR_HIP, "ncclCommInitRank: %s", g_rccl.GetErrorString(r)); }
+    *out = c;
+    return LIME_OK;
+}
+
+extern "C" void lime_comm_destroy(lime_comm *c)
+{
+    if (!c) return;
+    if (c->comm && g_rccl.CommDestroy) (void)g_rccl.CommDestroy(c->comm);
+    delete c;
+}
+
+// every rank holds a whole table of world * block_bytes bytes (zero padded past n_reads * n_refs); rank r ends
+// with the sum modulo 256 of everybody's block r -- its block of read rows, on which it goes on alone
+// (clusterChoose is row-independent, ClusterBWT_DA.cpp:385-443).  Asynchronous on `stream`.
+extern "C" int lime_comm_reduce_scatter_tables(lime_comm *c, const uint8_t *d_sim, uint8_t *d_block, size_t block_bytes, void *stream)
+{
+    if (!c || !d_sim || !d_block) return cfail(LIME_ERR_ARG, "lime_comm_reduce_scatter_tables: NULL argument");
+    NCCL_TRY(g_rccl.ReduceScatter(d_sim, d_block, block_bytes, nccl_Uint8, nccl_Sum, c->comm, (hipStream_t)stream));
+    return LIME_OK;
+}
+
+// the whole-table form (every rank ends with the complete table), in place
+extern "C" int lime_comm_allreduce_tables(lime_comm *c, uint8_t *d_sim, size_t bytes, void *stream)
+{
+    if (!c || !d_sim) return cfail(LIME_ERR_ARG, "lime_comm_allreduce_tables: NULL argument");
+    NCCL_TRY(g_rccl.AllReduce(d_sim, d_sim, bytes, nccl_Uint8, nccl_Sum, c->comm, (hipStream_t)stream));
+    return LIME_OK;
+}
+
+// cluster count (sum) and longest cluster (max) over the ranks: d_sum_max = device array {sum operand, max operand}
+extern "C" int lime_comm_combine_counters(lime_comm *c, uint64_t *d_sum_max, void *stream)
+{
+    if (!c || !d_sum_max) return cfail(LIME_ERR_ARG, "lime_comm_combine_counters: NULL argument");
+    NCCL_TRY(g_rccl.GroupStart());
+    NCCL_TRY(g_rccl.AllReduce(d_sum_max, d_sum_max, 1, nccl_Uint64, nccl_Sum, c->comm, (hipStream_t)stream));
+    NCCL_TRY(g_rccl.AllReduce(d_sum_max + 1, d_sum_max + 1, 1, nccl_Uint64, nccl_Max, c->comm, (hipStream_t)stream));
+    NCCL_TRY(g_rccl.GroupEnd());
+    return LIME_OK;
+}
+
+// ---- one process, several GPUs ------------------------------------------------------------
+// The collection is cut into position ranges (tile-aligned, each with a read-ahead halo of LIME_MAX_CLUSTER +
+// LIME_TILE positions: ClusterLCP.cpp:150-161 chunking, :196-202 skip, :246-264 straddle); device k scans range k
+// into its own table; one reduce-scatter leaves device k with read-row block k; the blocks are copied back into
+// the caller's table.  Host arrays may be pageable.
+namespace {
+struct DevSet {
+    int dev = -1; lime_ctx *ctx = nullptr; hipStream_t st = nullptr;
+    uint32_t *lcp = nullptr, *da = nullptr; uint8_t *ebwt = nullptr, *sim = nullptr, *blk = nullptr;
+    ~DevSet() {
+        if (dev < 0) return;
+        (void)hipSetDevice(dev);
+        if (st) { (void)hipStreamSynchronize(st); (void)hipStreamDestroy(st); }
+        (void)hipFree(lcp); (void)hipFree(da); (void)hipFree(ebwt); (void)hipFree(sim); (void)hipFree(blk);
+        if (ctx) lime_shutdown(ctx);
+    }
+};
+}
+
+extern "C" int lime_fused_multi(int n_dev, const int *devices, const uint32_t *lcp, const uint32_t *da, const uint8_t *ebwt,
+                                uint64_t n, uint32_t n_reads, uint32_t n_refs, uint32_t alpha, uint8_t *sim,
+                                uint64_t *n_clusters, uint64_t *max_len)
+{
+    if (n_dev < 1 || !sim || (n && (!lcp || !da))) return cfail(LIME_ERR_ARG, "lime_fused_multi: bad argument");
+    if (!n_reads || !n_refs) return cfail(LIME_ERR_ARG, "lime_fused_multi: n_reads and n_refs must be > 0");
+    int have = lime_device_count();
+    if (n_dev > have) return cfail(LIME_ERR_ARG, "lime_fused_multi: %d devices asked, %d visible", n_dev, have);
+    int rc;
+    if (n_dev > 1 && (rc = load_rccl())) return rc;
+    std::vector<int> devs(n_dev);
+    for (int k = 0; k < n_dev; ++k) devs[k] = devices ? devices[k] : k;
+    const uint64_t halo = (uint64_t)LIME_MAX_CLUSTER + LIME_TILE;
+    const uint64_t tiles = (n + LIME_TILE - 1) / LIME_TILE;
+    const size_t sim_bytes = lime_sim_bytes(n_reads, n_refs);
+    const size_t blk = (sim_bytes + 16u * (size_t)n_dev - 1) / (16u * (size_t)n_dev) * 16u;      // block of one device, 16-byte aligned
+    std::vector<DevSet> ds(n_dev);
+    std::vector<uint64_t> lo(n_dev), own(n_dev), avail(n_dev);
+    for (int k = 0; k < n_dev; ++k) {
+        const uint64_t t0 = tiles * (uint64_t)k / n_dev, t1 = tiles * (uint64_t)(k + 1) / n_dev;
+        lo[k] = t0 * LIME_TILE < n ? t0 * LIME_TILE : n;
+        const uint64_t hi = (k == n_dev - 1) ? n : (t1 * LIME_TILE < n ? t1 * LIME_TILE : n);
+        own[k] = hi - lo[k];
+        avail[k] = hi < n ? ((hi + halo < n ? hi + halo : n) - lo[k]) : n - lo[k];
+        DevSet &d = ds[k];
+        HIP_TRYC(hipSetDevice(devs[k]));
+        d.dev = devs[k];
+        if ((rc = lime_init(devs[k], &d.ctx))) return cfail(rc, "lime_init(device %d): %s", devs[k], lime_last_error());
+        HIP_TRYC(hipStreamCreateWithFlags(&d.st, hipStreamNonBlocking));
+        HIP_TRYC(hipMalloc(&d.lcp, avail[k] * 4 + 16)); HIP_TRYC(hipMalloc(&d.da, avail[k] * 4 + 16));
+        if (ebwt) HIP_TRYC(hipMalloc(&d.ebwt, avail[k] + 16));
+        HIP_TRYC(hipMalloc(&d.sim, blk * n_dev)); HIP_TRYC(hipMalloc(&d.blk, blk));
+        if (blk * n_dev > sim_bytes) HIP_TRYC(hipMemsetAsync(d.sim + sim_bytes, 0, blk * n_dev - sim_bytes, d.st));
+        HIP_TRYC(hipMemcpyAsync(d.lcp, lcp + lo[k], avail[k] * 4, hipMemcpyHostToDevice, d.st));
+        HIP_TRYC(hipMemcpyAsync(d.da, da + lo[k], avail[k] * 4, hipMemcpyHostToDevice, d.st));
+        if (ebwt) HIP_TRYC(hipMemcpyAsync(d.ebwt, ebwt + lo[k], avail[k], hipMemcpyHostToDevice, d.st));
+        rc = lime_fused_dev(d.ctx, d.lcp, d.da, d.ebwt, own[k], avail[k], lo[k] + avail[k] == n, n_reads, n_refs, alpha, d.sim, 1, d.st);
+        if (rc) return cfail(rc, "device %d: %s", devs[k], lime_last_error());
+    }
+    uint64_t tot = 0, mx = 0;
+    for (int k = 0; k < n_dev; ++k) {
+        HIP_TRYC(hipSetDevice(devs[k]));
+        lime_stats_t s;
+        if ((rc = lime_get_stats(ds[k].ctx, &s, ds[k].st))) return cfail(rc, "device %d: %s", devs[k], lime_last_error());
+        tot += s.n_clusters; if (s.max_len > mx) mx = s.max_len;
+    }
+    if (n_clusters) *n_clusters = tot;
+    if (max_len) *max_len = mx;
+    if (n_dev == 1) {
+        HIP_TRYC(hipSetDevice(devs[0]));
+        HIP_TRYC(hipMemcpyAsync(sim, ds[0].sim, (size_t)n_reads * n_refs, hipMemcpyDeviceToHost, ds[0].st));
+        HIP_TRYC(hipStreamSynchronize(ds[0].st));
+        return LIME_OK;
+    }
+    std::vector<ncclComm_t> comms(n_dev, nullptr);
+    NCCL_TRY(g_rccl.CommInitAll(comms.data(), n_dev, devs.data()));
+    rc = LIME_OK;
+    if (g_rccl.GroupStart() != 0) rc = cfail(LIME_ERR_HIP, "ncclGroupStart failed");
+    for (int k = 0; k < n_dev && !rc; ++k) {
+        (void)hipSetDevice(devs[k]);
+        ncclResult_t r = g_rccl.ReduceScatter(ds[k].sim, ds[k].blk, blk, nccl_Uint8, nccl_Sum, comms[k], ds[k].st);
+        if (r != 0) rc = cfail(LIME_ERR_HIP, "ncclReduceScatter: %s", g_rccl.GetErrorString(r));
+    }
+    if (!rc && g_rccl.GroupEnd() != 0) rc = cfail(LIME_ERR_HIP, "ncclGroupEnd failed");
+    const size_t total = (size_t)n_reads * n_refs;
+    for (int k = 0; k < n_dev && !rc; ++k) {
+        const size_t b0 = blk * (size_t)k;
+        if (b0 >= total) break;
+        const size_t len = total - b0 < blk ? total - b0 : blk;
+        (void)hipSetDevice(devs[k]);
+        hipError_t e = hipMemcpyAsync(sim + b0, ds[k].blk, len, hipMemcpyDeviceToHost, ds[k].st);
+        if (e != hipSuccess) rc = cfail(LIME_ERR_HIP, "hipMemcpyAsync: %s", hipGetErrorString(e));
+    }
+    for (int k = 0; k < n_dev; ++k) { (void)hipSetDevice(devs[k]); (void)hipStreamSynchronize(ds[k].st); }
+    for (int k = 0; k < n_dev; ++k) if (comms[k]) (void)g_rccl.CommDestroy(comms[k]);
+    return rc;
+}

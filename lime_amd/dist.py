@@ -54,6 +54,126 @@ def reduce_scatter_tables(sim_t, out_t, group=None, async_op=False):
     return dist.reduce_scatter_tensor(out_t, sim_t, op=dist.ReduceOp.SUM, group=group, async_op=async_op)
 
 
+class Comm:
+    """The exchange step through the C ABI (include/lime_hip.h, lime_comm_*): RCCL ncclReduceScatter / ncclAllReduce
+    on ncclUint8 with ncclSum, one rank per GPU.  torch.distributed is the control plane only: it carries the
+    128-byte ncclUniqueId from rank 0 to the others, the timing maximum and the barriers."""
+
+    def __init__(self, rank, world, device, group=None):
+        import ctypes as C
+        import torch
+        import torch.distributed as dist
+        from . import _lib
+        self.lib, self.rank, self.world, self.device, self.group = _lib.load(), rank, world, device, group
+        idbuf = (C.c_uint8 * 128)()
+        if rank == 0:
+            self._check(self.lib.lime_comm_unique_id(idbuf))
+        t = torch.tensor(list(bytes(idbuf)), dtype=torch.uint8, device=device if dist.get_backend(group) == "nccl" else "cpu")
+        dist.broadcast(t, src=0, group=group)
+        idb = (C.c_uint8 * 128)(*t.cpu().tolist())
+        h = C.c_void_p()
+        self._check(self.lib.lime_comm_init(idb, rank, world, C.byref(h)))
+        self.h = h
+
+    def _check(self, rc):
+        if rc:
+            from ._lib import LimeError
+            raise LimeError(rc, self.lib.lime_comm_error().decode(errors="replace"))
+
+    def reduce_scatter_tables(self, sim_t, blk_t, blk_bytes, stream=None):
+        """rank r receives block r (blk_bytes bytes) of the sum modulo 256 of everybody's sim_t (world * blk_bytes bytes)"""
+        self._check(self.lib.lime_comm_reduce_scatter_tables(self.h, sim_t.data_ptr(), blk_t.data_ptr(), blk_bytes, stream))
+
+    def allreduce_tables(self, sim_t, stream=None):
+        self._check(self.lib.lime_comm_allreduce_tables(self.h, sim_t.data_ptr(), sim_t.numel(), stream))
+
+    def combine_counters(self, n_clusters, max_len):
+        import torch
+        t = torch.tensor([n_clusters, max_len], dtype=torch.int64, device=self.device)
+        self._check(self.lib.lime_comm_combine_counters(self.h, t.data_ptr(), torch.cuda.current_stream().cuda_stream))
+        c, m = t.cpu().tolist()
+        return int(c), int(m)
+
+    def check_uint8_sum_wraps(self):
+        """self-check at start-up: RCCL's uint8 sum wraps modulo 256 (200 x world) in both collectives"""
+        import torch
+        w = self.world
+        want = (200 * w) % 256
+        src = torch.full((64 * w,), 200, dtype=torch.uint8, device=self.device)
+        blk = torch.empty(64, dtype=torch.uint8, device=self.device)
+        st = torch.cuda.current_stream().cuda_stream
+        self.reduce_scatter_tables(src, blk, 64, st)
+        self.allreduce_tables(src, st)
+        torch.cuda.synchronize()
+        if not bool((blk == want).all()) or not bool((src == want).all()):
+            raise RuntimeError(f"RCCL uint8 sum does not wrap modulo 256: got {int(blk[0])}/{int(src[0])}, want {want}")
+
+    def barrier(self):
+        import torch.distributed as dist
+        dist.barrier(group=self.group)
+
+    def max_float(self, x):
+        import torch
+        import torch.distributed as dist
+        t = torch.tensor([x], dtype=torch.float64, device=self.device)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX, group=self.group)
+        return float(t.item())
+
+    def close(self):
+        if self.h:
+            self.lib.lime_comm_destroy(self.h)
+            self.h = None
+
+
+class HostComm:
+    """Rehearsal stand-in for Comm on a one-GPU box (gloo backend, every rank on GPU 0): the same calls with the
+    exchange staged through host memory.  Never the measured path."""
+
+    def __init__(self, rank, world, device, group=None):
+        self.rank, self.world, self.device, self.group = rank, world, device, group
+
+    def reduce_scatter_tables(self, sim_t, blk_t, blk_bytes, stream=None):
+        import torch
+        import torch.distributed as dist
+        torch.cuda.synchronize()
+        h = sim_t.cpu()
+        dist.all_reduce(h, op=dist.ReduceOp.SUM, group=self.group)
+        blk_t.copy_(h.view(self.world, -1)[self.rank][:blk_bytes])
+
+    def allreduce_tables(self, sim_t, stream=None):
+        import torch
+        import torch.distributed as dist
+        torch.cuda.synchronize()
+        h = sim_t.cpu()
+        dist.all_reduce(h, op=dist.ReduceOp.SUM, group=self.group)
+        sim_t.copy_(h)
+
+    def combine_counters(self, n_clusters, max_len):
+        return combine_counters(n_clusters, max_len, "cpu", self.group)
+
+    def check_uint8_sum_wraps(self):
+        import torch
+        import torch.distributed as dist
+        t = torch.full((64,), 200, dtype=torch.uint8)
+        dist.all_reduce(t, op=dist.ReduceOp.SUM, group=self.group)
+        if not bool((t == (200 * self.world) % 256).all()):
+            raise RuntimeError("uint8 all-reduce does not wrap modulo 256")
+
+    def barrier(self):
+        import torch.distributed as dist
+        dist.barrier(group=self.group)
+
+    def max_float(self, x):
+        import torch
+        import torch.distributed as dist
+        t = torch.tensor([x], dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX, group=self.group)
+        return float(t.item())
+
+    def close(self):
+        pass
+
+
 def combine_counters(n_clusters, max_len, device, group=None):
     """(sum of cluster counts, max of maximum lengths) over ranks."""
     import torch
