@@ -329,7 +329,7 @@ static int fused_dev_impl(lime_ctx *c, const uint32_t *d_lcp, const uint32_t *d_
     uint32_t grid = 0, cap_w = 0, n_bins = 0, bin_shift = REGION_SHIFT;
     if (binned) {
         grid = scan_grid(ebwt, 0, 1, n_tiles, c->max_blocks);
-        // one bin per 64 KB region for small tables; else as few levels of fan-out as fit: at most 1024 bins of 2^k
+        // one bin per 64 KB region for small tables; else as few levels of fan-out as fit: at most 2048 bins of 2^k
         // regions (the bins' open output lines then merge in the L2), more bins only when k would pass its limit
         auto bins_at = [&](uint32_t sh) { return (sim_bytes + ((size_t)1 << sh) - 1) >> sh; };
         if (bins_at(bin_shift) > c->bin_one_level) {

@@ -28,7 +28,7 @@ constexpr uint32_t HT_EMPTY = 0xFFFFFFFFu;
 constexpr uint32_t BIN_MAX = 3072;           // bins: one u32 counter each in the 12 KB of LDS the CAS slots use otherwise
 constexpr uint32_t REGION_SHIFT = 16;        // k_apply builds 2^16 = 64 KB of the table per workgroup
 constexpr uint32_t BIN_ONE_LEVEL = 1024;     // tables of up to this many regions: one bin per region, no second level
-constexpr uint32_t BIN_TWO_LEVEL = 1024;     // larger tables: at most this many bins of 2^k regions each (while k allows); measured best of 256..2048 on configs[2]
+constexpr uint32_t BIN_TWO_LEVEL = 2048;     // larger tables: at most this many bins of 2^k regions each (while k allows); measured best of 256..2048 on configs[2]
 constexpr uint32_t BIN_SHIFT_MAX = 25;       // bin-relative cell offset + 7 bits of t must fit 32 bits
 constexpr uint32_t CELL_BITS = 40;           // pool record: cell | t << 40
 constexpr int APPLY_WG = 512;

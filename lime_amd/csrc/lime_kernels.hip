@@ -1266,126 +1266,188 @@ __global__ __launch_bounds__(256) void k_bin_rowscan(uint32_t *counts, uint32_t 
 }
 
 // (bins as wide as a region: the bin bases are the region bases; wider bins go through k_part2 first)
-// k_part: workgroup p moves the records of producer workgroup p (wave w those of producer wave 4p + w) from the
-// pool into their bins.  Cursors of all bins sit in LDS (start = the prefix k_bin_rowscan left); a record takes
-// its slot with one returning LDS add and goes out as 4 bytes: cell offset inside the bin | t << bin_shift.
-__global__ __launch_bounds__(SCANK_WG) void k_part(ScanArgs a, const uint64_t *binbase, uint32_t *out)
+//
+// Both partition kernels move records TILE by TILE through LDS: a tile's records are ranked inside their bin with
+// one returning LDS add each, an exclusive scan of the tile's bin counts gives every bin a run of LDS slots, the
+// records go to their slots together with their final position, and the tile leaves LDS slot by slot -- so a wave's
+// store instruction writes runs of consecutive positions instead of 64 scattered dwords (scattered 4-byte stores
+// cost the CU's address path about 3 cycles per lane: 0.8 ms per 1.2e8 records and level, measured).
+constexpr int PART_WG = 512;
+constexpr uint32_t PART_PER = 16, PART_TILE = PART_WG * PART_PER;          // 8192 records per tile, 64 KB of (position, record)
+
+// exclusive prefix of cnt[0 .. nb) into toff[0 .. nb), nb <= PART_WG * 8; all threads of the workgroup call it
+// (barriers inside: cnt is complete on entry, toff on exit)
+__device__ __forceinline__ void part_scan(const uint32_t *cnt, uint32_t *toff, uint32_t nb, uint32_t *wsum)
 {
-    extern __shared__ uint64_t part_lds[];                      // base[n_bins] (u64), then cur[n_bins] (u32)
-    uint64_t *base = part_lds;
-    uint32_t *cur = reinterpret_cast<uint32_t *>(part_lds + a.n_bins);
-    const uint32_t lane = lane_id(), wave = threadIdx.x >> 6;
-    for (uint32_t b = threadIdx.x; b < a.n_bins; b += SCANK_WG) {
-        cur[b] = a.counts[(size_t)b * gridDim.x + blockIdx.x];
-        base[b] = binbase[b];
+    const uint32_t tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
+    const uint32_t per = (nb + PART_WG - 1u) / PART_WG, b0 = tid * per;
+    uint32_t mine = 0;
+    for (uint32_t k = 0; k < per; ++k) mine += b0 + k < nb ? cnt[b0 + k] : 0u;
+    const uint32_t incl = wave_incl_scan(mine);
+    if (lane == 63u) wsum[wave] = incl;
+    __syncthreads();
+    uint32_t run = incl - mine;
+    for (uint32_t k = 0; k < wave; ++k) run += wsum[k];
+    for (uint32_t k = 0; k < per; ++k) if (b0 + k < nb) { toff[b0 + k] = run; run += cnt[b0 + k]; }
+    __syncthreads();
+}
+
+// k_part: workgroup p moves the records of producer workgroup p (its four waves' pool regions, one after the other)
+// into their bins; a record leaves as 4 bytes: cell offset inside the bin | t << bin_shift.  Positions are 32-bit
+// (the host keeps a pass below 2^32 records).
+__global__ __launch_bounds__(PART_WG) void k_part(ScanArgs a, const uint64_t *binbase, uint32_t *out)
+{
+    __shared__ uint2 stage[PART_TILE];                                   // (position in out, record)
+    extern __shared__ uint32_t part_lds[];                               // per bin: tile count, tile offset, cursor
+    uint32_t *cnt = part_lds, *toff = cnt + a.n_bins, *gcur = toff + a.n_bins;
+    __shared__ uint32_t wsum[PART_WG / 64];
+    const uint32_t tid = threadIdx.x;
+    for (uint32_t b = tid; b < a.n_bins; b += PART_WG) {
+        gcur[b] = (uint32_t)binbase[b] + a.counts[(size_t)b * gridDim.x + blockIdx.x];
+        cnt[b] = 0u;
     }
     __syncthreads();
-    const uint32_t wave_gid = blockIdx.x * (SCANK_WG / 64) + wave;
-    typedef unsigned long long u64x2 __attribute__((ext_vector_type(2)));
-    const u64x2 *src = reinterpret_cast<const u64x2 *>(a.pool + (size_t)wave_gid * a.cap_w);   // cap_w is even: 16-byte aligned
-    const uint32_t cnt = a.wave_cnt[wave_gid];
     const uint64_t cmask = (1ull << CELL_BITS) - 1ull;
     const uint32_t omask = (1u << a.bin_shift) - 1u;
-    constexpr uint32_t U = 4;                                   // 16-byte loads (2 records) per lane in flight, one batch ahead
-    const uint32_t n_batch = (cnt + 128u * U - 1u) / (128u * U);
-    u64x2 nxt[U];
-    auto load = [&](uint32_t bt, u64x2 (&r)[U]) {
+    static_assert(BIN_MAX <= 4096 && PART_TILE <= (1u << 20), "bin | rank << 12 must fit 32 bits");
+    // the producer's four wave regions as one sequence of tiles; the next tile's records are loaded while the
+    // current one goes through LDS
+    uint32_t n_w[SCANK_WG / 64];
 #pragma unroll
-        for (uint32_t u = 0; u < U; ++u) {
-            const uint32_t i = bt * 128u * U + 128u * u + 2u * lane;
-            r[u] = i < cnt ? __builtin_nontemporal_load(src + (i >> 1)) : u64x2{~0ull, ~0ull};
-            if (i + 1u >= cnt) r[u].y = ~0ull;                   // odd count: the pair's second record is not data
+    for (uint32_t w = 0; w < SCANK_WG / 64; ++w) n_w[w] = a.wave_cnt[blockIdx.x * (SCANK_WG / 64) + w];
+    auto seg_n = [&](uint32_t w) { return w == 0 ? n_w[0] : w == 1 ? n_w[1] : w == 2 ? n_w[2] : n_w[3]; };
+    auto load_tile = [&](uint32_t w, uint32_t t0, uint64_t (&rec)[PART_PER]) {
+        const uint64_t *src = a.pool + (size_t)(blockIdx.x * (SCANK_WG / 64) + w) * a.cap_w + t0;
+        const uint32_t n = seg_n(w), tn = n - t0 < PART_TILE ? n - t0 : PART_TILE;
+#pragma unroll
+        for (uint32_t j = 0; j < PART_PER; ++j) {
+            const uint32_t i = j * PART_WG + tid;
+            rec[j] = i < tn ? __builtin_nontemporal_load(src + i) : ~0ull;
         }
     };
-    if (n_batch) load(0, nxt);
-    for (uint32_t bt = 0; bt < n_batch; ++bt) {
-        u64x2 r[U];
+    uint32_t w = 0, t0 = 0;
+    while (w < SCANK_WG / 64 && seg_n(w) == 0u) ++w;
+    uint64_t rec[PART_PER];
+    if (w < SCANK_WG / 64) load_tile(w, t0, rec);
+    while (w < SCANK_WG / 64) {
+        const uint32_t n = seg_n(w), tn = n - t0 < PART_TILE ? n - t0 : PART_TILE;
+        uint32_t val[PART_PER], dr[PART_PER];
 #pragma unroll
-        for (uint32_t u = 0; u < U; ++u) r[u] = nxt[u];
-        if (bt + 1u < n_batch) load(bt + 1u, nxt);
-#pragma unroll
-        for (uint32_t u = 0; u < U; ++u) {
-#pragma unroll
-            for (int h = 0; h < 2; ++h) {
-                const uint64_t rec = h ? r[u].y : r[u].x;
-                if (rec != ~0ull) {
-                    const uint64_t cell = rec & cmask;
-                    const uint32_t b = (uint32_t)(cell >> a.bin_shift);
-                    const uint32_t k = atomicAdd(&cur[b], 1u);
-                    out[base[b] + k] = ((uint32_t)cell & omask) | ((uint32_t)(rec >> CELL_BITS) << a.bin_shift);
-                }
+        for (uint32_t j = 0; j < PART_PER; ++j) {
+            dr[j] = ~0u; val[j] = 0u;
+            if (rec[j] != ~0ull) {
+                const uint64_t cell = rec[j] & cmask;
+                const uint32_t d = (uint32_t)(cell >> a.bin_shift);
+                dr[j] = d | (atomicAdd(&cnt[d], 1u) << 12);
+                val[j] = ((uint32_t)cell & omask) | ((uint32_t)(rec[j] >> CELL_BITS) << a.bin_shift);
             }
         }
+        t0 += PART_TILE;                                     // the next tile, if any: its loads go out now
+        if (t0 >= n) { t0 = 0; ++w; while (w < SCANK_WG / 64 && seg_n(w) == 0u) ++w; }
+        if (w < SCANK_WG / 64) load_tile(w, t0, rec);
+        __syncthreads();
+        part_scan(cnt, toff, a.n_bins, wsum);
+#pragma unroll
+        for (uint32_t j = 0; j < PART_PER; ++j)
+            if (dr[j] != ~0u) {
+                const uint32_t d = dr[j] & 0xFFFu, r = dr[j] >> 12;
+                stage[toff[d] + r] = make_uint2(gcur[d] + r, val[j]);
+            }
+        __syncthreads();
+        for (uint32_t i = tid; i < tn; i += PART_WG) { const uint2 sv = stage[i]; out[sv.x] = sv.y; }
+        __syncthreads();
+        for (uint32_t b = tid; b < a.n_bins; b += PART_WG) { gcur[b] += cnt[b]; cnt[b] = 0u; }
+        __syncthreads();
     }
 }
 
 // k_part2: second level, one workgroup per bin (bins wider than a region only): the bin's records are counted per
 // 64 KB region of the table, the regions' bases go to regbase[bin * F2 + sub] (F2 = regions per bin), and a second
-// sweep (served by the L2: a bin's records are a few hundred KB) moves each record to its region's range of `out`.
-// Same cursor scheme as k_part; the few hundred open output lines of a bin merge in the L2.
-__global__ __launch_bounds__(1024) void k_part2(const uint32_t *recs, const uint64_t *binbase, uint32_t bin_shift,
-                                                uint64_t *regbase, uint32_t *out)
+// sweep (served by the L2: a bin's records are a few hundred KB) moves each record to its region's range of `out`,
+// tile by tile through LDS like k_part.
+__global__ __launch_bounds__(PART_WG) void k_part2(const uint32_t *recs, const uint64_t *binbase, uint32_t bin_shift,
+                                                   uint64_t *regbase, uint32_t *out)
 {
     constexpr uint32_t F2MAX = 1u << (BIN_SHIFT_MAX - REGION_SHIFT);
-    __shared__ uint32_t cnt[F2MAX], cur[F2MAX];
-    __shared__ uint32_t wsum[16];
-    const uint32_t tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
+    __shared__ uint2 stage[PART_TILE];
+    __shared__ uint32_t cnt[F2MAX], toff[F2MAX], gcur[F2MAX];
+    __shared__ uint32_t wsum[PART_WG / 64];
+    const uint32_t tid = threadIdx.x;
     const uint32_t f2 = 1u << (bin_shift - REGION_SHIFT), omask = (1u << bin_shift) - 1u;
     const uint32_t bin = blockIdx.x;
     const uint64_t lo = binbase[bin], hi = binbase[bin + 1];
-    for (uint32_t i = tid; i < f2; i += 1024u) cnt[i] = 0u;
+    for (uint32_t i = tid; i < f2; i += PART_WG) cnt[i] = 0u;
     __syncthreads();
-    // the bin's records in aligned groups of four (16-byte loads); records outside [lo, hi) read as 0 = no record
-    const uint64_t q0 = lo >> 2, q1 = (hi + 3u) >> 2;
-    const uint4 *rq = reinterpret_cast<const uint4 *>(recs);
-    auto load4 = [&](uint64_t q) -> uint4 {
-        if (q >= q1) return make_uint4(0u, 0u, 0u, 0u);
-        uint4 v = rq[q];
-        const uint64_t i = q << 2;
-        if (i < lo || i + 3u >= hi) {
-            v.x = (i >= lo && i < hi) ? v.x : 0u; v.y = (i + 1u >= lo && i + 1u < hi) ? v.y : 0u;
-            v.z = (i + 2u >= lo && i + 2u < hi) ? v.z : 0u; v.w = (i + 3u >= lo && i + 3u < hi) ? v.w : 0u;
-        }
-        return v;
-    };
-    constexpr uint32_t U = 4;
-    for (uint64_t qb = q0; qb < q1; qb += 1024ull * U) {
-        uint4 r[U];
-#pragma unroll
-        for (uint32_t u = 0; u < U; ++u) r[u] = load4(qb + 1024ull * u + tid);
-#pragma unroll
-        for (uint32_t u = 0; u < U; ++u) {
-            const uint32_t w[4] = {r[u].x, r[u].y, r[u].z, r[u].w};
-#pragma unroll
-            for (int k = 0; k < 4; ++k) if (w[k] >> bin_shift) atomicAdd(&cnt[(w[k] & omask) >> REGION_SHIFT], 1u);
-        }
-    }
-    __syncthreads();
-    // exclusive prefix over the f2 <= 512 counters: thread i takes counter i
+    // ---- sweep 1: records per region.  Aligned groups of four records (16-byte loads); records outside [lo, hi)
+    // read as 0 = no record (t == 0)
     {
-        const uint32_t v = tid < f2 ? cnt[tid] : 0u;
-        const uint32_t incl = wave_incl_scan(v);
-        if (lane == 63u) wsum[wave] = incl;
-        __syncthreads();
-        uint32_t pre = 0;
-        for (uint32_t k = 0; k < wave; ++k) pre += wsum[k];
-        if (tid < f2) { cur[tid] = pre + incl - v; regbase[(size_t)bin * f2 + tid] = lo + pre + incl - v; }
+        const uint64_t q0 = lo >> 2, q1 = (hi + 3u) >> 2;
+        const uint4 *rq = reinterpret_cast<const uint4 *>(recs);
+        constexpr uint32_t U = 4;
+        for (uint64_t qb = q0; qb < q1; qb += (uint64_t)PART_WG * U) {
+            uint4 r[U];
+#pragma unroll
+            for (uint32_t u = 0; u < U; ++u) {
+                const uint64_t q = qb + (uint64_t)PART_WG * u + tid;
+                uint4 v = make_uint4(0u, 0u, 0u, 0u);
+                if (q < q1) {
+                    v = rq[q];
+                    const uint64_t i = q << 2;
+                    if (i < lo || i + 3u >= hi) {
+                        v.x = (i >= lo && i < hi) ? v.x : 0u; v.y = (i + 1u >= lo && i + 1u < hi) ? v.y : 0u;
+                        v.z = (i + 2u >= lo && i + 2u < hi) ? v.z : 0u; v.w = (i + 3u >= lo && i + 3u < hi) ? v.w : 0u;
+                    }
+                }
+                r[u] = v;
+            }
+#pragma unroll
+            for (uint32_t u = 0; u < U; ++u) {
+                const uint32_t wv[4] = {r[u].x, r[u].y, r[u].z, r[u].w};
+#pragma unroll
+                for (int k = 0; k < 4; ++k) if (wv[k] >> bin_shift) atomicAdd(&cnt[(wv[k] & omask) >> REGION_SHIFT], 1u);
+            }
+        }
     }
     __syncthreads();
-    for (uint64_t qb = q0; qb < q1; qb += 1024ull * U) {
-        uint4 r[U];
+    part_scan(cnt, gcur, f2, wsum);                                  // gcur[sub] = where region sub starts inside the bin
+    for (uint32_t i = tid; i < f2; i += PART_WG) { regbase[(size_t)bin * f2 + i] = lo + gcur[i]; cnt[i] = 0u; }
+    __syncthreads();
+    // ---- sweep 2: tile by tile into the regions' ranges (the next tile's records are loaded meanwhile)
+    auto load_tile = [&](uint64_t t0, uint32_t (&v)[PART_PER]) {
+        const uint32_t tn = hi - t0 < PART_TILE ? (uint32_t)(hi - t0) : PART_TILE;
 #pragma unroll
-        for (uint32_t u = 0; u < U; ++u) r[u] = load4(qb + 1024ull * u + tid);
-#pragma unroll
-        for (uint32_t u = 0; u < U; ++u) {
-            const uint32_t w[4] = {r[u].x, r[u].y, r[u].z, r[u].w};
-#pragma unroll
-            for (int k = 0; k < 4; ++k)
-                if (w[k] >> bin_shift) {
-                    const uint32_t pos = atomicAdd(&cur[(w[k] & omask) >> REGION_SHIFT], 1u);
-                    out[lo + pos] = w[k];
-                }
+        for (uint32_t j = 0; j < PART_PER; ++j) {
+            const uint32_t i = j * PART_WG + tid;
+            v[j] = i < tn ? recs[t0 + i] : 0u;
         }
+    };
+    uint32_t nxt[PART_PER];
+    if (lo < hi) load_tile(lo, nxt);
+    for (uint64_t t0 = lo; t0 < hi; t0 += PART_TILE) {
+        const uint32_t tn = hi - t0 < PART_TILE ? (uint32_t)(hi - t0) : PART_TILE;
+        uint32_t val[PART_PER], dr[PART_PER];
+#pragma unroll
+        for (uint32_t j = 0; j < PART_PER; ++j) {
+            val[j] = nxt[j]; dr[j] = ~0u;
+            if (val[j] >> bin_shift) {
+                const uint32_t d = (val[j] & omask) >> REGION_SHIFT;
+                dr[j] = d | (atomicAdd(&cnt[d], 1u) << 12);
+            }
+        }
+        if (t0 + PART_TILE < hi) load_tile(t0 + PART_TILE, nxt);
+        __syncthreads();
+        part_scan(cnt, toff, f2, wsum);
+#pragma unroll
+        for (uint32_t j = 0; j < PART_PER; ++j)
+            if (dr[j] != ~0u) {
+                const uint32_t d = dr[j] & 0xFFFu, r = dr[j] >> 12;
+                stage[toff[d] + r] = make_uint2(gcur[d] + r, val[j]);
+            }
+        __syncthreads();
+        for (uint32_t i = tid; i < tn; i += PART_WG) { const uint2 sv = stage[i]; out[lo + sv.x] = sv.y; }
+        __syncthreads();
+        for (uint32_t i = tid; i < f2; i += PART_WG) { gcur[i] += cnt[i]; cnt[i] = 0u; }
+        __syncthreads();
     }
 }
 
@@ -1735,13 +1797,18 @@ void launch_bin_rowscan(uint32_t *counts, uint32_t *totals, uint32_t n_bins, uin
 
 void launch_part(const ScanArgs &a, uint32_t n_prod, const uint64_t *binbase, uint32_t *out, hipStream_t st)
 {
-    hipLaunchKernelGGL(k_part, dim3(n_prod), dim3(SCANK_WG), (size_t)a.n_bins * 12u, st, a, binbase, out);
+    static bool attr_set = false;
+    if (!attr_set) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(k_part), hipFuncAttributeMaxDynamicSharedMemorySize, (int)(BIN_MAX * 12u));
+        attr_set = true;
+    }
+    hipLaunchKernelGGL(k_part, dim3(n_prod), dim3(PART_WG), (size_t)a.n_bins * 12u, st, a, binbase, out);
 }
 
 void launch_part2(const uint32_t *recs, const uint64_t *binbase, uint32_t n_bins, uint32_t bin_shift, uint64_t *regbase,
                   uint32_t *out, hipStream_t st)
 {
-    hipLaunchKernelGGL(k_part2, dim3(n_bins), dim3(1024), 0, st, recs, binbase, bin_shift, regbase, out);
+    hipLaunchKernelGGL(k_part2, dim3(n_bins), dim3(PART_WG), 0, st, recs, binbase, bin_shift, regbase, out);
 }
 
 void launch_apply(uint8_t *sim, size_t sim_bytes, const uint32_t *recs, const uint64_t *regbase, uint32_t bin_shift, hipStream_t st)
