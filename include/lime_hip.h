@@ -68,6 +68,18 @@ typedef struct {
 #define LIME_FLAG_OVERFLOW 16u   /* an internal cluster list was too small (cannot happen with the default sizing) */
 #define LIME_FLAG_POOL_FULL 32u  /* binned table updates: the record pool was too small; lime_get_stats repeats the pass */
 
+/* Edge word of a shard (lime_stats_t.edge): what the host needs to decide about a run that crosses shard borders
+ * and is longer than the read-ahead halo.  LEAD_*: the positions before the shard's first cluster head (they belong
+ * to a run that started in an earlier shard) hold a read / a genome, and whether the shard has a head at all.
+ * OPEN*: a run headed in the shard's owned range is still open at the end of its arrays (and already longer than
+ * LIME_MAX_CLUSTER), with what it holds so far.  lime_combine_edges decides. */
+#define LIME_EDGE_LEAD_HEAD 1u
+#define LIME_EDGE_LEAD_R    2u
+#define LIME_EDGE_LEAD_G    4u
+#define LIME_EDGE_OPEN      8u
+#define LIME_EDGE_OPEN_R   16u
+#define LIME_EDGE_OPEN_G   32u
+
 /* ---- lifecycle ------------------------------------------------------------------------ */
 /* device < 0: keep the process's current HIP device.  Replaces the reference's
  * omp_set_num_threads set-up (ClusterLCP.cpp:73-84). */
@@ -139,6 +151,14 @@ int lime_fused_dev(lime_ctx *ctx, const uint32_t *d_lcp, const uint32_t *d_da,
                    const uint8_t *d_ebwt, uint64_t n_own, uint64_t n_avail, int eof,
                    uint32_t n_reads, uint32_t n_refs, uint32_t alpha,
                    uint8_t *d_sim, int zero_sim, void *stream);
+
+/* Runs longer than the halo that cross shard borders: the reference reads on without limit (ClusterLCP.cpp:246-264)
+ * and only refuses CLUSTERS longer than LIME_MAX_CLUSTER (ClusterBWT_DA.cpp:558-562).  A shard that ends inside such a
+ * run reports it in lime_stats_t.edge (and lime_get_stats returns LIME_ERR_HALO to callers that do not look);
+ * edge[k] = the edge word of shard k, shards in position order, the first one starting at position 0 and the last one
+ * run with eof != 0.  Returns LIME_OK if no border-crossing run is a read+genome cluster (nothing to score: the
+ * shards' tables are complete), LIME_ERR_MAXLEN if one is (the reference fails on such input too). */
+int lime_combine_edges(const uint32_t *edge, uint32_t n_shards);
 
 /* Detection only.  *d_clusters: library-owned DEVICE buffer valid until the next
  * lime_detect_dev/lime_shutdown on this ctx; pStart = pos_base + local position.

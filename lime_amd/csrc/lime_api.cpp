@@ -203,6 +203,7 @@ static ScanArgs base_args(lime_ctx *c, const uint32_t *lcp, const uint32_t *da, 
     a.small = c->d_small; a.cross_cap = c->small_cap; a.big = c->d_big; a.big_cap = c->big_cap;
     a.tile_cnt = c->d_tile_cnt; a.tile_off = c->d_tile_off; a.cross = c->d_cross; a.out = c->d_out;
     a.wmask = c->d_wmask;
+    a.edge = &c->d_stats->edge;
     a.ablate = c->ablate;
     return a;
 }
@@ -309,7 +310,8 @@ static int ensure_binned(lime_ctx *c, uint64_t n_own, uint32_t n_waves, uint32_t
 // cluster / update counters and flags accumulate, only the per-call list counters restart.
 static int fused_dev_impl(lime_ctx *c, const uint32_t *d_lcp, const uint32_t *d_da, const uint8_t *d_ebwt,
                           uint64_t n_own, uint64_t n_avail, int eof, uint32_t n_reads, uint32_t n_refs,
-                          uint32_t alpha, uint8_t *d_sim, int zero_sim, bool keep_stats, hipStream_t st)
+                          uint32_t alpha, uint8_t *d_sim, int zero_sim, bool keep_stats, hipStream_t st,
+                          uint32_t *d_edge = nullptr)
 {
     int rc;
     if (n_own > n_avail) return fail(LIME_ERR_ARG, "lime_fused_dev: n_own > n_avail");
@@ -347,6 +349,7 @@ static int fused_dev_impl(lime_ctx *c, const uint32_t *d_lcp, const uint32_t *d_
     if (zero_sim && !binned) HIP_TRY(hipMemsetAsync(d_sim, 0, sim_bytes, st));           // the binned path writes every byte itself
     if (!n_avail) { if ((rc = timing_mark(c, st)) || (rc = timing_mark(c, st)) || (rc = timing_mark(c, st))) return rc; return LIME_OK; }
     ScanArgs a = base_args(c, d_lcp, d_da, d_ebwt, n_own, n_avail, eof, n_reads, n_refs, alpha, d_sim);
+    if (d_edge) a.edge = d_edge;                          // a chunk of a stream: its own (cleared) word
     if (binned) {
         a.upd_mode = 1; a.pool = c->d_pool; a.cap_w = cap_w; a.wave_cnt = c->d_wave_cnt; a.counts = c->d_counts;
         a.n_bins = n_bins; a.bin_shift = bin_shift;
@@ -424,7 +427,29 @@ extern "C" int lime_get_stats(lime_ctx *c, lime_stats_t *out, void *stream)
     if (out) *out = s;
     if (c->big_cap && s.n_big > c->big_cap)
         return fail(LIME_ERR_NOMEM, "more clusters longer than %u symbols (%u) than the list holds (%u)", SMALL_MAX, s.n_big, c->big_cap);
-    return flags_to_rc(s.flags);
+    if ((rc = flags_to_rc(s.flags))) return rc;
+    if (s.edge & LIME_EDGE_OPEN)
+        return fail(LIME_ERR_HALO, "a run owned by this shard is still open where its arrays end: whether it is a cluster is decided by "
+                                   "the shards' edge words together (lime_combine_edges)");
+    return LIME_OK;
+}
+
+extern "C" int lime_combine_edges(const uint32_t *edge, uint32_t n_shards)
+{
+    if (n_shards && !edge) return fail(LIME_ERR_ARG, "lime_combine_edges: edge is NULL");
+    bool open = false, r = false, g = false;
+    for (uint32_t k = 0; k < n_shards; ++k) {
+        const uint32_t e = edge[k];
+        if (open) {                                        // the run goes on through this shard's leading positions
+            r = r || (e & LIME_EDGE_LEAD_R); g = g || (e & LIME_EDGE_LEAD_G);
+            if ((e & LIME_EDGE_LEAD_HEAD) || k + 1 == n_shards) {          // closed by a head, or by the end of the collection
+                if (r && g) return fail(LIME_ERR_MAXLEN, "maximum cluster size is greater than %u (sizeMaxBuf): a cluster crosses shard borders", LIME_MAX_CLUSTER);
+                open = false;
+            }
+        }
+        if (e & LIME_EDGE_OPEN) { open = true; r = (e & LIME_EDGE_OPEN_R) != 0; g = (e & LIME_EDGE_OPEN_G) != 0; }
+    }
+    return LIME_OK;
 }
 
 extern "C" int lime_detect_dev(lime_ctx *c, const uint32_t *d_lcp, const uint32_t *d_da, uint64_t n_own,
@@ -590,6 +615,10 @@ extern "C" int lime_fused_stream(lime_ctx *c, const uint32_t *lcp, const uint32_
     }
     if ((rc = ds.alloc(lime_sim_bytes(n_reads, n_refs)))) return rc;
     if (!n) HIP_TRY(hipMemsetAsync(ds.p, 0, lime_sim_bytes(n_reads, n_refs), pp.comp));
+    const uint64_t n_chunks = (n + chunk - 1) / chunk;
+    DevBuf dedge;                                          // one edge word per chunk (runs longer than the halo across chunk borders)
+    if ((rc = dedge.alloc((size_t)(n_chunks + 1) * 4))) return rc;
+    HIP_TRY(hipMemsetAsync(dedge.p, 0, (size_t)(n_chunks + 1) * 4, pp.comp));
     uint64_t k = 0;
     for (uint64_t lo = 0; lo < n; lo += chunk, ++k) {
         const int b = (int)(k & 1);
@@ -603,7 +632,7 @@ extern "C" int lime_fused_stream(lime_ctx *c, const uint32_t *lcp, const uint32_
         HIP_TRY(hipEventRecord(pp.copied[b], pp.copy));
         HIP_TRY(hipStreamWaitEvent(pp.comp, pp.copied[b], 0));
         rc = fused_dev_impl(c, (const uint32_t *)dl[b].p, (const uint32_t *)dd[b].p, ebwt ? (const uint8_t *)de[b].p : nullptr,
-                            own, avail, eof, n_reads, n_refs, alpha, (uint8_t *)ds.p, k == 0, k != 0, pp.comp);
+                            own, avail, eof, n_reads, n_refs, alpha, (uint8_t *)ds.p, k == 0, k != 0, pp.comp, (uint32_t *)dedge.p + k);
         if (rc) { (void)hipDeviceSynchronize(); return rc; }
         HIP_TRY(hipEventRecord(pp.consumed[b], pp.comp));
     }
@@ -612,6 +641,12 @@ extern "C" int lime_fused_stream(lime_ctx *c, const uint32_t *lcp, const uint32_
     if (n_clusters) *n_clusters = n ? s.n_clusters : 0;
     if (max_len) *max_len = n ? s.max_len : 0;
     if (rc) { (void)hipDeviceSynchronize(); return rc; }
+    if (n_chunks > 1) {
+        std::vector<uint32_t> edges(n_chunks);
+        HIP_TRY(hipMemcpyAsync(edges.data(), dedge.p, (size_t)n_chunks * 4, hipMemcpyDeviceToHost, pp.comp));
+        HIP_TRY(hipStreamSynchronize(pp.comp));
+        if ((rc = lime_combine_edges(edges.data(), (uint32_t)n_chunks))) { (void)hipDeviceSynchronize(); return rc; }
+    }
     HIP_TRY(hipMemcpyAsync(sim, ds.p, (size_t)n_reads * n_refs, hipMemcpyDeviceToHost, pp.comp));
     HIP_TRY(hipStreamSynchronize(pp.comp));
     HIP_TRY(hipStreamSynchronize(pp.copy));

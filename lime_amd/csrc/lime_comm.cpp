@@ -207,12 +207,17 @@ extern "C" int lime_fused_multi(int n_dev, const int *devices, const uint32_t *l
         if (rc) return cfail(rc, "device %d: %s", devs[k], lime_last_error());
     }
     uint64_t tot = 0, mx = 0;
+    std::vector<uint32_t> edges(n_dev);
     for (int k = 0; k < n_dev; ++k) {
         HIP_TRYC(hipSetDevice(devs[k]));
         lime_stats_t s;
-        if ((rc = lime_get_stats(ds[k].ctx, &s, ds[k].st))) return cfail(rc, "device %d: %s", devs[k], lime_last_error());
+        rc = lime_get_stats(ds[k].ctx, &s, ds[k].st);
+        if (rc && !(rc == LIME_ERR_HALO && (s.edge & LIME_EDGE_OPEN))) return cfail(rc, "device %d: %s", devs[k], lime_last_error());
         tot += s.n_clusters; if (s.max_len > mx) mx = s.max_len;
+        edges[k] = s.edge;
     }
+    // runs longer than the halo across range borders: clusters among them are refused, the others are nothing
+    if ((rc = lime_combine_edges(edges.data(), (uint32_t)n_dev))) return cfail(rc, "%s", lime_last_error());
     if (n_clusters) *n_clusters = tot;
     if (max_len) *max_len = mx;
     if (n_dev == 1) {

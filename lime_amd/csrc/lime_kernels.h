@@ -61,6 +61,7 @@ struct ScanArgs {
     lime_cluster_t *big; uint32_t big_cap;       // clusters > SMALL_MAX
     uint32_t *tile_cnt; uint64_t *tile_off; CrossRec *cross; lime_cluster_t *out;   // detect only
     WinMasks *wmask;                             // detect only: count pass -> emit pass
+    uint32_t *edge;                              // LIME_EDGE_* word of this shard (default: &stats->edge)
     int ablate;                                  // timing experiments only (LIME_ABLATE_BUILD): 0 = full kernel
     // binned table updates (upd_mode 1; 0 = compare-and-swap on the table)
     int upd_mode;

@@ -828,6 +828,18 @@ struct Ctx16 {
     uint32_t info;      // fh | lh << 5 | pre_r << 10 | pre_g << 11 | suf_r << 12 | suf_g << 13
 };
 
+// An owned run that is still open where the shard's arrays end, with more of the collection behind them
+// (ClusterLCP.cpp:246-264 would read on).  Longer than LIME_MAX_CLUSTER already: if it holds a read and a genome
+// it is a cluster ClusterBWT_DA refuses (:558-562) -- error now; else whether it becomes one is decided by the
+// shards after this one: leave its content in the shard's edge word for the host to combine (lime_combine_edges).
+// Shorter (a caller with a halo below LIME_MAX_CLUSTER): cannot be decided here -> LIME_FLAG_HALO.
+__device__ __forceinline__ void open_run_at_end(const ScanArgs &a, uint64_t len_so_far, bool has_r, bool has_g)
+{
+    if (len_so_far <= LIME_MAX_CLUSTER) { atomicOr(&a.stats->flags, LIME_FLAG_HALO); return; }
+    if (has_r && has_g) { atomicOr(&a.stats->flags, LIME_FLAG_MAXLEN); return; }
+    atomicOr(a.edge, LIME_EDGE_OPEN | (has_r ? LIME_EDGE_OPEN_R : 0u) | (has_g ? LIME_EDGE_OPEN_G : 0u));
+}
+
 // H64 / R64 / G64: the read-ahead chunk (16 bits, wave-uniform).  own_lim <= WIN.
 __device__ __forceinline__ Ctx16 chunk_context(uint32_t h, uint32_t r, uint32_t g, uint32_t H64, uint32_t R64, uint32_t G64,
                                                 uint32_t own_lim)
@@ -1003,8 +1015,16 @@ __global__ __launch_bounds__(SCANK_WG) __attribute__((amdgpu_waves_per_eu(LIME_S
                 if (dw) {
                     const uint32_t lw2 = 63u - (uint32_t)__clzll((long long)dw);
                     const uint32_t hl2 = rl32(dh, lw2);
-                    const uint32_t sstar = PPL * lw2 + 31u - (uint32_t)__builtin_clz(hl2);
-                    if (lane == 0 && sstar < own_lim) atomicOr(&a.stats->flags, LIME_FLAG_HALO);
+                    const uint32_t bp = 31u - (uint32_t)__builtin_clz(hl2), sstar = PPL * lw2 + bp;
+                    if (MODE == 1) {                           // detection alone has no length limit: the host starts over with one chunk
+                        if (lane == 0 && sstar < own_lim) atomicOr(&a.stats->flags, LIME_FLAG_HALO);
+                    } else {
+                        // what the open run holds so far: its head's chunk from the head on, the chunks after it, the read-ahead
+                        const uint32_t cm = lane > lw2 ? 0xFFFFu : (lane == lw2 ? (0xFFFFu << bp) & 0xFFFFu : 0u);
+                        const bool hr = __ballot((rb & vb & cm) != 0u) != 0ull || R64 != 0u;
+                        const bool hg = __ballot((gb & cm) != 0u) != 0ull || G64 != 0u;
+                        if (lane == 0 && sstar < own_lim) open_run_at_end(a, a.n_avail - (lo + sstar), hr, hg);
+                    }
                 }
             }
         }
@@ -1173,6 +1193,17 @@ __global__ __launch_bounds__(256) void k_resolve(ScanArgs a)
     const uint32_t t = blockIdx.x * 256u + threadIdx.x;
     if (t >= a.n_tiles) return;
     if (MODE == 1) { CrossRec z; z.start = 0; z.len = 0; a.cross[t] = z; }
+    if (MODE == 0 && t == 0u) {
+        // what lies before the shard's first head belongs to a run of an earlier shard: its content for the
+        // host's combination of the shards' edge words
+        uint32_t lead = 0;
+        for (uint32_t u = 0; u < a.n_tiles; ++u) {
+            const TileSummary o = a.summ[u];
+            lead |= ((o.pre & 1u) ? LIME_EDGE_LEAD_R : 0u) | ((o.pre & 2u) ? LIME_EDGE_LEAD_G : 0u);
+            if (o.first_head != NONE32) { if ((uint64_t)u * WIN + o.first_head < a.n_avail) lead |= LIME_EDGE_LEAD_HEAD; break; }
+        }
+        atomicOr(a.edge, lead);
+    }
     const TileSummary me = a.summ[t];
     if (me.last_head == NONE32) return;
     const uint64_t s = (uint64_t)t * WIN + me.last_head;
@@ -1186,8 +1217,12 @@ __global__ __launch_bounds__(256) void k_resolve(ScanArgs a)
         if (o.first_head != NONE32) { e = (uint64_t)u * WIN + o.first_head; closed_by_data = true; break; }
     }
     if (e >= a.n_avail) { e = a.n_avail; closed_by_data = false; }
+    if (!closed_by_data && !a.eof) {                            // still open where the shard's arrays end
+        if (MODE == 1) { if (e >= ((uint64_t)t + 1u) * WIN + HALO) atomicOr(&a.stats->flags, LIME_FLAG_HALO); }   // (inside the read-ahead: k_scan saw it)
+        else open_run_at_end(a, e - s, (fl & 1u) != 0u, (fl & 2u) != 0u);
+        return;
+    }
     if (e < ((uint64_t)t + 1u) * WIN + HALO) return;            // seen (and handled) inside the window's read-ahead
-    if (!closed_by_data && !a.eof) { atomicOr(&a.stats->flags, LIME_FLAG_HALO); return; }
     const uint64_t len = e - s;
     if (fl != 3u || len < 2u) return;
     atomicAdd(&a.stats->n_clusters, 1ull);

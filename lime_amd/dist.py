@@ -54,6 +54,18 @@ def reduce_scatter_tables(sim_t, out_t, group=None, async_op=False):
     return dist.reduce_scatter_tensor(out_t, sim_t, op=dist.ReduceOp.SUM, group=group, async_op=async_op)
 
 
+def combine_edges(edges):
+    """edges[k] = lime_stats_t.edge of shard k (position order): raises LimeError(LIME_ERR_MAXLEN) if a run that
+    crosses shard borders is a read+genome cluster (the reference refuses it too), else returns None"""
+    import numpy as np
+    from . import _lib
+    e = np.ascontiguousarray(edges, dtype=np.uint32)
+    _lib.check(_lib.load().lime_combine_edges(e.ctypes.data, len(e)))
+
+
+EDGE_OPEN = 8
+
+
 class Comm:
     """The exchange step through the C ABI (include/lime_hip.h, lime_comm_*): RCCL ncclReduceScatter / ncclAllReduce
     on ncclUint8 with ncclSum, one rank per GPU.  torch.distributed is the control plane only: it carries the

@@ -112,3 +112,26 @@ def test_clrs_and_aux_writers(golden, tmp_path):
     nr, ng, al, m, n = C.c_uint32(), C.c_uint32(), C.c_uint32(), C.c_uint64(), C.c_uint64()
     assert lib.lime_read_aux(a, C.byref(nr), C.byref(ng), C.byref(al), C.byref(m), C.byref(n)) == 0
     assert (nr.value, ng.value, al.value, m.value, n.value) == (golden["n_reads"], golden["n_refs"], golden["alpha"], ml, len(cl))
+
+
+def test_combine_edges_host_logic():
+    """lime_combine_edges (pure host): runs longer than the halo across shard borders -- closed by a later shard's
+    first head or by the end of the collection; only a read+genome run is an error (ClusterBWT_DA.cpp:558-562)"""
+    import ctypes as C
+    import numpy as np
+    from lime_amd import _lib
+    lib = _lib.load()
+    HEAD, LR, LG, OPEN, OR, OG = 1, 2, 4, 8, 16, 32
+
+    def rc(*e):
+        a = np.array(e, dtype=np.uint32)
+        return lib.lime_combine_edges(a.ctypes.data, len(a))
+    assert rc() == 0 and rc(HEAD) == 0
+    assert rc(HEAD | OPEN | OG, HEAD | LG) == 0                       # genome-only run closed in the next shard
+    assert rc(HEAD | OPEN | OG, HEAD | LG | LR) == -4                 # ... a read joins before it closes: a cluster
+    assert rc(HEAD | OPEN | OR, LR, LR | LG | HEAD) == -4             # through a shard without any head
+    assert rc(HEAD | OPEN | OR, LR, LR | HEAD) == 0
+    assert rc(HEAD | OPEN | OR, LG) == -4                             # closed by the end of the collection
+    assert rc(HEAD | OPEN | OR, LR) == 0
+    assert rc(HEAD | LR | LG, HEAD | LR | LG) == 0                    # leading content without an open run: nothing
+    assert rc(HEAD | OPEN | OG, HEAD | LG | OPEN | OR, HEAD | LR) == 0  # two separate long runs

@@ -478,6 +478,101 @@ def test_clusters_of_up_to_64_symbols_with_few_documents(ctx, length, nr, ng):
         assert np.array_equal(ctx.score(da, e, cl, nr, ng), exp)
 
 
+def _long_run_case(kind):
+    """700 000 positions with one run of 250 000 (far longer than the 69 632-position halo of a chunk / shard):
+    genome-only, read-only, or reads with one genome near its end (a cluster of 250 000: refused)"""
+    n, nr, ng = 700000, 40, 9
+    lcp, da, eb = O.synth(99, 0, n, nr, ng, 16, 0)
+    a, b = 200000, 450000
+    lcp[a + 1:b] = 40; lcp[a] = 0; lcp[b] = 0
+    if kind == "genomes":
+        da[a:b] = nr + (np.arange(b - a) % ng)
+    elif kind == "reads":
+        da[a:b] = np.arange(b - a) % nr
+    else:
+        da[a:b] = np.arange(b - a) % nr
+        da[b - 10] = nr + 2                             # reads for 249 990 positions, then one genome: a cluster after all
+    return n, nr, ng, lcp.astype(np.uint32), da.astype(np.uint32), eb
+
+
+@pytest.mark.parametrize("kind", ["genomes", "reads"])
+def test_long_run_that_is_no_cluster_crosses_chunks_and_shards(ctx, kind):
+    """the reference reads on without limit and refuses only CLUSTERS longer than 65536 (ClusterLCP.cpp:246-264,
+    ClusterBWT_DA.cpp:558-562): a genome-only (read-only) run of 250 000 positions across chunk / shard borders is
+    nothing at all"""
+    import torch
+    import lime_amd
+    from lime_amd.dist import shard_ranges, combine_edges
+    n, nr, ng, lcp, da, eb = _long_run_case(kind)
+    cl, nc, ml = O.detect(lcp, da, nr, 16)
+    assert ml < 100
+    exp = O.score(da, eb, cl, nr, ng, threads=4)
+    for chunk in (4096, 65536):
+        sim, gnc, gml = ctx.fused_stream(lcp, da, eb, nr, ng, 16, chunk=chunk)
+        assert (gnc, gml) == (nc, ml) and np.array_equal(sim, exp)
+    total = np.zeros((nr, ng), np.uint8); tot_c = 0; edges = []; saw_open = False
+    for lo, hi, hh in shard_ranges(n, 5):
+        tl = torch.from_numpy(lcp[lo:hh].view(np.int32)).cuda(); td = torch.from_numpy(da[lo:hh].view(np.int32)).cuda()
+        te = torch.from_numpy(eb[lo:hh]).cuda()
+        sim = torch.zeros(lime_sim_bytes(nr, ng), dtype=torch.uint8, device="cuda")
+        ctx.fused_dev(tl, td, te, hi - lo, hh - lo, hh == n, nr, ng, 16, sim)
+        s, rc = ctx.stats()
+        assert rc == 0 or (rc == -5 and s.edge & 8), (rc, s.edge)          # LIME_ERR_HALO only with an open run reported
+        saw_open |= bool(s.edge & 8)
+        edges.append(s.edge); tot_c += s.n_clusters
+        total = (total + sim[:nr * ng].cpu().numpy().reshape(nr, ng)).astype(np.uint8)
+    assert saw_open
+    combine_edges(edges)                                                   # no cluster among the border-crossing runs
+    assert tot_c == nc and np.array_equal(total, exp)
+
+
+def test_long_cluster_across_chunks_is_refused(ctx):
+    import torch
+    import lime_amd
+    from lime_amd.dist import shard_ranges, combine_edges
+    n, nr, ng, lcp, da, eb = _long_run_case("cluster")
+    cl, nc, ml = O.detect(lcp, da, nr, 16)
+    assert ml == 250000
+    with pytest.raises(lime_amd.LimeError) as e:
+        ctx.fused_stream(lcp, da, eb, nr, ng, 16, chunk=65536)
+    assert e.value.code == -4
+    edges = []
+    for lo, hi, hh in shard_ranges(n, 5):
+        tl = torch.from_numpy(lcp[lo:hh].view(np.int32)).cuda(); td = torch.from_numpy(da[lo:hh].view(np.int32)).cuda()
+        sim = torch.zeros(lime_sim_bytes(nr, ng), dtype=torch.uint8, device="cuda")
+        ctx.fused_dev(tl, td, None, hi - lo, hh - lo, hh == n, nr, ng, 16, sim)
+        s, rc = ctx.stats()
+        assert rc == 0 or (rc == -5 and s.edge & 8)     # no shard sees a read and a genome of the run by itself
+        edges.append(s.edge)
+    with pytest.raises(lime_amd.LimeError) as e:
+        combine_edges(edges)
+    assert e.value.code == -4
+
+
+@pytest.mark.parametrize("n", [1024, 4096, 5000, 65536, 300032])
+def test_nothing_beyond_n_avail_is_used(ctx, n):
+    """the arrays handed to lime_fused_dev / lime_detect_dev end exactly at n_avail inside larger device buffers whose
+    continuation is poison (runs that would go on, reads and genomes that would complete clusters): results must be
+    those of the first n positions alone -- n a multiple of the 1024-position window (no partial window, nothing
+    after the last one but the poison) and not"""
+    import torch
+    nr, ng = 300, 25
+    lcp, da, eb = O.synth(4242 + n, 0, n + 2048, nr, ng, 16, 1)
+    lcp[n:] = 99                                   # the data "goes on" as one long run of alternating read / genome
+    da[n:] = np.where(np.arange(2048) % 2 == 0, 0, nr).astype(np.uint32)
+    cl, nc, ml = O.detect(lcp[:n], da[:n], nr, 16)
+    tl = torch.from_numpy(lcp.view(np.int32)).cuda(); td = torch.from_numpy(da.view(np.int32)).cuda(); te = torch.from_numpy(eb).cuda()
+    for e, et in ((eb, te), (None, None)):
+        exp = O.score(da[:n], None if e is None else e[:n], cl, nr, ng, threads=4)
+        sim = torch.zeros(lime_sim_bytes(nr, ng), dtype=torch.uint8, device="cuda")
+        ctx.fused_dev(tl, td, et, n, n, True, nr, ng, 16, sim)
+        s, rc = ctx.stats()
+        assert rc == 0 and (s.n_clusters, s.max_len) == (nc, ml)
+        assert np.array_equal(sim[:nr * ng].cpu().numpy().reshape(nr, ng), exp)
+    ptr, gnc, gml = ctx.detect_dev(tl, td, n, n, True, 0, nr, 16)
+    assert (gnc, gml) == (nc, ml)
+
+
 def lime_sim_bytes(nr, ng):
     import lime_amd
     return lime_amd.sim_bytes(nr, ng)
