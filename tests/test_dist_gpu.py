@@ -1,0 +1,126 @@
+"""Two ranks on ONE GPU (gloo control plane, every rank on cuda:0) driving the HIP path per rank: each rank scans its
+position range with lime_fused_dev, the per-rank uint8 tables are summed block-wise (HostComm: the host-staged stand-in
+for the RCCL reduce-scatter, which wants one GPU per rank), rank 0 checks the blocks against the oracle.  Also the
+bench's N>1 control flow under the same rehearsal backend.  The RCCL calls themselves run on one rank here
+(world size 1) -- the 8-GPU node is the driver's."""
+import json
+import os
+import socket
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+pytestmark = pytest.mark.gpu
+
+WORKER = r'''
+import os, sys
+import numpy as np, torch, torch.distributed as dist
+sys.path.insert(0, os.environ["LIME_ROOT"])
+import lime_amd
+from lime_amd import dist as ldist
+from oracle import oracle_py as O
+rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
+torch.cuda.set_device(0); dev = torch.device("cuda", 0)
+dist.init_process_group("gloo")
+comm = ldist.HostComm(rank, world, dev); comm.check_uint8_sum_wraps()
+n, nr, ng = 900001, 700, 90
+lcp, da, eb = O.synth(21, 0, n, nr, ng, 16, 1)
+lcp[449000:451000] = 30                                        # a run across the cut between the two ranges
+lo, hi, hh = ldist.shard_ranges(n, world)[rank]
+ctx = lime_amd.Context(0)
+sim_bytes = lime_amd.sim_bytes(nr, ng); blk = ldist.table_block_bytes(sim_bytes, world)
+for e in (eb, None):
+    tl = torch.from_numpy(lcp[lo:hh].view(np.int32)).to(dev); td = torch.from_numpy(da[lo:hh].view(np.int32)).to(dev)
+    te = None if e is None else torch.from_numpy(e[lo:hh]).to(dev)
+    sim = torch.zeros(blk * world, dtype=torch.uint8, device=dev); mine = torch.empty(blk, dtype=torch.uint8, device=dev)
+    ctx.fused_dev(tl, td, te, hi - lo, hh - lo, hh == n, nr, ng, 16, sim)
+    s, rc = ctx.stats(); assert rc == 0, rc
+    comm.reduce_scatter_tables(sim, mine, blk)
+    nc, ml = comm.combine_counters(int(s.n_clusters), int(s.max_len))
+    gathered = [torch.empty(blk, dtype=torch.uint8) for _ in range(world)]
+    dist.all_gather(gathered, mine.cpu())
+    if rank == 0:
+        cl, enc, eml = O.detect(lcp, da, nr, 16)
+        exp = O.score(da, e, cl, nr, ng, threads=4)
+        got = torch.cat(gathered)[:nr * ng].numpy().reshape(nr, ng)
+        assert (nc, ml) == (enc, eml), ((nc, ml), (enc, eml))
+        assert np.array_equal(got, exp), "summed shard tables differ from the oracle"
+ctx.close(); dist.destroy_process_group()
+if rank == 0: print("DIST_OK")
+'''
+
+
+def _free_port():
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); p = s.getsockname()[1]; s.close(); return p
+
+
+def _torchrun(args, env_extra, timeout=600):
+    env = dict(os.environ, LIME_ROOT=ROOT, **env_extra)
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+           "--master-port", str(_free_port())] + args
+    return subprocess.run(cmd, capture_output=True, timeout=timeout, env=env, cwd=ROOT)
+
+
+def test_two_ranks_run_the_hip_path_and_sum_to_the_oracle(tmp_path):
+    w = tmp_path / "worker.py"
+    w.write_text(WORKER)
+    r = _torchrun([str(w)], {})
+    assert r.returncode == 0 and b"DIST_OK" in r.stdout, r.stderr.decode()[-3000:]
+
+
+def test_bench_control_flow_with_two_ranks():
+    """bench.py --gpus 2 (strong scaling of a small collection, exposed and overlapped exchange) under the rehearsal backend"""
+    r = _torchrun(["bench.py", "--gpus", "2", "--steps", "2", "--warmup", "1", "--workload", "c2", "--scaling", "strong",
+                   "--n-total", "30000000"], {"LIME_BENCH_BACKEND": "gloo"})
+    assert r.returncode == 0, r.stderr.decode()[-3000:]
+    line = [ln for ln in r.stdout.decode().splitlines() if ln.startswith("{")][-1]
+    d = json.loads(line)
+    assert d["n_gpus"] == 2 and d["scaling"] == "strong" and d["value"] > 0 and d["also"]["overlapped"]["value"] > 0
+    assert d["config"]["symbols_total"] == 30000000
+
+
+def test_rccl_calls_through_the_c_abi_on_one_rank():
+    """lime_comm_* with a world of one rank (the one GPU of this box): id, init, the uint8 reduce-scatter / all-reduce
+    self-check and the counter combination"""
+    import torch
+    import lime_amd
+    from lime_amd import dist as ldist
+    import torch.distributed as dist
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1"); os.environ["MASTER_PORT"] = str(_free_port())
+    dist.init_process_group("gloo", rank=0, world_size=1)
+    try:
+        dev = torch.device("cuda", 0)
+        comm = ldist.Comm(0, 1, dev)
+        comm.check_uint8_sum_wraps()
+        assert comm.combine_counters(123, 45) == (123, 45)
+        src = torch.arange(4096, dtype=torch.int32, device=dev).to(torch.uint8)
+        out = torch.zeros(4096, dtype=torch.uint8, device=dev)
+        comm.reduce_scatter_tables(src, out, 4096, torch.cuda.current_stream().cuda_stream)
+        torch.cuda.synchronize()
+        assert torch.equal(src, out)
+        comm.close()
+    finally:
+        dist.destroy_process_group()
+
+
+def test_fused_multi_single_device_matches_oracle():
+    """lime_fused_multi (one process, n devices) with the one device of this box"""
+    import ctypes as C
+    import lime_amd
+    from lime_amd import _lib
+    from oracle import oracle_py as O
+    lib = _lib.load()
+    n, nr, ng = 500001, 300, 40
+    lcp, da, eb = O.synth(5, 0, n, nr, ng, 16, 1)
+    cl, nc, ml = O.detect(lcp, da, nr, 16)
+    for e in (eb, None):
+        exp = O.score(da, e, cl, nr, ng, threads=4)
+        sim = np.zeros((nr, ng), np.uint8)
+        gnc, gml = C.c_uint64(0), C.c_uint64(0)
+        rc = lib.lime_fused_multi(1, None, lcp.ctypes.data, da.ctypes.data, None if e is None else e.ctypes.data, n, nr, ng, 16,
+                                  sim.ctypes.data, C.byref(gnc), C.byref(gml))
+        assert rc == 0, lib.lime_comm_error()
+        assert (gnc.value, gml.value) == (nc, ml) and np.array_equal(sim, exp)
