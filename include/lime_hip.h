@@ -233,6 +233,14 @@ int  lime_fused_multi(int n_dev, const int *devices, const uint32_t *lcp, const 
                       uint64_t n, uint32_t n_reads, uint32_t n_refs, uint32_t alpha, uint8_t *sim,
                       uint64_t *n_clusters, uint64_t *max_len);
 
+/* lime_score_choose on n_dev GPUs of one process (what the drop-in ClusterBWT_DA does under LIME_GPUS=k): the cluster
+ * list is cut by position into n_dev parts, every device scores its part into its own table, one RCCL reduce-scatter
+ * by read-row blocks, row scan and list compaction per block.  Outputs as lime_score_choose. */
+int  lime_score_choose_multi(int n_dev, const int *devices, const uint32_t *da, const uint8_t *ebwt, uint64_t n,
+                             const lime_cluster_t *clusters, uint64_t n_clusters, uint32_t n_reads, uint32_t n_refs,
+                             uint32_t norm, float beta, uint8_t *row_max, uint64_t *row_off, lime_pair_t **pairs,
+                             uint64_t *n_pairs);
+
 /* ---- pure host helpers (no device work; used by the CLIs and by CPU-side tests) -------- */
 uint8_t lime_sym_index(uint8_t byte);                              /* ClusterBWT_DA.cpp:455-470 */
 uint8_t lime_pair_score(const uint8_t cr[16], const uint8_t cg[16]); /* :129-177, host build of the device routine */

@@ -78,6 +78,7 @@ SYMBOLS = {
     "lime_comm_allreduce_tables": (_i, [_vp, _vp, _sz, _vp]),
     "lime_comm_combine_counters": (_i, [_vp, _vp, _vp]),
     "lime_fused_multi": (_i, [_i, _vp, _vp, _vp, _vp, _u64, _u32, _u32, _u32, _vp, _pu64, _pu64]),
+    "lime_score_choose_multi": (_i, [_i, _vp, _vp, _vp, _u64, _vp, _u64, _u32, _u32, _u32, C.c_float, _vp, _vp, _pp, _pu64]),
     "lime_write_res_txt_pairs": (_i, [C.c_char_p, _vp, _vp, _vp, _u32, _u32, C.c_float]),
     "lime_write_res_bin_pairs": (_i, [C.c_char_p, C.c_char_p, _vp, _vp, _vp, _u32, _u32, C.c_float]),
 }

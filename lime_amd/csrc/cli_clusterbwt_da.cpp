@@ -58,16 +58,25 @@ int main(int argc, char **argv)
 
     auto t0 = std::chrono::steady_clock::now();
     std::cerr << "Computing similarity arrays SimArray_i[1,numRead]..." << std::endl;
-    lime_ctx *ctx = nullptr;
-    if (lime_init(pick_device(), &ctx) != LIME_OK) { std::cerr << "Error: " << lime_last_error() << std::endl; exit(EXIT_FAILURE); }
     // the table stays in HBM: the row scan and the (idRef, sim) lists of the passing reads are made
-    // on the device and only those come back (lime_score_choose)
+    // on the device and only those come back (lime_score_choose).  LIME_GPUS=k: the cluster list is cut over k GPUs
+    // of this process, one RCCL reduce-scatter of the tables (lime_score_choose_multi)
     std::vector<uint8_t> rmax((size_t)numRead + 1);
     std::vector<uint64_t> roff((size_t)numRead + 2);
     lime_pair_t *pairs = nullptr; uint64_t nPairs = 0;
-    int rc = lime_score_choose(ctx, (const uint32_t *)da.data, EBWT ? (const uint8_t *)bwt.data : nullptr, n,
+    const int gpus = getenv("LIME_GPUS") ? atoi(getenv("LIME_GPUS")) : 0;
+    lime_ctx *ctx = nullptr;
+    int rc;
+    if (gpus >= 1) {
+        rc = lime_score_choose_multi(gpus, nullptr, (const uint32_t *)da.data, EBWT ? (const uint8_t *)bwt.data : nullptr, n,
+                                     (const lime_cluster_t *)clrs.data, nClusters, numRead, numRef, norm, beta,
+                                     rmax.data(), roff.data(), &pairs, &nPairs);
+    } else {
+        if (lime_init(pick_device(), &ctx) != LIME_OK) { std::cerr << "Error: " << lime_last_error() << std::endl; exit(EXIT_FAILURE); }
+        rc = lime_score_choose(ctx, (const uint32_t *)da.data, EBWT ? (const uint8_t *)bwt.data : nullptr, n,
                                (const lime_cluster_t *)clrs.data, nClusters, numRead, numRef, norm, beta,
                                rmax.data(), roff.data(), &pairs, &nPairs, nullptr);
+    }
     if (rc != LIME_OK) { std::cerr << "Error: " << lime_last_error() << std::endl; exit(1); }
     fprintf(stderr, "TIME clusterAnalyze: %.6lf\n", std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count());
 
@@ -83,7 +92,7 @@ int main(int argc, char **argv)
     lime_free(pairs);
     if (rc != LIME_OK) { std::cerr << "Error opening " << fnF << "." << std::endl; exit(EXIT_FAILURE); }
     fprintf(stdout, "Time: %.6lf\n", std::chrono::duration<double>(std::chrono::steady_clock::now() - t1).count());
-    lime_shutdown(ctx);
+    if (ctx) lime_shutdown(ctx);
     std::cout << "Cluster analysis completed with beta=" << beta << "." << std::endl;
     std::cout << "Number of clusters: " << nClusters << "." << std::endl;
     fprintf(stdout, "Time: %.6lf\n", std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count());

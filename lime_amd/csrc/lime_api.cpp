@@ -893,6 +893,104 @@ extern "C" int lime_score_choose(lime_ctx *c, const uint32_t *da, const uint8_t 
     return LIME_OK;
 }
 
+// ---- clusterAnalyze + clusterChoose on several GPUs of one process ------------------------------------
+// The cluster list is cut by position into n_dev parts of equal symbol counts (the reference cuts it by cluster
+// count over OpenMP threads, ClusterBWT_DA.cpp:641-648; any cut gives the same table); device k scores its part
+// into its own table; ONE reduce-scatter (RCCL, sum modulo 256) leaves device k with the block of read rows
+// [k * rpd, (k+1) * rpd); each device runs the row scan and the list compaction on its block; the host appends
+// the blocks' results in row order.  A host thread per device does the uploads and launches.
+int lime_internal_reduce_scatter(int n_dev, const int *devs, uint8_t *const *d_sim, uint8_t *const *d_blk, size_t blk);   // lime_comm.cpp
+#include <thread>
+
+extern "C" int lime_score_choose_multi(int n_dev, const int *devices, const uint32_t *da, const uint8_t *ebwt, uint64_t n,
+                                       const lime_cluster_t *clusters, uint64_t n_clusters, uint32_t n_reads, uint32_t n_refs,
+                                       uint32_t norm, float beta, uint8_t *row_max, uint64_t *row_off, lime_pair_t **pairs,
+                                       uint64_t *n_pairs)
+{
+    if (n_dev < 1 || !pairs || !n_pairs || !row_off || (n_reads && !row_max) || (n && !da) || (n_clusters && !clusters))
+        return fail(LIME_ERR_ARG, "lime_score_choose_multi: bad argument");
+    if (!n_reads || !n_refs) return fail(LIME_ERR_ARG, "lime_score_choose_multi: n_reads and n_refs must be > 0");
+    if (n_dev > lime_device_count()) return fail(LIME_ERR_ARG, "lime_score_choose_multi: %d devices asked, %d visible", n_dev, lime_device_count());
+    *pairs = nullptr; *n_pairs = 0; row_off[0] = 0;
+    std::vector<int> devs(n_dev);
+    for (int k = 0; k < n_dev; ++k) devs[k] = devices ? devices[k] : k;
+    // row blocks: a multiple of 16 rows each, so that every block starts 16-byte aligned whatever n_refs is
+    const uint64_t rpd = (((uint64_t)n_reads + n_dev - 1) / n_dev + 15u) & ~15ull;
+    const size_t blk = (size_t)rpd * n_refs, tbl = blk * (size_t)n_dev;
+    // the clusters in position order, cut where the running symbol count passes k/n_dev of the total
+    std::vector<lime_cluster_t> order;
+    const lime_cluster_t *cl = clusters;
+    bool sorted = true;
+    uint64_t total_len = 0;
+    for (uint64_t i = 0; i < n_clusters; ++i) { if (i && clusters[i].pStart < clusters[i - 1].pStart) sorted = false; total_len += clusters[i].len; }
+    if (!sorted) {
+        order.assign(clusters, clusters + n_clusters);
+        std::sort(order.begin(), order.end(), [](const lime_cluster_t &x, const lime_cluster_t &y) { return x.pStart < y.pStart; });
+        cl = order.data();
+    }
+    std::vector<uint64_t> cut(n_dev + 1, n_clusters);
+    cut[0] = 0;
+    { uint64_t run = 0; int k = 1; for (uint64_t i = 0; i < n_clusters && k < n_dev; ++i) { run += cl[i].len; while (k < n_dev && run * (uint64_t)n_dev >= total_len * (uint64_t)k) cut[k++] = i + 1; } }
+    struct Dev { lime_ctx *ctx = nullptr; uint8_t *sim = nullptr, *blkp = nullptr; int rc = LIME_OK; std::string err; };
+    std::vector<Dev> dv(n_dev);
+    auto cleanup = [&]() {
+        for (int k = 0; k < n_dev; ++k) { (void)hipSetDevice(devs[k]); (void)hipFree(dv[k].sim); (void)hipFree(dv[k].blkp); if (dv[k].ctx) lime_shutdown(dv[k].ctx); }
+    };
+    std::vector<std::thread> th;
+    for (int k = 0; k < n_dev; ++k)
+        th.emplace_back([&, k]() {
+            Dev &d = dv[k];
+            auto bad = [&](int rc, const char *what) { d.rc = rc; d.err = std::string(what) + ": " + lime_last_error(); };
+            if (hipSetDevice(devs[k]) != hipSuccess) { d.rc = LIME_ERR_HIP; d.err = "hipSetDevice"; return; }
+            int rc = lime_init(devs[k], &d.ctx);
+            if (rc) { bad(rc, "lime_init"); return; }
+            if (hipMalloc(&d.sim, tbl + 16) != hipSuccess || hipMalloc(&d.blkp, blk + 16) != hipSuccess) { d.rc = LIME_ERR_NOMEM; d.err = "hipMalloc of the table"; return; }
+            if (hipMemset(d.sim, 0, tbl + 16) != hipSuccess) { d.rc = LIME_ERR_HIP; d.err = "hipMemset"; return; }
+            rc = score_in_chunks(d.ctx, da, ebwt, n, cl + cut[k], cut[k + 1] - cut[k], n_reads, n_refs, d.sim);
+            if (rc) { bad(rc, "scoring"); return; }
+            if (hipDeviceSynchronize() != hipSuccess) { d.rc = LIME_ERR_HIP; d.err = "hipDeviceSynchronize"; }
+        });
+    for (auto &t : th) t.join();
+    for (int k = 0; k < n_dev; ++k) if (dv[k].rc) { const int rc = dv[k].rc; const std::string e = dv[k].err; cleanup(); return fail(rc, "device %d: %s", devs[k], e.c_str()); }
+    int rc = LIME_OK;
+    if (n_dev > 1 || getenv("LIME_FORCE_RCCL")) {
+        std::vector<uint8_t *> sims(n_dev), blks(n_dev);
+        for (int k = 0; k < n_dev; ++k) { sims[k] = dv[k].sim; blks[k] = dv[k].blkp; }
+        if ((rc = lime_internal_reduce_scatter(n_dev, devs.data(), sims.data(), blks.data(), blk))) { cleanup(); return fail(rc, "%s", lime_comm_error()); }
+    } else {
+        (void)hipSetDevice(devs[0]);
+        if (hipMemcpy(dv[0].blkp, dv[0].sim, blk, hipMemcpyDeviceToDevice) != hipSuccess) { cleanup(); return fail(LIME_ERR_HIP, "hipMemcpy"); }
+    }
+    // row scan + compaction per block, appended in row order
+    std::vector<lime_pair_t *> pp(n_dev, nullptr);
+    std::vector<uint64_t> np(n_dev, 0);
+    std::vector<std::vector<uint64_t>> off(n_dev);
+    uint64_t total = 0;
+    for (int k = 0; k < n_dev && !rc; ++k) {
+        const uint64_t r0 = rpd * (uint64_t)k;
+        if (r0 >= n_reads) break;
+        const uint32_t rows = (uint32_t)(n_reads - r0 < rpd ? n_reads - r0 : rpd);
+        off[k].resize((size_t)rows + 2);
+        (void)hipSetDevice(devs[k]);
+        rc = lime_choose_pairs_dev(dv[k].ctx, dv[k].blkp, rows, n_refs, norm, beta, row_max + r0, off[k].data(), &pp[k], &np[k], nullptr);
+        if (!rc) { for (uint32_t r = 0; r < rows; ++r) row_off[r0 + r] = total + off[k][r]; total += np[k]; }
+    }
+    std::string err = rc ? lime_last_error() : "";
+    if (!rc) {
+        row_off[n_reads] = total;
+        lime_pair_t *all = total ? (lime_pair_t *)malloc((size_t)total * sizeof(lime_pair_t)) : nullptr;
+        if (total && !all) { rc = LIME_ERR_NOMEM; err = "out of host memory"; }
+        else {
+            uint64_t at = 0;
+            for (int k = 0; k < n_dev; ++k) if (np[k]) { memcpy(all + at, pp[k], (size_t)np[k] * sizeof(lime_pair_t)); at += np[k]; }
+            *pairs = all; *n_pairs = total;
+        }
+    }
+    for (int k = 0; k < n_dev; ++k) free(pp[k]);
+    cleanup();
+    return rc ? fail(rc, "%s", err.c_str()) : LIME_OK;
+}
+
 // ---- pure host helpers ------------------------------------------------------------------
 extern "C" uint8_t lime_sym_index(uint8_t b) { return (uint8_t)sym_index(b); }
 

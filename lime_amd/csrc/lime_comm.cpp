@@ -148,6 +148,25 @@ extern "C" int lime_comm_combine_counters(lime_comm *c, uint64_t *d_sum_max, voi
     return LIME_OK;
 }
 
+// all devices of one process: device k ends with block k of the summed tables (internal; lime_api.cpp uses it too)
+int lime_internal_reduce_scatter(int n_dev, const int *devs, uint8_t *const *d_sim, uint8_t *const *d_blk, size_t blk)
+{
+    int rc = load_rccl(); if (rc) return rc;
+    std::vector<ncclComm_t> comms(n_dev, nullptr);
+    NCCL_TRY(g_rccl.CommInitAll(comms.data(), n_dev, devs));
+    rc = LIME_OK;
+    if (g_rccl.GroupStart() != 0) rc = cfail(LIME_ERR_HIP, "ncclGroupStart failed");
+    for (int k = 0; k < n_dev && !rc; ++k) {
+        (void)hipSetDevice(devs[k]);
+        ncclResult_t r = g_rccl.ReduceScatter(d_sim[k], d_blk[k], blk, nccl_Uint8, nccl_Sum, comms[k], nullptr);
+        if (r != 0) rc = cfail(LIME_ERR_HIP, "ncclReduceScatter: %s", g_rccl.GetErrorString(r));
+    }
+    if (!rc && g_rccl.GroupEnd() != 0) rc = cfail(LIME_ERR_HIP, "ncclGroupEnd failed");
+    for (int k = 0; k < n_dev; ++k) { (void)hipSetDevice(devs[k]); (void)hipDeviceSynchronize(); }
+    for (int k = 0; k < n_dev; ++k) if (comms[k]) (void)g_rccl.CommDestroy(comms[k]);
+    return rc;
+}
+
 // ---- one process, several GPUs ------------------------------------------------------------
 // The collection is cut into position ranges (tile-aligned, each with a read-ahead halo of LIME_MAX_CLUSTER +
 // LIME_TILE positions: ClusterLCP.cpp:150-161 chunking, :196-202 skip, :246-264 straddle); device k scans range k

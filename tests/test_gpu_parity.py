@@ -186,6 +186,27 @@ def test_cli_dropin_files(golden, ebwt_mode, binary, tmp_path):
         assert open(base + ".res.txt", "rb").read() == g[f"txt_{tag}"].tobytes()
 
 
+@pytest.mark.parametrize("ebwt_mode,binary", [(1, 1), (0, 0)])
+def test_cli_dropin_multi_gpu_entry(golden, ebwt_mode, binary, tmp_path):
+    """ClusterBWT_DA under LIME_GPUS=1 goes through lime_score_choose_multi (cluster list cut by position, row blocks of
+    a multiple of 16 rows, RCCL reduce-scatter -- forced here on the one device -- and per-block row scans): same bytes"""
+    g = golden
+    base = str(tmp_path / "X.fasta")
+    g["lcp"].astype("<u4").tofile(base + ".lcp"); g["da"].astype("<u4").tofile(base + ".da"); g["ebwt"].tofile(base + ".ebwt")
+    g["clrs"].astype("<u8").tofile(f"{base}.{g['alpha']}.clrs")
+    open(str(tmp_path / "X.out"), "wb").write(g["out"].tobytes())
+    env = dict(os.environ, LIME_EBWT=str(ebwt_mode), LIME_BIN=str(binary), LIME_GPUS="1", LIME_FORCE_RCCL="1")
+    r = subprocess.run([f"{BIN}/ClusterBWT_DA", base, str(g["read_len"]), repr(g["beta"]), "4"],
+                       capture_output=True, timeout=300, env=env, cwd=tmp_path)
+    assert r.returncode == 0, r.stderr.decode()
+    tag = f"e{ebwt_mode}"
+    if binary:
+        assert open(base + ".res.bin", "rb").read() == g[f"bin_{tag}"].tobytes()
+        assert open(base + ".res.pos", "rb").read() == g[f"pos_{tag}"].tobytes()
+    else:
+        assert open(base + ".res.txt", "rb").read() == g[f"txt_{tag}"].tobytes()
+
+
 def test_cli_usage_errors(tmp_path):
     r = subprocess.run([f"{BIN}/ClusterLCP", "x"], capture_output=True, timeout=60)
     assert r.returncode == 1 and b"Error usage" in r.stderr
