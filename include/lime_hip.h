@@ -89,6 +89,8 @@ const char *lime_last_error(void);
 void lime_free(void *p);                 /* frees host buffers returned by this library     */
 const char *lime_version(void);
 int  lime_device_count(void);            /* HIP devices visible to the process (0 if none) */
+int  lime_pick_device(unsigned salt);    /* the device with the most free memory (ties by salt, e.g. the pid): for
+                                          * LiME_paired.sh's four concurrent ClusterLCP processes (:44-53) */
 
 /* ---- host-pointer API (pageable host arrays; the library stages them through HBM) ------ */
 

@@ -43,6 +43,7 @@ SYMBOLS = {
     "lime_free": (None, [_vp]),
     "lime_version": (C.c_char_p, []),
     "lime_device_count": (_i, []),
+    "lime_pick_device": (_i, [C.c_uint]),
     "lime_detect": (_i, [_vp, _vp, _vp, _u64, _u32, _u32, _pp, _pu64, _pu64]),
     "lime_score": (_i, [_vp, _vp, _vp, _u64, _vp, _u64, _u32, _u32, _vp]),
     "lime_fused": (_i, [_vp, _vp, _vp, _vp, _u64, _u32, _u32, _u32, _vp, _pu64, _pu64]),

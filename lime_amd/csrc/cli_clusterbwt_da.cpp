@@ -25,6 +25,7 @@ int main(int argc, char **argv)
     const int EBWT = env_flag("LIME_EBWT", 1), BIN = env_flag("LIME_BIN", 1);
     int threads = 1;
     sscanf(argv[4], "%d", &threads);
+    io_threads_from_argv(threads);
     printf("Number of threads: %d (host); scoring on GPU\n", threads);
     std::string fileFasta = argv[1];
     unsigned char readLen = 0;                 // dataTypeSim, parsed with %hhu (:519-521)

@@ -22,6 +22,7 @@ int main(int argc, char **argv)
     sscanf(argv[3], "%u", &numGenomes);
     sscanf(argv[4], "%u", &alpha);
     sscanf(argv[5], "%d", &threads);
+    io_threads_from_argv(threads);
     printf("Number of threads: %d (host); scan on GPU\n", threads);
 
     std::string fnLCP = fileFasta + ".lcp", fnDA = fileFasta + ".da";

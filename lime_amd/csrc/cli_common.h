@@ -37,12 +37,20 @@ struct MappedFile {
 };
 
 // LiME_paired.sh starts four ClusterLCP processes at once (LiME_paired.sh:44-53): spread them
-// over the node's GPUs.  LIME_DEVICE pins a device; otherwise pid modulo device count.
+// over the node's GPUs.  LIME_DEVICE pins a device; otherwise the device with the most free memory
+// (lime_pick_device), processes that start together and see the same picture falling apart by pid.
 static inline int pick_device()
 {
     if (const char *s = getenv("LIME_DEVICE")) return atoi(s);
-    int n = lime_device_count();
-    return n > 1 ? (int)(getpid() % n) : 0;
+    return lime_pick_device((unsigned)getpid());
+}
+
+// the reference's `threads` argument: here the host threads that stage the mapped files into pinned memory
+static inline void io_threads_from_argv(int threads)
+{
+    if (threads < 1) threads = 1;
+    char buf[16]; snprintf(buf, sizeof buf, "%d", threads);
+    setenv("LIME_IO_THREADS", buf, 0);
 }
 
 static inline std::string aux_name(const std::string &fileFasta)

@@ -8,7 +8,12 @@
 #include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
+#include <atomic>
+#include <condition_variable>
+#include <functional>
+#include <mutex>
 #include <string>
+#include <thread>
 #include <vector>
 
 #include "lime_device.h"
@@ -85,6 +90,24 @@ extern "C" int lime_device_count(void)
     int n = 0;
     return hipGetDeviceCount(&n) == hipSuccess ? n : 0;
 }
+// the device with the most free memory; devices within 1 GiB of the best count as equally free and `salt`
+// (a pid) picks among them, so that processes started together do not all land on device 0
+extern "C" int lime_pick_device(unsigned salt)
+{
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess || n <= 1) return 0;
+    std::vector<size_t> fr(n, 0);
+    size_t best = 0;
+    for (int d = 0; d < n; ++d) {
+        size_t f = 0, t = 0;
+        if (hipSetDevice(d) == hipSuccess && hipMemGetInfo(&f, &t) == hipSuccess) fr[d] = f;
+        if (fr[d] > best) best = fr[d];
+    }
+    std::vector<int> cand;
+    for (int d = 0; d < n; ++d) if (fr[d] + ((size_t)1 << 30) >= best) cand.push_back(d);
+    return cand.empty() ? 0 : cand[salt % cand.size()];
+}
+
 extern "C" size_t lime_sim_bytes(uint32_t n_reads, uint32_t n_refs)
 {
     size_t b = (size_t)n_reads * n_refs;
@@ -496,12 +519,12 @@ extern "C" int lime_detect_dev(lime_ctx *c, const uint32_t *d_lcp, const uint32_
     return LIME_OK;
 }
 
-extern "C" int lime_score_dev(lime_ctx *c, const uint32_t *d_da, const uint8_t *d_ebwt, uint64_t n,
-                              const lime_cluster_t *d_clusters, uint64_t n_clusters, uint32_t n_reads,
-                              uint32_t n_refs, uint8_t *d_sim, int zero_sim, void *stream)
+// pos_base: the collection position of d_da[0] (the records' pStart are collection positions)
+static int score_dev_impl(lime_ctx *c, const uint32_t *d_da, const uint8_t *d_ebwt, uint64_t n,
+                          const lime_cluster_t *d_clusters, uint64_t n_clusters, uint32_t n_reads,
+                          uint32_t n_refs, uint8_t *d_sim, int zero_sim, uint64_t pos_base, hipStream_t st)
 {
-    int rc = check_ctx(c, "lime_score_dev"); if (rc) return rc;
-    hipStream_t st = (hipStream_t)stream;
+    int rc;
     if (!d_sim || (n && !d_da) || (n_clusters && !d_clusters)) return fail(LIME_ERR_ARG, "lime_score_dev: NULL array");
     if (misaligned(d_sim, 4)) return fail(LIME_ERR_ARG, "lime_score_dev: d_sim must be 4-byte aligned");
     if (!n_reads || !n_refs) return fail(LIME_ERR_ARG, "lime_score_dev: n_reads and n_refs must be > 0");
@@ -520,6 +543,7 @@ extern "C" int lime_score_dev(lime_ctx *c, const uint32_t *d_da, const uint8_t *
     if (zero_sim) HIP_TRY(hipMemsetAsync(d_sim, 0, lime_sim_bytes(n_reads, n_refs), st));
     if (!n_clusters) return LIME_OK;
     ScanArgs a = base_args(c, nullptr, d_da, d_ebwt, n, n, 1, n_reads, n_refs, 0, d_sim);
+    a.pos_base = pos_base;
     const int ebwt = d_ebwt != nullptr;
     uint64_t batches = (n_clusters + 255) / 256;          // 64 clusters per wave, 4 waves per workgroup
     uint32_t blocks = (uint32_t)(batches < c->list_blocks ? batches : c->list_blocks);
@@ -527,6 +551,14 @@ extern "C" int lime_score_dev(lime_ctx *c, const uint32_t *d_da, const uint8_t *
     launch_score_big(ebwt, a, c->d_big_scratch, st);
     HIP_TRY(hipGetLastError());
     return LIME_OK;
+}
+
+extern "C" int lime_score_dev(lime_ctx *c, const uint32_t *d_da, const uint8_t *d_ebwt, uint64_t n,
+                              const lime_cluster_t *d_clusters, uint64_t n_clusters, uint32_t n_reads,
+                              uint32_t n_refs, uint8_t *d_sim, int zero_sim, void *stream)
+{
+    int rc = check_ctx(c, "lime_score_dev"); if (rc) return rc;
+    return score_dev_impl(c, d_da, d_ebwt, n, d_clusters, n_clusters, n_reads, n_refs, d_sim, zero_sim, 0, (hipStream_t)stream);
 }
 
 extern "C" int lime_choose_dev(lime_ctx *c, const uint8_t *d_sim, uint32_t n_reads, uint32_t n_refs,
@@ -591,7 +623,124 @@ struct Pipe {
     }
 };
 const uint64_t STREAM_HALO = (uint64_t)LIME_MAX_CLUSTER + LIME_TILE;   // a run the reference accepts closes inside it
-const uint64_t STREAM_CHUNK = 64ull << 20;                              // default symbols per chunk
+const uint64_t STREAM_CHUNK = 64ull << 20;                              // default symbols per chunk, sources pinned (or small)
+const uint64_t STAGED_CHUNK = 4ull << 20;                               // through the pinned ring: short chunks fill the pipeline sooner and the
+                                                                        // three slots stay small (measured best of 4 / 16 / 64 Mi on 10^9 symbols)
+}
+
+// ---- host arrays -> HBM, chunk by chunk ---------------------------------------------------------
+// The callers' arrays are usually pageable (the drop-in programs hand over mmap-ed files): a copy straight from
+// them is synchronous and staged by the runtime in small pieces.  The Feeder moves chunk k through a ring of three
+// pinned slots instead: a producer thread (with LIME_IO_THREADS helpers) copies the chunk's pieces into slot k % 3
+// while the copy engine empties slot (k-1) % 3 into one device buffer set and the kernels work on the other.
+// Sources that are already pinned (hipHostMalloc / hipHostRegister) skip the ring.
+namespace {
+struct Piece { const void *src; size_t bytes; void *dst; };
+
+struct Feeder {
+    static constexpr int NS = 3, MAXP = 3;
+    void *slot[NS] = {nullptr, nullptr, nullptr};
+    hipEvent_t h2d_done[NS] = {nullptr, nullptr, nullptr};
+    size_t slot_bytes = 0;
+    bool staged = false;
+    int io_threads = 1, device = 0;
+    uint64_t n_chunks = 0;
+    std::function<int(uint64_t, Piece *)> describe;       // pieces of chunk k (at most MAXP); returns their number
+    std::thread producer;
+    std::mutex mu; std::condition_variable cv;
+    uint64_t filled = 0, issued = 0; bool stop = false, failed = false;
+
+    // would a walk over `total_bytes` of these sources go through the ring?  (the caller picks its chunk size by it)
+    static bool will_stage(bool all_sources_pinned, size_t total_bytes)
+    {
+        return !all_sources_pinned && !getenv("LIME_NO_STAGING") && (total_bytes >= ((size_t)8 << 20) || getenv("LIME_FORCE_STAGING"));
+    }
+    static bool pinned(const void *p)
+    {
+        if (!p) return true;
+        hipPointerAttribute_t at;
+        if (hipPointerGetAttributes(&at, p) != hipSuccess) { (void)hipGetLastError(); return false; }
+        return at.type == hipMemoryTypeHost;
+    }
+    static void copy_parallel(void *dst, const void *src, size_t bytes, int threads)
+    {
+        if (threads <= 1 || bytes < (8u << 20)) { memcpy(dst, src, bytes); return; }
+        std::vector<std::thread> th;
+        const size_t part = ((bytes + (size_t)threads - 1) / (size_t)threads + 4095) & ~(size_t)4095;    // threads * part >= bytes
+        for (int t = 0; t < threads; ++t) {
+            const size_t o = part * (size_t)t;
+            if (o >= bytes) break;
+            const size_t len = bytes - o < part ? bytes - o : part;
+            th.emplace_back([=]() { memcpy((char *)dst + o, (const char *)src + o, len); });
+        }
+        for (auto &t : th) t.join();
+    }
+    int init(size_t bytes_per_chunk, uint64_t chunks, bool all_sources_pinned, std::function<int(uint64_t, Piece *)> d)
+    {
+        describe = std::move(d); n_chunks = chunks; slot_bytes = bytes_per_chunk;
+        // small collections: the ring's set-up (pinned allocations, a thread) costs more than it hides
+        staged = will_stage(all_sources_pinned, bytes_per_chunk * chunks);
+        if (!staged) return LIME_OK;
+        HIP_TRY(hipGetDevice(&device));
+        io_threads = 4;
+        if (const char *e = getenv("LIME_IO_THREADS")) { const int v = atoi(e); if (v >= 1) io_threads = v > 32 ? 32 : v; }
+        for (int i = 0; i < NS; ++i) {
+            HIP_TRY(hipHostMalloc(&slot[i], slot_bytes + 64, hipHostMallocDefault));
+            HIP_TRY(hipEventCreateWithFlags(&h2d_done[i], hipEventDisableTiming));
+        }
+        producer = std::thread([this]() {
+            (void)hipSetDevice(device);
+            Piece pc[MAXP];
+            for (uint64_t k = 0; k < n_chunks; ++k) {
+                if (k >= NS) {                               // slot k % NS: its previous content must have left for the device
+                    std::unique_lock<std::mutex> lk(mu);
+                    cv.wait(lk, [&] { return issued > k - NS || stop; });
+                    if (stop) return;
+                    lk.unlock();
+                    if (hipEventSynchronize(h2d_done[k % NS]) != hipSuccess) { std::lock_guard<std::mutex> g(mu); failed = true; cv.notify_all(); return; }
+                }
+                { std::lock_guard<std::mutex> g(mu); if (stop) return; }
+                const int np = describe(k, pc);
+                size_t off = 0;
+                for (int i = 0; i < np; ++i) { copy_parallel((char *)slot[k % NS] + off, pc[i].src, pc[i].bytes, io_threads); off += (pc[i].bytes + 15) & ~(size_t)15; }
+                { std::lock_guard<std::mutex> g(mu); filled = k + 1; }
+                cv.notify_all();
+            }
+        });
+        return LIME_OK;
+    }
+    // the copies of chunk k, asynchronous on `copy` (chunks must be fed in order)
+    int feed(uint64_t k, hipStream_t copy)
+    {
+        Piece pc[MAXP];
+        const int np = describe(k, pc);
+        if (!staged) {
+            for (int i = 0; i < np; ++i) HIP_TRY(hipMemcpyAsync(pc[i].dst, pc[i].src, pc[i].bytes, hipMemcpyHostToDevice, copy));
+            return LIME_OK;
+        }
+        {
+            std::unique_lock<std::mutex> lk(mu);
+            cv.wait(lk, [&] { return filled > k || failed; });
+            if (failed) return fail(LIME_ERR_HIP, "staging thread failed");
+        }
+        size_t off = 0;
+        for (int i = 0; i < np; ++i) {
+            HIP_TRY(hipMemcpyAsync(pc[i].dst, (char *)slot[k % NS] + off, pc[i].bytes, hipMemcpyHostToDevice, copy));
+            off += (pc[i].bytes + 15) & ~(size_t)15;
+        }
+        HIP_TRY(hipEventRecord(h2d_done[k % NS], copy));
+        { std::lock_guard<std::mutex> g(mu); issued = k + 1; }
+        cv.notify_all();
+        return LIME_OK;
+    }
+    ~Feeder()
+    {
+        { std::lock_guard<std::mutex> g(mu); stop = true; }
+        cv.notify_all();
+        if (producer.joinable()) producer.join();
+        for (int i = 0; i < NS; ++i) { if (h2d_done[i]) { (void)hipEventSynchronize(h2d_done[i]); (void)hipEventDestroy(h2d_done[i]); } if (slot[i]) (void)hipHostFree(slot[i]); }
+    }
+};
 }
 
 extern "C" int lime_fused_stream(lime_ctx *c, const uint32_t *lcp, const uint32_t *da, const uint8_t *ebwt, uint64_t n,
@@ -601,7 +750,8 @@ extern "C" int lime_fused_stream(lime_ctx *c, const uint32_t *lcp, const uint32_
     int rc = check_ctx(c, "lime_fused_stream"); if (rc) return rc;
     if (!sim || (n && (!lcp || !da))) return fail(LIME_ERR_ARG, "lime_fused_stream: NULL array");
     if (!n_reads || !n_refs) return fail(LIME_ERR_ARG, "lime_fused_stream: n_reads and n_refs must be > 0");
-    if (!chunk) chunk = STREAM_CHUNK;
+    const bool src_pinned = Feeder::pinned(lcp) && Feeder::pinned(da) && Feeder::pinned(ebwt);
+    if (!chunk) chunk = Feeder::will_stage(src_pinned, (size_t)n * 9) ? STAGED_CHUNK : STREAM_CHUNK;
     chunk = (chunk + LIME_TILE - 1) / LIME_TILE * LIME_TILE;
     const uint64_t cap = (chunk < n ? chunk : n) + STREAM_HALO;         // elements per device buffer
     Pipe pp;
@@ -619,6 +769,16 @@ extern "C" int lime_fused_stream(lime_ctx *c, const uint32_t *lcp, const uint32_
     DevBuf dedge;                                          // one edge word per chunk (runs longer than the halo across chunk borders)
     if ((rc = dedge.alloc((size_t)(n_chunks + 1) * 4))) return rc;
     HIP_TRY(hipMemsetAsync(dedge.p, 0, (size_t)(n_chunks + 1) * 4, pp.comp));
+    Feeder feeder;
+    if ((rc = feeder.init(cap * 9 + 64, n_chunks, src_pinned,
+                          [&](uint64_t kk, Piece *pc) {
+                              const uint64_t lo = kk * chunk, own = n - lo < chunk ? n - lo : chunk;
+                              const uint64_t avail = n - lo < own + STREAM_HALO ? n - lo : own + STREAM_HALO;
+                              const int b = (int)(kk & 1);
+                              pc[0] = Piece{lcp + lo, (size_t)avail * 4, dl[b].p}; pc[1] = Piece{da + lo, (size_t)avail * 4, dd[b].p};
+                              if (ebwt) pc[2] = Piece{ebwt + lo, (size_t)avail, de[b].p};
+                              return ebwt ? 3 : 2;
+                          }))) return rc;
     uint64_t k = 0;
     for (uint64_t lo = 0; lo < n; lo += chunk, ++k) {
         const int b = (int)(k & 1);
@@ -626,9 +786,7 @@ extern "C" int lime_fused_stream(lime_ctx *c, const uint32_t *lcp, const uint32_
         const uint64_t avail = n - lo < own + STREAM_HALO ? n - lo : own + STREAM_HALO;
         const int eof = lo + avail == n;
         if (k >= 2) HIP_TRY(hipStreamWaitEvent(pp.copy, pp.consumed[b], 0));        // the buffer is free again
-        HIP_TRY(hipMemcpyAsync(dl[b].p, lcp + lo, avail * 4, hipMemcpyHostToDevice, pp.copy));
-        HIP_TRY(hipMemcpyAsync(dd[b].p, da + lo, avail * 4, hipMemcpyHostToDevice, pp.copy));
-        if (ebwt) HIP_TRY(hipMemcpyAsync(de[b].p, ebwt + lo, avail, hipMemcpyHostToDevice, pp.copy));
+        if ((rc = feeder.feed(k, pp.copy))) { (void)hipDeviceSynchronize(); return rc; }
         HIP_TRY(hipEventRecord(pp.copied[b], pp.copy));
         HIP_TRY(hipStreamWaitEvent(pp.comp, pp.copied[b], 0));
         rc = fused_dev_impl(c, (const uint32_t *)dl[b].p, (const uint32_t *)dd[b].p, ebwt ? (const uint8_t *)de[b].p : nullptr,
@@ -662,53 +820,70 @@ extern "C" int lime_detect(lime_ctx *c, const uint32_t *lcp, const uint32_t *da,
     if (n && (!lcp || !da)) return fail(LIME_ERR_ARG, "lime_detect: NULL array");
     if (!n) return LIME_OK;
     // position-range chunks with a read-ahead halo (see lime_fused_stream); records of chunk k follow
-    // those of chunk k-1, so the list stays in ascending pStart = the reference's 1-thread order
-    uint64_t chunk = STREAM_CHUNK;
-    if (const char *e = getenv("LIME_DETECT_CHUNK")) { const uint64_t v = strtoull(e, nullptr, 10); if (v) chunk = v; }
-    chunk = (chunk + LIME_TILE - 1) / LIME_TILE * LIME_TILE;
-    const uint64_t cap = (chunk < n ? chunk : n) + STREAM_HALO;
-    DevBuf dl, dd;
-    if ((rc = dl.alloc(cap * 4 + 16))) return rc;
-    if ((rc = dd.alloc(cap * 4 + 16))) return rc;
+    // those of chunk k-1, so the list stays in ascending pStart = the reference's 1-thread order.  The copy of
+    // chunk k+1 (through the pinned ring when the arrays are pageable) is under way while chunk k is scanned.
+    uint64_t chunk0 = Feeder::will_stage(Feeder::pinned(lcp) && Feeder::pinned(da), (size_t)n * 8) ? STAGED_CHUNK : STREAM_CHUNK;
+    if (const char *e = getenv("LIME_DETECT_CHUNK")) { const uint64_t v = strtoull(e, nullptr, 10); if (v) chunk0 = v; }
     lime_cluster_t *h = nullptr;
     uint64_t have = 0, room = 0, ml = 0;
-    for (uint64_t lo = 0; lo < n; lo += chunk) {
-        const uint64_t own = n - lo < chunk ? n - lo : chunk;
-        const uint64_t avail = n - lo < own + STREAM_HALO ? n - lo : own + STREAM_HALO;
-        hipError_t e = hipMemcpy(dl.p, lcp + lo, avail * 4, hipMemcpyHostToDevice);
-        if (e == hipSuccess) e = hipMemcpy(dd.p, da + lo, avail * 4, hipMemcpyHostToDevice);
-        if (e != hipSuccess) { free(h); return fail(LIME_ERR_HIP, "hipMemcpy: %s", hipGetErrorString(e)); }
-        const lime_cluster_t *dc = nullptr;
-        uint64_t cnt = 0, m = 0;
-        rc = lime_detect_dev(c, (const uint32_t *)dl.p, (const uint32_t *)dd.p, own, avail, lo + avail == n, lo, n_reads,
-                             alpha, &dc, &cnt, &m, nullptr);
-        if (rc == LIME_ERR_HALO && chunk < n) {
-            // a run longer than the halo crosses a chunk border.  ClusterLCP itself has no length limit
-            // (only ClusterBWT_DA refuses such a cluster later): redo the whole collection as one chunk
-            free(h); h = nullptr; have = 0; room = 0; ml = 0;
-            chunk = (n + LIME_TILE - 1) / LIME_TILE * LIME_TILE;
-            (void)hipFree(dl.p); dl.p = nullptr; (void)hipFree(dd.p); dd.p = nullptr;
-            if ((rc = dl.alloc(n * 4 + 16))) return rc;
-            if ((rc = dd.alloc(n * 4 + 16))) return rc;
-            lo = 0 - chunk;                               // the loop's increment brings it back to 0
-            continue;
-        }
-        if (rc) { free(h); return rc; }
-        if (m > ml) ml = m;
-        if (cnt) {
-            if (have + cnt > room) {
-                room = (have + cnt) + (have + cnt) / 2 + 1024;
-                lime_cluster_t *g = (lime_cluster_t *)realloc(h, (size_t)room * sizeof(lime_cluster_t));
-                if (!g) { free(h); return fail(LIME_ERR_NOMEM, "lime_detect: out of host memory"); }
-                h = g;
+    auto walk = [&](uint64_t chunk) -> int {
+        chunk = (chunk + LIME_TILE - 1) / LIME_TILE * LIME_TILE;
+        const uint64_t cap = (chunk < n ? chunk : n) + STREAM_HALO, n_chunks = (n + chunk - 1) / chunk;
+        int rc;
+        Pipe pp;
+        if ((rc = pp.init())) return rc;
+        DevBuf dl[2], dd[2];
+        for (int b = 0; b < (n_chunks > 1 ? 2 : 1); ++b) { if ((rc = dl[b].alloc(cap * 4 + 16))) return rc; if ((rc = dd[b].alloc(cap * 4 + 16))) return rc; }
+        Feeder feeder;
+        if ((rc = feeder.init(cap * 8 + 64, n_chunks, Feeder::pinned(lcp) && Feeder::pinned(da), [&](uint64_t kk, Piece *pc) {
+                const uint64_t lo = kk * chunk, own = n - lo < chunk ? n - lo : chunk;
+                const uint64_t avail = n - lo < own + STREAM_HALO ? n - lo : own + STREAM_HALO;
+                pc[0] = Piece{lcp + lo, (size_t)avail * 4, dl[kk & 1].p}; pc[1] = Piece{da + lo, (size_t)avail * 4, dd[kk & 1].p};
+                return 2;
+            }))) return rc;
+        if ((rc = feeder.feed(0, pp.copy))) return rc;
+        HIP_TRY(hipEventRecord(pp.copied[0], pp.copy));
+        for (uint64_t k = 0; k < n_chunks; ++k) {
+            const int b = (int)(k & 1);
+            const uint64_t lo = k * chunk, own = n - lo < chunk ? n - lo : chunk;
+            const uint64_t avail = n - lo < own + STREAM_HALO ? n - lo : own + STREAM_HALO;
+            if (k + 1 < n_chunks) {                       // the next chunk's copy goes out before this chunk's scan is waited for
+                const int nb = (int)((k + 1) & 1);
+                if (k + 1 >= 2) HIP_TRY(hipStreamWaitEvent(pp.copy, pp.consumed[nb], 0));
+                if ((rc = feeder.feed(k + 1, pp.copy))) { (void)hipDeviceSynchronize(); return rc; }
+                HIP_TRY(hipEventRecord(pp.copied[nb], pp.copy));
             }
-            e = hipMemcpy(h + have, dc, (size_t)cnt * sizeof(lime_cluster_t), hipMemcpyDeviceToHost);
-            if (e != hipSuccess) { free(h); return fail(LIME_ERR_HIP, "hipMemcpy: %s", hipGetErrorString(e)); }
-            have += cnt;
-        } else {
-            HIP_TRY(hipDeviceSynchronize());
+            HIP_TRY(hipStreamWaitEvent(pp.comp, pp.copied[b], 0));
+            const lime_cluster_t *dc = nullptr;
+            uint64_t cnt = 0, m = 0;
+            rc = lime_detect_dev(c, (const uint32_t *)dl[b].p, (const uint32_t *)dd[b].p, own, avail, lo + avail == n, lo, n_reads,
+                                 alpha, &dc, &cnt, &m, pp.comp);
+            if (rc) { (void)hipDeviceSynchronize(); return rc; }
+            if (m > ml) ml = m;
+            if (cnt) {
+                if (have + cnt > room) {
+                    room = (have + cnt) + (have + cnt) / 2 + 1024;
+                    lime_cluster_t *g = (lime_cluster_t *)realloc(h, (size_t)room * sizeof(lime_cluster_t));
+                    if (!g) { (void)hipDeviceSynchronize(); return fail(LIME_ERR_NOMEM, "lime_detect: out of host memory"); }
+                    h = g;
+                }
+                HIP_TRY(hipMemcpyAsync(h + have, dc, (size_t)cnt * sizeof(lime_cluster_t), hipMemcpyDeviceToHost, pp.comp));
+                have += cnt;
+            }
+            HIP_TRY(hipEventRecord(pp.consumed[b], pp.comp));
+            HIP_TRY(hipStreamSynchronize(pp.comp));       // the record list of the ctx is reused by the next chunk
         }
+        HIP_TRY(hipStreamSynchronize(pp.copy));
+        return LIME_OK;
+    };
+    rc = walk(chunk0);
+    if (rc == LIME_ERR_HALO && chunk0 < n) {
+        // a run longer than the halo crosses a chunk border.  ClusterLCP itself has no length limit (only
+        // ClusterBWT_DA refuses such a cluster later): redo the whole collection as one chunk
+        have = 0; ml = 0;
+        rc = walk(n);
     }
+    if (rc) { free(h); return rc; }
     *clusters = h; *n_clusters = have; *max_len = ml;
     return LIME_OK;
 }
@@ -722,8 +897,9 @@ static int score_in_chunks(lime_ctx *c, const uint32_t *da, const uint8_t *ebwt,
 {
     int rc;
     HIP_TRY(hipMemset(d_sim, 0, lime_sim_bytes(n_reads, n_refs)));
+    HIP_TRY(hipDeviceSynchronize());                      // the chunks below run on streams of their own
     if (!n_clusters) return LIME_OK;
-    uint64_t chunk = STREAM_CHUNK;
+    uint64_t chunk = Feeder::will_stage(Feeder::pinned(da) && Feeder::pinned(ebwt), (size_t)n * 5) ? STAGED_CHUNK : STREAM_CHUNK;
     if (const char *e = getenv("LIME_SCORE_CHUNK")) { const uint64_t v = strtoull(e, nullptr, 10); if (v) chunk = v; }
     bool sorted = true;
     for (uint64_t i = 0; i < n_clusters; ++i) {
@@ -739,40 +915,58 @@ static int score_in_chunks(lime_ctx *c, const uint32_t *da, const uint8_t *ebwt,
         std::sort(order.begin(), order.end(), [](const lime_cluster_t &x, const lime_cluster_t &y) { return x.pStart < y.pStart; });
         cl = order.data();
     }
-    std::vector<lime_cluster_t> part;
-    DevBuf dd, de, dc;
-    size_t cap_el = 0, cap_cl = 0;
+    // the plan: chunk k = clusters [i, j) that start in [lo, lo + chunk), arrays [lo, end) up to the end of the last of them
+    struct Plan { uint64_t i, j, lo, end; };
+    std::vector<Plan> plan;
+    size_t max_el = 0, max_cl = 0;
     for (uint64_t i = 0; i < n_clusters;) {
         const uint64_t lo = cl[i].pStart, hi = lo + chunk;
         uint64_t j = i, end = lo;
-        part.clear();
-        while (j < n_clusters && cl[j].pStart < hi) {
-            lime_cluster_t q = cl[j]; q.pStart -= lo;
-            if (cl[j].pStart + cl[j].len > end) end = cl[j].pStart + cl[j].len;
-            part.push_back(q); ++j;
-        }
-        const uint64_t cnt = end - lo;
-        if (cnt > cap_el) {
-            if (dd.p) { HIP_TRY(hipDeviceSynchronize()); (void)hipFree(dd.p); dd.p = nullptr; if (de.p) { (void)hipFree(de.p); de.p = nullptr; } }
-            cap_el = (size_t)cnt + (size_t)cnt / 8;
-            if ((rc = dd.alloc(cap_el * 4 + 16))) return rc;
-            if (ebwt && (rc = de.alloc(cap_el + 16))) return rc;
-        }
-        if (part.size() > cap_cl) {
-            if (dc.p) { HIP_TRY(hipDeviceSynchronize()); (void)hipFree(dc.p); dc.p = nullptr; }
-            cap_cl = part.size() + part.size() / 8;
-            if ((rc = dc.alloc(cap_cl * sizeof(lime_cluster_t)))) return rc;
-        }
-        HIP_TRY(hipMemcpy(dd.p, da + lo, cnt * 4, hipMemcpyHostToDevice));
-        if (ebwt) HIP_TRY(hipMemcpy(de.p, ebwt + lo, cnt, hipMemcpyHostToDevice));
-        HIP_TRY(hipMemcpy(dc.p, part.data(), part.size() * sizeof(lime_cluster_t), hipMemcpyHostToDevice));
-        rc = lime_score_dev(c, (const uint32_t *)dd.p, ebwt ? (const uint8_t *)de.p : nullptr, cnt,
-                            (const lime_cluster_t *)dc.p, part.size(), n_reads, n_refs, d_sim, 0, nullptr);
-        if (rc) return rc;
-        lime_stats_t st;
-        if ((rc = lime_get_stats(c, &st, nullptr))) return rc;
+        while (j < n_clusters && cl[j].pStart < hi) { if (cl[j].pStart + cl[j].len > end) end = cl[j].pStart + cl[j].len; ++j; }
+        plan.push_back(Plan{i, j, lo, end});
+        if (end - lo > max_el) max_el = (size_t)(end - lo);
+        if (j - i > max_cl) max_cl = (size_t)(j - i);
         i = j;
     }
+    Pipe pp;
+    if ((rc = pp.init())) return rc;
+    DevBuf dd[2], de[2], dc[2];
+    for (int b = 0; b < (plan.size() > 1 ? 2 : 1); ++b) {
+        if ((rc = dd[b].alloc(max_el * 4 + 16))) return rc;
+        if (ebwt && (rc = de[b].alloc(max_el + 16))) return rc;
+        if ((rc = dc[b].alloc(max_cl * sizeof(lime_cluster_t)))) return rc;
+    }
+    Feeder feeder;
+    if ((rc = feeder.init(max_el * 5 + max_cl * sizeof(lime_cluster_t) + 64, plan.size(),
+                          Feeder::pinned(da) && Feeder::pinned(ebwt) && Feeder::pinned(cl), [&](uint64_t k, Piece *pc) {
+            const Plan &q = plan[k];
+            const int b = (int)(k & 1);
+            int np = 0;
+            pc[np++] = Piece{da + q.lo, (size_t)(q.end - q.lo) * 4, dd[b].p};
+            if (ebwt) pc[np++] = Piece{ebwt + q.lo, (size_t)(q.end - q.lo), de[b].p};
+            pc[np++] = Piece{cl + q.i, (size_t)(q.j - q.i) * sizeof(lime_cluster_t), dc[b].p};
+            return np;
+        }))) return rc;
+    if ((rc = feeder.feed(0, pp.copy))) return rc;
+    HIP_TRY(hipEventRecord(pp.copied[0], pp.copy));
+    for (uint64_t k = 0; k < plan.size(); ++k) {
+        const int b = (int)(k & 1);
+        const Plan &q = plan[k];
+        if (k + 1 < plan.size()) {                        // the next chunk's copy goes out before this chunk's scoring is waited for
+            const int nb = (int)((k + 1) & 1);
+            if (k + 1 >= 2) HIP_TRY(hipStreamWaitEvent(pp.copy, pp.consumed[nb], 0));
+            if ((rc = feeder.feed(k + 1, pp.copy))) { (void)hipDeviceSynchronize(); return rc; }
+            HIP_TRY(hipEventRecord(pp.copied[nb], pp.copy));
+        }
+        HIP_TRY(hipStreamWaitEvent(pp.comp, pp.copied[b], 0));
+        rc = score_dev_impl(c, (const uint32_t *)dd[b].p, ebwt ? (const uint8_t *)de[b].p : nullptr, q.end - q.lo,
+                            (const lime_cluster_t *)dc[b].p, q.j - q.i, n_reads, n_refs, d_sim, 0, q.lo, pp.comp);
+        if (rc) { (void)hipDeviceSynchronize(); return rc; }
+        HIP_TRY(hipEventRecord(pp.consumed[b], pp.comp));
+        lime_stats_t st;
+        if ((rc = lime_get_stats(c, &st, pp.comp))) { (void)hipDeviceSynchronize(); return rc; }
+    }
+    HIP_TRY(hipStreamSynchronize(pp.copy));
     return LIME_OK;
 }
 
@@ -900,7 +1094,6 @@ extern "C" int lime_score_choose(lime_ctx *c, const uint32_t *da, const uint8_t 
 // [k * rpd, (k+1) * rpd); each device runs the row scan and the list compaction on its block; the host appends
 // the blocks' results in row order.  A host thread per device does the uploads and launches.
 int lime_internal_reduce_scatter(int n_dev, const int *devs, uint8_t *const *d_sim, uint8_t *const *d_blk, size_t blk);   // lime_comm.cpp
-#include <thread>
 
 extern "C" int lime_score_choose_multi(int n_dev, const int *devices, const uint32_t *da, const uint8_t *ebwt, uint64_t n,
                                        const lime_cluster_t *clusters, uint64_t n_clusters, uint32_t n_reads, uint32_t n_refs,

@@ -1551,7 +1551,7 @@ __global__ __launch_bounds__(SCAN_WG) void k_score_list(ScanArgs a, const lime_c
     for (uint64_t b = (uint64_t)blockIdx.x * (SCAN_WG / 64) + wave; b < n_batches; b += stride) {
         const uint64_t c = b * 64u + lane;
         uint64_t ps = 0, len = 0;
-        if (c < n_list) { ps = list[c].pStart; len = list[c].len; }
+        if (c < n_list) { ps = list[c].pStart - a.pos_base; len = list[c].len; }      // pos_base: where the arrays handed over start in the collection
         const bool bad = (len > LIME_MAX_CLUSTER) || (ps > a.n_avail) || (len > a.n_avail - ps);
         if (bad) { atomicOr(&a.stats->flags, len > LIME_MAX_CLUSTER ? LIME_FLAG_MAXLEN : LIME_FLAG_BADCLUSTER); len = 0; }
         if (len > SMALL_MAX) {

@@ -33,6 +33,7 @@ def test_detect_golden(ctx, golden):
 def test_detect_golden_in_chunks(ctx, golden, monkeypatch):
     """lime_detect walks the arrays in position-range chunks (here 4096 positions): same records, same order"""
     monkeypatch.setenv("LIME_DETECT_CHUNK", "4096")
+    monkeypatch.setenv("LIME_FORCE_STAGING", "1")           # through the pinned staging ring although the arrays are small
     cl, nc, ml = ctx.detect(golden["lcp"], golden["da"], golden["n_reads"], golden["alpha"])
     assert nc == len(golden["clrs"]) and np.array_equal(cl, golden["clrs"])
     assert ml == (int(golden["clrs"][:, 1].max()) if nc else 0)
@@ -67,7 +68,9 @@ def test_fused_stream_golden(ctx, golden, ebwt_mode):
 
 @pytest.mark.parametrize("n,chunk", [(1, 4096), (4096, 4096), (4097, 4096), (300001, 8192), (300001, 65536),
                                      (1000003, 0), (1000003, 262144)])
-def test_fused_stream_synth_vs_oracle(ctx, n, chunk):
+def test_fused_stream_synth_vs_oracle(ctx, n, chunk, monkeypatch):
+    if n == 300001:
+        monkeypatch.setenv("LIME_FORCE_STAGING", "1")       # dozens of chunks through the three pinned slots
     nr, ng, alpha = 500, 40, 16
     lcp, da, eb = O.synth(77, 0, n, nr, ng, alpha, 1)
     clrs, _, ml = O.detect(lcp, da, nr, alpha)
@@ -81,6 +84,7 @@ def test_score_in_chunks(ctx, golden, monkeypatch):
     """lime_score takes the arrays through HBM in position-range chunks (here 4096 positions), clusters in
     any order"""
     monkeypatch.setenv("LIME_SCORE_CHUNK", "4096")
+    monkeypatch.setenv("LIME_FORCE_STAGING", "1")
     rng = np.random.default_rng(5)
     cl = golden["clrs"][rng.permutation(len(golden["clrs"]))]
     for mode in (1, 0):
