@@ -43,3 +43,42 @@ def test_egsa_to_bcr(tmp_path, n, tail):
 def test_egsa_to_bcr_usage(tmp_path):
     assert subprocess.run([EXE], capture_output=True).returncode == 1
     assert subprocess.run([EXE, str(tmp_path / "missing.fasta"), "3"], capture_output=True).returncode != 0
+
+
+def test_suffix_sort_builder_matches_the_naive_one():
+    """lime_amd.builder.build_arrays_sa (prefix doubling + Kasai) == the naive sort on a toy collection with repeats,
+    a region shared by two genomes and IUPAC codes"""
+    import numpy as np
+    from lime_amd.builder import build_arrays, build_arrays_sa
+    rng = np.random.default_rng(7)
+
+    def rs(n):
+        return bytes(rng.choice(np.frombuffer(b"ACGT", np.uint8), n))
+    g = [rs(500), rs(350) + b"NNRYK" + rs(60)]
+    g[1] = g[1][:120] + g[0][40:160] + g[1][240:]
+    reads = []
+    for _ in range(60):
+        src = g[int(rng.integers(0, 2))]
+        s = int(rng.integers(0, len(src) - 30))
+        reads.append(src[s:s + 30])
+    reads += [reads[0], reads[1]]                        # identical reads
+    for term in (0, ord("$")):
+        a = build_arrays(reads, g, term=term)
+        b = build_arrays_sa(reads, g, term=term)
+        for x, y in zip(a, b):
+            assert np.array_equal(x, y)
+
+
+def test_truncated_lcp_gives_the_same_clusters():
+    """README.md:59-61: an lcp array truncated at k >= alpha (eGap --trlcp k) is as good as the full one for LiME --
+    detection only asks lcp >= alpha"""
+    import numpy as np
+    from tests.conftest import load_golden
+    from oracle import oracle_py as O
+    g = load_golden("text_example")
+    full = O.detect(g["lcp"], g["da"], g["n_reads"], g["alpha"])
+    for k in (g["alpha"], g["alpha"] + 1, 40):
+        cut = O.detect(np.minimum(g["lcp"], k).astype(np.uint32), g["da"], g["n_reads"], g["alpha"])
+        assert np.array_equal(cut[0], full[0]) and cut[1:] == full[1:]
+    below = O.detect(np.minimum(g["lcp"], g["alpha"] - 1).astype(np.uint32), g["da"], g["n_reads"], g["alpha"])
+    assert below[1] == 0                                  # truncated below alpha: nothing left, as expected

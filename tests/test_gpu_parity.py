@@ -255,6 +255,18 @@ def test_fused_vs_oracle_synth(ctx, n, nr, ng, mode):
     assert np.array_equal(gcl, cl) and (gnc, gml) == (nc, ml)
 
 
+def test_truncated_lcp_gives_the_same_clusters_and_table(ctx):
+    """README.md:59-61 (eGap --trlcp k, k >= alpha): an lcp array capped at k is as good as the full one"""
+    from tests.conftest import load_golden
+    g = load_golden("text_example")
+    for k in (g["alpha"], 40):
+        lcp = np.minimum(g["lcp"], k).astype(np.uint32)
+        cl, nc, ml = ctx.detect(lcp, g["da"], g["n_reads"], g["alpha"])
+        assert np.array_equal(cl, g["clrs"])
+        sim, gnc, gml = ctx.fused(lcp, g["da"], g["ebwt"], g["n_reads"], g["n_refs"], g["alpha"])
+        assert gnc == len(g["clrs"]) and np.array_equal(sim, g["sim_e1"])
+
+
 def test_empty_input(ctx):
     z32 = np.zeros(0, np.uint32)
     cl, nc, ml = ctx.detect(z32, z32, 3, 16)
