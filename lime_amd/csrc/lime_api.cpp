@@ -288,7 +288,7 @@ extern "C" int lime_get_timing(lime_ctx *c, double *scan_ms_avg, uint64_t *launc
 // Which way the scan's table updates go.  Binned (records -> bins -> table regions built in LDS, the table
 // written once and never cleared) pays for update-dense passes over tables beyond the caches; compare-and-swap
 // on the table for sparse ones and wherever the table must be added to (zero_sim == 0, streaming chunks).
-static bool want_binned(const lime_ctx *c, uint64_t n_own, size_t sim_bytes, int zero_sim, bool keep_stats)
+static bool want_binned(const lime_ctx *c, uint64_t n_own, size_t sim_bytes, int zero_sim, bool keep_stats, int ebwt)
 {
     if (!zero_sim || keep_stats || !n_own) return false;
     if (sim_bytes > ((size_t)BIN_MAX << BIN_SHIFT_MAX) || sim_bytes >= (1ull << CELL_BITS)) return false;
@@ -349,7 +349,7 @@ static int fused_dev_impl(lime_ctx *c, const uint32_t *d_lcp, const uint32_t *d_
     const size_t sim_bytes = lime_sim_bytes(n_reads, n_refs);
     const int ebwt = d_ebwt != nullptr;
     const uint32_t n_tiles = (uint32_t)((n_avail + WIN - 1) / WIN);
-    bool binned = n_avail && want_binned(c, n_own, sim_bytes, zero_sim, keep_stats);
+    bool binned = n_avail && want_binned(c, n_own, sim_bytes, zero_sim, keep_stats, ebwt);
     if (binned && (double)n_own * c->pool_density * 1.10 + 512.0 * 4096.0 > 3.9e9) binned = false;   // more records than 32-bit counts hold: compare-and-swap path
     uint32_t grid = 0, cap_w = 0, n_bins = 0, bin_shift = REGION_SHIFT;
     if (binned) {
@@ -357,8 +357,10 @@ static int fused_dev_impl(lime_ctx *c, const uint32_t *d_lcp, const uint32_t *d_
         // one bin per 64 KB region for small tables; else as few levels of fan-out as fit: at most 2048 bins of 2^k
         // regions (the bins' open output lines then merge in the L2), more bins only when k would pass its limit
         auto bins_at = [&](uint32_t sh) { return (sim_bytes + ((size_t)1 << sh) - 1) >> sh; };
-        if (bins_at(bin_shift) > c->bin_one_level) {
-            while ((bins_at(bin_shift) > c->bin_two_level && bin_shift < BIN_SHIFT_MAX) || bins_at(bin_shift) > BIN_MAX) ++bin_shift;
+        const uint32_t bmax = BIN_MAX;                        // what the scan's LDS histogram holds
+        const uint32_t one = c->bin_one_level < bmax ? c->bin_one_level : bmax, two = c->bin_two_level < bmax ? c->bin_two_level : bmax;
+        if (bins_at(bin_shift) > one) {
+            while ((bins_at(bin_shift) > two && bin_shift < BIN_SHIFT_MAX) || bins_at(bin_shift) > bmax) ++bin_shift;
         }
         n_bins = (uint32_t)bins_at(bin_shift);           // <= BIN_MAX: want_binned checked the table size
         if ((rc = ensure_binned(c, n_own, grid * (SCAN_WG / 64), grid, n_bins, bin_shift, &cap_w, st))) return rc;

@@ -803,9 +803,10 @@ __device__ __forceinline__ void window_load(WinRegs &t, const ScanArgs &a, uint6
 // (position, length) of its accepted clusters into an LDS list at the slots a wave prefix sum gives
 // it; the scoring rounds read that list 64 clusters at a time.
 // =========================================================================================
-struct alignas(16) ScanLds {
+template <int EBWT>                          // EBWT == 0: no symbols are staged (a kilobyte less per wave: a fourth workgroup per CU)
+struct alignas(16) ScanLdsT {
     uint32_t da[WPOS + SMALL_MAX];
-    uint8_t fl[WPOS + SMALL_MAX];
+    uint8_t fl[EBWT ? WPOS + SMALL_MAX : 16];
     alignas(8) uint8_t hb[WPOS / 8 + 14];    // head / read bit of every staged position (byte k = positions 8k..8k+7)
     alignas(8) uint8_t rb[WPOS / 8 + 14];
     // accepted clusters of the window, in order: start | min(len, 63) << 10.  The scoring rounds read it 64
@@ -817,7 +818,7 @@ struct alignas(16) ScanLds {
     uint8_t m_flag[64], m_dup[64];
     uint32_t q_read[QCAP_SCAN], q_gen[QCAP_SCAN];
     uint32_t g_doc[DUP_SLOTS][SMALL_MAX];
-    uint8_t g_sym[DUP_SLOTS][SMALL_MAX], g_len[DUP_SLOTS];
+    uint8_t g_sym[EBWT ? DUP_SLOTS : 1][SMALL_MAX], g_len[DUP_SLOTS];
 };
 
 struct Ctx16 {
@@ -887,32 +888,39 @@ __device__ __forceinline__ Ctx16 chunk_context(uint32_t h, uint32_t r, uint32_t 
 }
 
 // BIN 1 (MODE 0 only): table updates leave the kernel as records (binned update path) instead of compare-and-swaps.
+// waves per SIMD the kernel is compiled for.  (The binned EBWT=0 scan was tried at four -- 128 VGPRs, 39.6 KB of LDS per
+// workgroup with a 1024-bin histogram, no spills: same time as at three, 2.08 vs 2.10 ms on configs[2]; the scan is
+// bound by the vector ALU's issue rate and the memory system together, not by latency a fourth wave would hide.)
+template <int EBWT, int BIN> struct ScanCfg { static constexpr int waves = LIME_SCAN_WAVES; };
+
 template <int EBWT, int MODE, int BIN>
-__global__ __launch_bounds__(SCANK_WG) __attribute__((amdgpu_waves_per_eu(LIME_SCAN_WAVES, LIME_SCAN_WAVES))) void k_scan(ScanArgs a)
+__global__ __launch_bounds__(SCANK_WG) __attribute__((amdgpu_waves_per_eu(ScanCfg<EBWT, BIN>::waves, ScanCfg<EBWT, BIN>::waves))) void k_scan(ScanArgs a)
 {
     static_assert(BIN == 0 || MODE == 0, "records are made by the scoring scan only");
+    typedef ScanLdsT<EBWT> ScanLds;
     __shared__ ScanLds lds[SCANK_WG / 64];
     __shared__ WgTables T;
     // per wave the in-flight compare-and-swap slots (entry read, genome | t, expected word: 3 x 256 words); in
-    // binned mode the same 12 KB are the workgroup's histogram of update records per table bin
-    __shared__ uint32_t fslots[SCANK_WG / 64][768];
+    // binned mode the workgroup's histogram of update records per table bin instead
+    constexpr uint32_t FS = BIN ? BIN_MAX : (SCANK_WG / 64) * 768u;
+    __shared__ uint32_t fslots[FS];
     __shared__ uint32_t wg_done;
-    static_assert(sizeof(fslots) / 4 >= BIN_MAX, "the bin histogram lives in the CAS slots' LDS");
     const uint32_t lane = lane_id(), wave = (uint32_t)__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));   // wave-uniform: LDS bases stay scalar
     ScanLds &L = lds[wave];
     constexpr bool binned = BIN != 0;
     if (binned) {
-        for (uint32_t i = threadIdx.x; i < (uint32_t)(sizeof(fslots) / 4); i += SCANK_WG) (&fslots[0][0])[i] = 0u;
+        for (uint32_t i = threadIdx.x; i < FS; i += SCANK_WG) fslots[i] = 0u;
         if (threadIdx.x == 0) wg_done = 0u;
     }
     tables_init(T);                                        // the only workgroup barrier of the kernel
     const uint32_t n_win = a.n_tiles, stride = gridDim.x * (SCANK_WG / 64);
     uint32_t win = blockIdx.x * (SCANK_WG / 64) + wave;
     UpdQueue qu; qu.qr = L.q_read; qu.qg = L.q_gen; qu.n = 0; qu.cap = QCAP_SCAN;
-    qu.async = true; qu.fr = fslots[wave]; qu.fg = fslots[wave] + 256; qu.fe = fslots[wave] + 512;
+    qu.async = true;
+    if (!binned) { qu.fr = fslots + 768u * wave; qu.fg = qu.fr + 256; qu.fe = qu.fr + 512; }
     const uint32_t wave_gid = blockIdx.x * (SCANK_WG / 64) + wave;
     qu.binned = binned;
-    if (binned) { qu.out = a.pool + (size_t)wave_gid * a.cap_w; qu.hist = &fslots[0][0]; }
+    if (binned) { qu.out = a.pool + (size_t)wave_gid * a.cap_w; qu.hist = fslots; }
     // binned mode, end of a wave: its record count; the workgroup's last wave writes the bin histogram
     auto finish_binned = [&]() {
         if (lane == 0) {

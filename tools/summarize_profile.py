@@ -1,19 +1,20 @@
 #!/usr/bin/env python3
-"""tools/summarize_profile.py TAG -- turn the rocprofv3 output of tools/profile.sh TAG
+"""tools/summarize_profile.py TAG WORKLOAD -- turn the rocprofv3 output of tools/profile.sh TAG WORKLOAD
 (gpurun_out/prof_TAG/{trace,pmc1..pmc4}) into the summaries kept under profiles/:
 
-  profiles/TAG_kernel_stats.csv   the --kernel-trace --stats table (lime:: kernels and fills)
+  profiles/TAG_kernel_stats.csv   the --kernel-trace --stats table
   profiles/TAG_pmc_summary.json   per kernel, every counter averaged over its launches
-  profiles/traffic.json           HBM bytes per launch of the dominant kernel, read by bench.py
+  profiles/TAG_bench.json         the bench line of the traced run
+  profiles/traffic.json           [WORKLOAD] HBM bytes per launch of the dominant kernel, read by bench.py
 
-HBM bytes follow /opt/skills/guides/MI355X_MICROARCH.md: FETCH_SIZE and WRITE_SIZE are in KiB,
-and gfx950 counts 128-byte fetch requests as 64 bytes, so fetch bytes = 2 x FETCH_SIZE x 1024.
-"""
+HBM bytes follow /opt/skills/guides/MI355X_MICROARCH.md: FETCH_SIZE and WRITE_SIZE are in KiB, and gfx950 counts
+128-byte fetch requests as 64 bytes, so fetch bytes = 2 x FETCH_SIZE x 1024."""
 import csv
 import glob
 import json
 import os
 import re
+import shutil
 import sys
 from collections import defaultdict
 
@@ -26,14 +27,19 @@ def short(name):
 
 
 def main():
-    tag = sys.argv[1] if len(sys.argv) > 1 else "r01"
+    tag = sys.argv[1] if len(sys.argv) > 1 else "r02"
+    wl = sys.argv[2] if len(sys.argv) > 2 else "c3"
     src = os.path.join(ROOT, "gpurun_out", "prof_" + tag)
     dst = os.path.join(ROOT, "profiles")
     stats = glob.glob(os.path.join(src, "trace", "**", "*kernel_stats.csv"), recursive=True)
     if not stats:
         sys.exit("no kernel_stats.csv under " + src)
-    with open(stats[0]) as f, open(os.path.join(dst, tag + "_kernel_stats.csv"), "w") as g:
-        g.write(f.read())
+    shutil.copy(stats[0], os.path.join(dst, tag + "_kernel_stats.csv"))
+    bl = os.path.join(src, "bench_line.json")
+    bench = None
+    if os.path.exists(bl) and os.path.getsize(bl):
+        bench = json.load(open(bl))
+        json.dump(bench, open(os.path.join(dst, tag + "_bench.json"), "w"), indent=1)
     acc = defaultdict(lambda: defaultdict(list))
     for path in glob.glob(os.path.join(src, "pmc*", "**", "*counter_collection.csv"), recursive=True):
         per_dispatch = defaultdict(float)
@@ -49,23 +55,26 @@ def main():
                for k, ctrs in sorted(acc.items()) if k.startswith("lime::")}
     with open(os.path.join(dst, tag + "_pmc_summary.json"), "w") as g:
         json.dump(summary, g, indent=1)
-    dom = max((k for k in summary if "k_scan" in k), key=lambda k: summary[k].get("FETCH_SIZE", 0.0), default=None)
+    dom = max((k for k in summary if "k_scan<" in k), key=lambda k: summary[k].get("FETCH_SIZE", 0.0), default=None)
     if dom and "FETCH_SIZE" in summary[dom] and "WRITE_SIZE" in summary[dom]:
         s = summary[dom]
-        traffic = {
-            "kernel": dom,
+        tfile = os.path.join(dst, "traffic.json")
+        try:
+            allt = json.load(open(tfile))
+            if "kernel" in allt:            # round-1 layout: one entry
+                allt = {}
+        except Exception:
+            allt = {}
+        allt[wl] = {
+            "kernel": dom, "symbols": bench["config"]["symbols_total"] if bench else None,
             "hbm_bytes_per_launch": int(2 * s["FETCH_SIZE"] * 1024 + s["WRITE_SIZE"] * 1024),
-            "FETCH_SIZE_KiB": s["FETCH_SIZE"], "WRITE_SIZE_KiB": s["WRITE_SIZE"],
-            "TCC_EA0_ATOMIC_sum": s.get("TCC_EA0_ATOMIC_sum"),
-            "correction": "HBM bytes = 2 x FETCH_SIZE x 1024 (gfx950 counts 128-B requests at 64 B) + WRITE_SIZE x 1024; "
-                          "separate --pmc passes (tools/profile.sh %s), bench.py --steps 5 --warmup 2 --no-cpu, "
-                          "averages over %d launches" % (tag, s["launches"]),
-            "algorithmic_bytes_per_launch": 900000000,
-            "profile": tag,
+            "FETCH_SIZE_KiB": s["FETCH_SIZE"], "WRITE_SIZE_KiB": s["WRITE_SIZE"], "TCC_EA0_ATOMIC_sum": s.get("TCC_EA0_ATOMIC_sum"),
+            "algorithmic_bytes_per_launch": bench["roofline"]["algorithmic_bytes_per_launch"] if bench else None,
+            "from": f"profiles/{tag}_pmc_summary.json: HBM bytes = 2 x FETCH_SIZE x 1024 (gfx950 counts 128-B requests at 64 B) + WRITE_SIZE x 1024, "
+                    f"separate --pmc passes of tools/profile.sh {tag} {wl}, averages over {s['launches']} launches",
         }
-        with open(os.path.join(dst, "traffic.json"), "w") as g:
-            json.dump(traffic, g, indent=1)
-        print(json.dumps(traffic))
+        json.dump(allt, open(tfile, "w"), indent=1)
+        print(json.dumps(allt[wl]))
     for k, s in summary.items():
         print(k, {c: round(v) for c, v in s.items()})
 
