@@ -1315,8 +1315,11 @@ __global__ __launch_bounds__(256) void k_bin_rowscan(uint32_t *counts, uint32_t 
 // records go to their slots together with their final position, and the tile leaves LDS slot by slot -- so a wave's
 // store instruction writes runs of consecutive positions instead of 64 scattered dwords (scattered 4-byte stores
 // cost the CU's address path about 3 cycles per lane: 0.8 ms per 1.2e8 records and level, measured).
+#ifndef LIME_PART_PER
+#define LIME_PART_PER 16
+#endif
 constexpr int PART_WG = 512;
-constexpr uint32_t PART_PER = 16, PART_TILE = PART_WG * PART_PER;          // 8192 records per tile, 64 KB of (position, record)
+constexpr uint32_t PART_PER = LIME_PART_PER, PART_TILE = PART_WG * PART_PER;   // 8192 records per tile, 64 KB of (position, record)
 
 // exclusive prefix of cnt[0 .. nb) into toff[0 .. nb), nb <= PART_WG * 8; all threads of the workgroup call it
 // (barriers inside: cnt is complete on entry, toff on exit)
