@@ -44,11 +44,16 @@ WORKLOADS = {
     "c2": dict(n=100_000_000, nr=100_000, ng=500, ebwt=1, mode=0, what="BASELINE.json configs[1]"),
     "c2_clustered": dict(n=100_000_000, nr=100_000, ng=500, ebwt=1, mode=1, what="configs[1] shape, clustered generator (SURVEY 8d)"),
     "n1e10": dict(n=10_000_000_000, nr=1_000_000, ng=1000, ebwt=0, mode=0, what="north_star scaling series, N = 10^10"),
+    # text-derived statistics: tests/golden/text_example.npz (2000 example reads x 3 surrogate genomes, 442 003 symbols, 49.5 % of
+    # them in clusters, 0.24 table updates per symbol) laid side by side 226 times, every copy with its own reads and genomes
+    "text_tiled": dict(n=226 * 442_003, nr=226 * 2000, ng=226 * 3, ebwt=1, mode=-1, tiled=226,
+                       what="tests/golden/text_example.npz x 226 copies (real-text cluster statistics; stands in for configs[0])"),
 }
 
 
 def describe(wl, n_total, world):
-    return (f"synthetic S (seed {SEED}, generator mode {wl['mode']}): {n_total} symbols, {wl['nr']} reads x {wl['ng']} genomes "
+    return ((f"synthetic S (seed {SEED}, generator mode {wl['mode']})" if not wl.get("tiled") else "text-derived S") +
+            f": {n_total} symbols, {wl['nr']} reads x {wl['ng']} genomes "
             f"({wl['nr'] * wl['ng'] / 1e9:.2f} GB table), alpha={ALPHA}, EBWT={wl['ebwt']} ({8 + wl['ebwt']} B/symbol) -- {wl['what']}"
             + (f"; cut into {world} position ranges" if world > 1 else ""))
 
@@ -122,7 +127,22 @@ def run_pass_series(torch, lime_amd, ldist, wl, n_total, steps, warmup, world, r
     stream = torch.cuda.current_stream().cuda_stream
     ex_stream = torch.cuda.Stream(device=dev) if (world > 1 and overlap) else None
     done = [None] * nbuf                       # event: the exchange that read sims[b] has completed
-    ctx.synth_dev(SEED, lo, n_avail, wl["nr"], wl["ng"], ALPHA, wl["mode"], lcp, da, eb, stream)
+    if wl.get("tiled"):
+        import numpy as np
+        z = np.load(os.path.join(ROOT, "tests", "golden", "text_example.npz"))
+        k, m = wl["tiled"], len(z["lcp"])
+        nr1, ng1 = int(z["params"][0]), int(z["params"][1])
+        assert world == 1 and n_avail == k * m and wl["nr"] == k * nr1 and wl["ng"] == k * ng1
+        l1 = torch.from_numpy(z["lcp"].astype(np.int32)).to(dev); d1 = torch.from_numpy(z["da"].astype(np.int64)).to(dev)
+        e1 = torch.from_numpy(z["ebwt"]).to(dev)
+        copy = torch.arange(k, device=dev, dtype=torch.int64).repeat_interleave(m)
+        dd = d1.repeat(k)
+        isr = dd < nr1                                  # copy c: reads c*nr1 .., genomes (after ALL reads) c*ng1 ..
+        da.copy_(torch.where(isr, dd + copy * nr1, k * nr1 + copy * ng1 + (dd - nr1)).to(torch.int32))
+        lcp.copy_(l1.repeat(k)); eb.copy_(e1.repeat(k))
+        del l1, d1, e1, copy, dd, isr
+    else:
+        ctx.synth_dev(SEED, lo, n_avail, wl["nr"], wl["ng"], ALPHA, wl["mode"], lcp, da, eb, stream)
     torch.cuda.synchronize()
     counter = [0]
 
@@ -286,7 +306,7 @@ def main():
     if not args.no_also:
         also = {}
         if world == 1:
-            for name in ("c2", "c2_clustered", "n1e10"):
+            for name in ("c2", "c2_clustered", "text_tiled", "n1e10"):
                 if name == wname:
                     continue
                 w2 = WORKLOADS[name]

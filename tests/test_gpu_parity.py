@@ -404,7 +404,7 @@ def test_position_range_shards_sum_to_whole(ctx, n_shards):
     assert np.array_equal(total, exp)
 
 
-@pytest.mark.parametrize("shape", ["C2", "C3"])
+@pytest.mark.parametrize("shape", ["C2", "C3", "C4"])
 def test_full_size_paths_agree(ctx, shape):
     """BASELINE.json's full sizes (configs[1]: 10^8 symbols, 10^5 x 500, EBWT=1; configs[2]: 10^9 symbols,
     10^6 x 5000, EBWT=0), inputs generated on the device.  Too big for the oracle, so size-independent
@@ -416,7 +416,11 @@ def test_full_size_paths_agree(ctx, shape):
     import torch
     import lime_amd
     from lime_amd.dist import shard_ranges
-    n, nr, ng, ebwt_on = (100_000_000, 100_000, 500, True) if shape == "C2" else (1_000_000_000, 1_000_000, 5000, False)
+    # C4: the shapes of configs[3] (setB2: 20 249 373 reads x 930 genomes = 18.8 GB table, README.md:137) on 2*10^9
+    # synthetic symbols, EBWT=1; its four position-range shards run one after the other on this one GPU
+    n, nr, ng, ebwt_on = {"C2": (100_000_000, 100_000, 500, True), "C3": (1_000_000_000, 1_000_000, 5000, False),
+                          "C4": (2_000_000_000, 20_249_373, 930, True)}[shape]
+    n_shards = 4 if shape == "C4" else 3
     alpha, dev = 16, torch.device("cuda:0")
     lcp = torch.empty(n, dtype=torch.int32, device=dev); da = torch.empty_like(lcp)
     eb = torch.empty(n, dtype=torch.uint8, device=dev) if ebwt_on else None
@@ -426,10 +430,10 @@ def test_full_size_paths_agree(ctx, shape):
     ctx.fused_dev(lcp, da, eb, n, n, True, nr, ng, alpha, A, True)
     sA, rc = ctx.stats(); assert rc == 0
     assert sA.n_clusters > n // 30 and sA.n_updates > 0
-    # (1) three shards into one table
+    # (1) three (C4: four) shards into one table
     B = torch.empty(tb, dtype=torch.uint8, device=dev)
     tot_c, tot_m, tot_u = 0, 0, 0
-    for k, (lo, hi, hh) in enumerate(shard_ranges(n, 3)):
+    for k, (lo, hi, hh) in enumerate(shard_ranges(n, n_shards)):
         ctx.fused_dev(lcp[lo:], da[lo:], None if eb is None else eb[lo:], hi - lo, hh - lo, hh == n, nr, ng, alpha, B, k == 0)
         s, rc = ctx.stats(); assert rc == 0
         tot_c += s.n_clusters; tot_m = max(tot_m, s.max_len); tot_u += s.n_updates
