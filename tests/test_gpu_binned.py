@@ -141,3 +141,35 @@ def test_binned_shards_sum_to_whole(bctx, n_shards):
         total = (total + sim[:nr * ng].cpu().numpy().reshape(nr, ng)).astype(np.uint8)
     assert tot_c == nc
     assert np.array_equal(total, exp)
+
+
+@pytest.mark.parametrize("seed", range(12))
+def test_binned_random_shapes(monkeypatch, seed):
+    """random table shapes around region and bin edges (rows that are not multiples of 4 bytes, tables of exactly k
+    regions +- a few bytes, one row, one column), random level limits, both builds, against the oracle"""
+    import lime_amd
+    rng = np.random.default_rng(1000 + seed)
+    kind = seed % 4
+    if kind == 0:                                   # table ends a few bytes around a multiple of 64 KB
+        ng = int(rng.integers(3, 900)); nr = max(1, (int(rng.integers(1, 6)) * 65536 + int(rng.integers(-5, 6))) // ng)
+    elif kind == 1:                                 # one read, many genomes / one genome, many reads
+        nr, ng = (1, int(rng.integers(70000, 200000))) if seed % 8 == 1 else (int(rng.integers(70000, 200000)), 1)
+    elif kind == 2:                                 # odd widths
+        nr, ng = int(rng.integers(50, 3000)), int(rng.integers(1, 40)) * 2 + 1
+    else:
+        nr, ng = int(rng.integers(1000, 20000)), int(rng.integers(100, 2000))
+    levels = f"{int(rng.integers(1, 40))},{int(rng.integers(1, 300))}"
+    monkeypatch.setenv("LIME_UPDATE_PATH", "bin")
+    monkeypatch.setenv("LIME_BIN_LEVELS", levels)
+    n = int(rng.integers(200000, 900000))
+    lcp, da, eb = O.synth(7000 + seed, 0, n, nr, ng, 16, seed & 1)
+    cl, nc, ml = O.detect(lcp, da, nr, 16)
+    c = lime_amd.Context()
+    try:
+        for e in (eb, None):
+            exp = O.score(da, e, cl, nr, ng, threads=4)
+            sim, gnc, gml = c.fused(lcp, da, e, nr, ng, 16)
+            assert (gnc, gml) == (nc, ml), (nr, ng, levels)
+            assert np.array_equal(sim, exp), (nr, ng, levels, int((sim != exp).sum()))
+    finally:
+        c.close()
