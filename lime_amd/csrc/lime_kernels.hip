@@ -555,6 +555,32 @@ __device__ __forceinline__ uint32_t score_lists(LDS &L, const ScanArgs &a, uint3
     return nupd;
 }
 
+// Clusters of exactly 2 symbols, one lane per cluster: an accepted one holds one read and one genome (never a
+// repeated document), so it is ONE pair -- two documents, one read bit, one compatibility lookup, at most one queue
+// entry per lane (slots from a ballot, no prefix sum).  Real collections are mostly such clusters (98 % in the
+// text-derived fixture): windows with more than 64 clusters score theirs in rounds of their own.
+template <int EBWT, typename LDS>
+__device__ __forceinline__ uint32_t score_len2(LDS &L, const WgTables &T, UpdQueue &qu, const ScanArgs &a, bool on, uint32_t p)
+{
+    const uint32_t d0 = L.da[p], d1 = L.da[p + 1u];
+    const uint32_t r0 = ((uint32_t)L.rb[p >> 3] >> (p & 7u)) & 1u;           // position p is the read; else p + 1 is
+    bool hit = on;
+    if (EBWT) hit = hit && ((T.compatb[L.fl[p]] >> T.symidx[L.fl[p + 1u]]) & 1u);
+    const uint32_t rd = r0 ? d0 : d1, gd = (r0 ? d1 : d0) - a.n_reads;
+    const bool bad = hit && gd >= a.n_refs;
+    if (__ballot(bad)) { if (bad) atomicOr(&a.stats->flags, LIME_FLAG_DOCID); }
+    hit = hit && !bad;
+    const uint64_t m = __ballot(hit);
+    const uint32_t tot = (uint32_t)__popcll(m);
+    while (qu.n + tot > qu.cap) drain(qu, a);
+    if (hit) {
+        const uint32_t slot = qu.n + (uint32_t)__popcll(m & ((1ull << lane_id()) - 1ull));
+        qu.qr[slot] = rd; qu.qg[slot] = gd | (1u << T_SHIFT);
+    }
+    qu.n += tot;
+    return hit ? 1u : 0u;
+}
+
 // Clusters of 2..4 symbols (the bulk), one lane per cluster, no loops.  `p` is the window
 // position of the cluster's head; its length and which of its symbols are reads come from the
 // window's head / read bytes; the 4 documents and ebwt bytes sit in registers.  Two equal
@@ -1040,11 +1066,22 @@ __global__ __launch_bounds__(SCANK_WG) __attribute__((amdgpu_waves_per_eu(ScanCf
         if (!ABL(3)) {
         // ---- every lane lists the accepted clusters of its chunk: slots from a wave prefix sum ---------
         const uint32_t cnt = (uint32_t)__popc(c.ah);
-        const uint32_t incl = wave_incl_scan(cnt), total = rl32(incl, 63);
+        // heads of 2-symbol clusters: the next head of the chunk is two positions on; the chunk's last head by its segment's end
+        uint32_t m2 = c.ah & ~(c.h >> 1) & (c.h >> 2);
+        {
+            const uint32_t lhb = (c.info >> 5) & 31u;
+            if (MODE == 0 && ((c.ah >> lhb) & 1u) && c.e_suf - (c0 + lhb) == 2u) m2 |= 1u << lhb;
+        }
+        const uint32_t cnt2 = (uint32_t)__popc(m2);
+        // one prefix sum for both lists: 2-symbol clusters in the low half, the others in the high half
+        const uint32_t incl = wave_incl_scan(MODE == 0 ? cnt2 | ((cnt - cnt2) << 16) : cnt);
+        const uint32_t tot2 = rl32(incl, 63);
+        const uint32_t n2 = MODE == 0 ? tot2 & 0xFFFFu : 0u, total = MODE == 0 ? n2 + (tot2 >> 16) : tot2;
         acc_n += cnt;
         if (MODE == 0) {
             {
-                uint32_t m = c.ah, k = incl - cnt;
+                // the window's list: the 2-symbol clusters first ([0, n2)), then the others
+                uint32_t m = c.ah, k2 = (incl & 0xFFFFu) - cnt2, ko = n2 + (incl >> 16) - (cnt - cnt2);
                 while (__ballot(m != 0u)) {
                     if (m) {
                         const uint32_t b = (uint32_t)__builtin_ctz(m);
@@ -1053,14 +1090,25 @@ __global__ __launch_bounds__(SCANK_WG) __attribute__((amdgpu_waves_per_eu(ScanCf
                         const uint32_t e = hi ? p + 1u + (uint32_t)__builtin_ctz(hi) : c.e_suf;
                         const uint32_t len = e - p;
                         acc_max = len > acc_max ? len : acc_max;
-                        L.listM[k++] = (uint16_t)(p | ((len < 63u ? len : 63u) << 10));
+                        const uint32_t slot = (m2 >> b) & 1u ? k2++ : ko++;
+                        L.listM[slot] = (uint16_t)(p | ((len < 63u ? len : 63u) << 10));
                     }
                 }
             }
             uint32_t nM = 0, nX = 0;
             PT(3)
+            // more clusters than one round takes: the 2-symbol ones go first, in rounds of their own (one pair each)
+            uint32_t first = 0;
+            if (total > 64u && !ABL(4) && !ABL(10)) {
+                for (uint32_t base = 0; base < n2; base += 64u) {
+                    const uint32_t t = base + lane;
+                    const bool on = t < n2;
+                    acc_upd += score_len2<EBWT>(L, T, qu, a, on, on ? (uint32_t)L.listM[t] & 1023u : 0u);
+                }
+                first = n2;
+            }
             if (!ABL(4))
-            for (uint32_t base = 0; base < total; base += 64u) {
+            for (uint32_t base = first; base < total; base += 64u) {
                 const uint32_t t = base + lane;
                 const bool on = t < total;
                 const uint32_t item = on ? L.listM[t] : 0u;
