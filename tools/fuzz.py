@@ -1,0 +1,91 @@
+#!/usr/bin/env python3
+"""tools/fuzz.py [seconds] [seed] -- random inputs through every entry point of the hot path against the oracle (bit-exact), on
+the GPU box.  Shapes, generator parameters, cluster-length regimes, update paths, chunk sizes and shard counts are
+drawn at random; stops at the first difference with a description that reproduces it.  Not part of the test suite
+(time-boxed soak); the fixed cases it found nothing beyond are in tests/."""
+import os, sys, time
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import numpy as np
+import torch
+import lime_amd
+from lime_amd.dist import shard_ranges, combine_edges
+from oracle import oracle_py as O
+
+budget = float(sys.argv[1]) if len(sys.argv) > 1 else 120.0
+seed0 = int(sys.argv[2]) if len(sys.argv) > 2 else 1
+t_end = time.time() + budget
+it = 0
+stats = {"cases": 0, "symbols": 0, "binned": 0, "shards": 0, "streams": 0}
+while time.time() < t_end:
+    it += 1
+    rng = np.random.default_rng(seed0 * 100003 + it)
+    n = int(rng.choice([rng.integers(1, 3000), rng.integers(3000, 200000), rng.integers(200000, 1500000)]))
+    nr = int(rng.choice([1, 2, rng.integers(3, 50), rng.integers(50, 5000), rng.integers(5000, 200000)]))
+    ng = int(rng.choice([1, 2, rng.integers(3, 50), rng.integers(50, 3000)]))
+    alpha = int(rng.choice([1, 2, 16, 16, 16, 30]))
+    mode = int(rng.integers(0, 2))
+    lcp, da, eb = O.synth(int(rng.integers(1, 1 << 30)), int(rng.integers(0, 1 << 20)), n, nr, ng, alpha, mode)
+    regime = int(rng.integers(0, 5))
+    if regime == 1:                      # long runs
+        k = int(rng.integers(1, 6))
+        for _ in range(k):
+            a0 = int(rng.integers(0, n)); ln = int(rng.integers(10, min(n, 70000) + 1))
+            lcp[a0:a0 + ln] = alpha + 3
+    elif regime == 2:                    # dense short clusters
+        per = int(rng.integers(2, 7)); lcp[:] = alpha; lcp[::per] = 0
+    elif regime == 3 and n > 10:         # few documents: repeats everywhere
+        da = np.where(da < nr, da % min(nr, 2), nr + (da - nr) % min(ng, 2)).astype(np.uint32)
+    lcp[0] = int(rng.choice([0, alpha]))  # leading positions before the first head are ignored
+    lcp = lcp.astype(np.uint32)
+    if rng.random() < 0.2:
+        eb = rng.choice(np.frombuffer(b"ACGTNRYKMSWBDHV\x00$#acgt", np.uint8), n).astype(np.uint8)
+    cl, nc, ml = O.detect(lcp, da, nr, alpha)
+    desc = f"it={it} seed0={seed0} n={n} nr={nr} ng={ng} alpha={alpha} mode={mode} regime={regime}"
+    path = "bin" if rng.random() < 0.5 else "cas"
+    os.environ["LIME_UPDATE_PATH"] = path
+    if path == "bin" and rng.random() < 0.5:
+        os.environ["LIME_BIN_LEVELS"] = f"{int(rng.integers(1, 30))},{int(rng.integers(1, 200))}"
+    else:
+        os.environ.pop("LIME_BIN_LEVELS", None)
+    ctx = lime_amd.Context()
+    try:
+        gcl, gnc, gml = ctx.detect(lcp, da, nr, alpha)
+        assert (gnc, gml) == (nc, ml) and np.array_equal(gcl, cl), "detect: " + desc
+        for e in (eb, None):
+            tag = desc + f" path={path} levels={os.environ.get('LIME_BIN_LEVELS')} ebwt={e is not None}"
+            if ml > 65536:
+                try:
+                    ctx.fused(lcp, da, e, nr, ng, alpha); raise AssertionError("no MAXLEN error: " + tag)
+                except lime_amd.LimeError as ex:
+                    assert ex.code == -4, tag
+                continue
+            exp = O.score(da, e, cl, nr, ng, threads=8)
+            sim, gnc, gml = ctx.fused(lcp, da, e, nr, ng, alpha)
+            assert (gnc, gml) == (nc, ml) and np.array_equal(sim, exp), "fused: " + tag
+            r = rng.random()
+            if r < 0.35:
+                chunk = int(rng.choice([4096, 8192, 65536, 262144]))
+                sim, gnc, gml = ctx.fused_stream(lcp, da, e, nr, ng, alpha, chunk=chunk)
+                assert (gnc, gml) == (nc, ml) and np.array_equal(sim, exp), f"stream chunk={chunk}: " + tag
+                stats["streams"] += 1
+            elif r < 0.6:
+                assert np.array_equal(ctx.score(da, e, cl[rng.permutation(len(cl))] if len(cl) else cl, nr, ng), exp), "score: " + tag
+            elif r < 0.85 and n > 8192:
+                ns = int(rng.integers(2, 6)); tot = np.zeros((nr, ng), np.uint8); tc = 0; edges = []
+                for lo, hi, hh in shard_ranges(n, ns):
+                    tl = torch.from_numpy(lcp[lo:hh].view(np.int32)).cuda(); td = torch.from_numpy(da[lo:hh].view(np.int32)).cuda()
+                    te = None if e is None else torch.from_numpy(e[lo:hh]).cuda()
+                    st = torch.full((lime_amd.sim_bytes(nr, ng),), 3, dtype=torch.uint8, device="cuda")
+                    ctx.fused_dev(tl, td, te, hi - lo, hh - lo, hh == n, nr, ng, alpha, st, True)
+                    s, rc = ctx.stats()
+                    assert rc == 0 or (rc == -5 and s.edge & 8), f"shard rc={rc}: " + tag
+                    edges.append(s.edge); tc += s.n_clusters
+                    tot = (tot + st[:nr * ng].cpu().numpy().reshape(nr, ng)).astype(np.uint8)
+                combine_edges(edges)
+                assert tc == nc and np.array_equal(tot, exp), f"shards={ns}: " + tag
+                stats["shards"] += 1
+            s, rc = ctx.stats()
+        stats["cases"] += 1; stats["symbols"] += n; stats["binned"] += path == "bin"
+    finally:
+        ctx.close()
+print("fuzz ok:", stats, "in", round(budget), "s")
