@@ -15,6 +15,7 @@ budget = float(sys.argv[1]) if len(sys.argv) > 1 else 120.0
 seed0 = int(sys.argv[2]) if len(sys.argv) > 2 else 1
 t_end = time.time() + budget
 it = 0
+t_print = time.time()
 stats = {"cases": 0, "symbols": 0, "binned": 0, "shards": 0, "streams": 0}
 while time.time() < t_end:
     it += 1
@@ -86,6 +87,8 @@ while time.time() < t_end:
                 stats["shards"] += 1
             s, rc = ctx.stats()
         stats["cases"] += 1; stats["symbols"] += n; stats["binned"] += path == "bin"
+        if time.time() - t_print > 30:                   # a line now and then: a silent GPU run is taken for hung
+            print("fuzz ...", stats, flush=True); t_print = time.time()
     finally:
         ctx.close()
 print("fuzz ok:", stats, "in", round(budget), "s")
