@@ -42,7 +42,8 @@ static int fail(int code, const char *fmt, ...)
 
 struct lime_ctx {
     int device = 0;
-    DevStats *d_stats = nullptr;
+    DevStats *d_stats = nullptr;                // followed by the sticky word: passes with a pool overflow not settled by lime_get_stats
+    uint32_t *d_sticky = nullptr;
     unsigned long long *d_total = nullptr;
     // per-tile scratch (capacity in tiles)
     size_t tile_cap = 0;
@@ -76,6 +77,7 @@ struct lime_ctx {
         const uint32_t *lcp = nullptr, *da = nullptr; const uint8_t *ebwt = nullptr;
         uint64_t n_own = 0, n_avail = 0; int eof = 0; uint32_t n_reads = 0, n_refs = 0, alpha = 0;
         uint8_t *sim = nullptr; int zero_sim = 0; hipStream_t st = nullptr; uint32_t n_waves = 0;
+        uint64_t own_total = 0;             // owned symbols the counters in d_stats stand for (chunks of a stream accumulate)
     } last;
     // timing with HIP events on the launch stream: per pass {pass start, scan start, scan end, pass end}
     bool timing = false;
@@ -128,9 +130,10 @@ extern "C" int lime_init(int device, lime_ctx **out)
     lime_ctx *c = new (std::nothrow) lime_ctx();
     if (!c) return fail(LIME_ERR_NOMEM, "lime_init: out of host memory");
     HIP_TRY(hipGetDevice(&c->device));
-    HIP_TRY(hipMalloc(&c->d_stats, sizeof(DevStats)));
+    HIP_TRY(hipMalloc(&c->d_stats, sizeof(DevStats) + 16));
+    c->d_sticky = reinterpret_cast<uint32_t *>(c->d_stats + 1);
     HIP_TRY(hipMalloc(&c->d_total, sizeof(unsigned long long)));
-    HIP_TRY(hipMemset(c->d_stats, 0, sizeof(DevStats)));
+    HIP_TRY(hipMemset(c->d_stats, 0, sizeof(DevStats) + 16));
 #ifdef LIME_ABLATE_BUILD
     if (const char *s = getenv("LIME_ABLATE")) c->ablate = atoi(s);
 #endif
@@ -228,6 +231,7 @@ static ScanArgs base_args(lime_ctx *c, const uint32_t *lcp, const uint32_t *da, 
     a.tile_cnt = c->d_tile_cnt; a.tile_off = c->d_tile_off; a.cross = c->d_cross; a.out = c->d_out;
     a.wmask = c->d_wmask;
     a.edge = &c->d_stats->edge;
+    a.sticky = c->d_sticky;
     a.ablate = c->ablate;
     return a;
 }
@@ -311,8 +315,8 @@ static int ensure_binned(lime_ctx *c, uint64_t n_own, uint32_t n_waves, uint32_t
     const size_t want = (size_t)cw * n_waves;
     if (want > c->pool_cap) {
         HIP_TRY(hipStreamSynchronize(st));
-        if ((rc = regrow(c->d_pool, want))) return rc;
-        if ((rc = regrow(c->d_recs, want))) return rc;
+        if ((rc = regrow(c->d_pool, want + 8))) return rc;       // slack: k_part2 / k_apply read aligned groups of four 4-byte records
+        if ((rc = regrow(c->d_recs, want + 8))) return rc;
         c->pool_cap = want; c->recs_cap = want;
     }
     if (n_waves > c->wave_cap) { HIP_TRY(hipStreamSynchronize(st)); if ((rc = regrow(c->d_wave_cnt, (size_t)n_waves))) return rc; c->wave_cap = n_waves; }
@@ -335,7 +339,7 @@ static int ensure_binned(lime_ctx *c, uint64_t n_own, uint32_t n_waves, uint32_t
 static int fused_dev_impl(lime_ctx *c, const uint32_t *d_lcp, const uint32_t *d_da, const uint8_t *d_ebwt,
                           uint64_t n_own, uint64_t n_avail, int eof, uint32_t n_reads, uint32_t n_refs,
                           uint32_t alpha, uint8_t *d_sim, int zero_sim, bool keep_stats, hipStream_t st,
-                          uint32_t *d_edge = nullptr)
+                          uint32_t *d_edge = nullptr, bool no_bin = false)
 {
     int rc;
     if (n_own > n_avail) return fail(LIME_ERR_ARG, "lime_fused_dev: n_own > n_avail");
@@ -350,7 +354,9 @@ static int fused_dev_impl(lime_ctx *c, const uint32_t *d_lcp, const uint32_t *d_
     const size_t sim_bytes = lime_sim_bytes(n_reads, n_refs);
     const int ebwt = d_ebwt != nullptr;
     const uint32_t n_tiles = (uint32_t)((n_avail + WIN - 1) / WIN);
-    bool binned = n_avail && want_binned(c, n_own, sim_bytes, zero_sim, keep_stats, ebwt);
+    // no_bin: a chunk of a multi-chunk stream -- its device buffers are reused by later chunks, so the pass could not be
+    // repeated after a pool overflow, and the later chunks add to the table by compare-and-swap
+    bool binned = n_avail && !no_bin && want_binned(c, n_own, sim_bytes, zero_sim, keep_stats, ebwt);
     if (binned && (double)n_own * c->pool_density * 1.10 + 512.0 * 4096.0 > 3.9e9) binned = false;   // more records than 32-bit counts hold: compare-and-swap path
     uint32_t grid = 0, cap_w = 0, n_bins = 0, bin_shift = REGION_SHIFT;
     if (binned) {
@@ -411,6 +417,10 @@ static int fused_dev_impl(lime_ctx *c, const uint32_t *d_lcp, const uint32_t *d_
         l.valid = true; l.binned = binned; l.lcp = d_lcp; l.da = d_da; l.ebwt = d_ebwt; l.n_own = n_own; l.n_avail = n_avail;
         l.eof = eof; l.n_reads = n_reads; l.n_refs = n_refs; l.alpha = alpha; l.sim = d_sim; l.zero_sim = zero_sim; l.st = st;
         l.n_waves = grid * (SCAN_WG / 64);
+        l.own_total = n_own;
+    } else {
+        c->last.own_total += n_own;         // a later chunk of a stream: the update counter keeps accumulating
+        c->last.binned = false;             // and the pass stored in `last` can no longer be repeated on its own
     }
     return LIME_OK;
 }
@@ -424,10 +434,13 @@ extern "C" int lime_fused_dev(lime_ctx *c, const uint32_t *d_lcp, const uint32_t
                           (hipStream_t)stream);
 }
 
-static int read_stats(lime_ctx *c, lime_stats_t *s, hipStream_t st)
+static int read_stats(lime_ctx *c, lime_stats_t *s, hipStream_t st, uint32_t *sticky = nullptr)
 {
-    HIP_TRY(hipMemcpyAsync(s, c->d_stats, sizeof *s, hipMemcpyDeviceToHost, st));
+    struct { lime_stats_t s; uint32_t sticky[4]; } h;
+    HIP_TRY(hipMemcpyAsync(&h, c->d_stats, sizeof(lime_stats_t) + 4, hipMemcpyDeviceToHost, st));
     HIP_TRY(hipStreamSynchronize(st));
+    *s = h.s;
+    if (sticky) *sticky = h.sticky[0];
     return LIME_OK;
 }
 
@@ -436,7 +449,17 @@ extern "C" int lime_get_stats(lime_ctx *c, lime_stats_t *out, void *stream)
     int rc = check_ctx(c, "lime_get_stats"); if (rc) return rc;
     hipStream_t st = (hipStream_t)stream;
     lime_stats_t s;
-    if ((rc = read_stats(c, &s, st))) return rc;
+    uint32_t unsettled = 0;
+    if ((rc = read_stats(c, &s, st, &unsettled))) return rc;
+    // A pass EARLIER than the last one overflowed its record pool and no lime_get_stats came before the next pass
+    // (every pass clears the flags; the sticky word survives): that pass's table is short and cannot be repaired now.
+    if (unsettled > ((s.flags & LIME_FLAG_POOL_FULL) ? 1u : 0u)) {
+        HIP_TRY(hipMemsetAsync(c->d_sticky, 0, 4, st));
+        if (out) *out = s;
+        return fail(LIME_ERR_NOMEM, "an earlier lime_fused_dev pass on this ctx overflowed its update record pool and was followed by another "
+                                    "pass before lime_get_stats: that pass's table is incomplete (call lime_get_stats after every pass)");
+    }
+    if (unsettled) HIP_TRY(hipMemsetAsync(c->d_sticky, 0, 4, st));
     // binned table updates: the record pool was too small for this pass -> the table is incomplete.  The pass
     // told how many records its busiest wave produced: repeat it with a pool sized for that (the caller's arrays
     // are still in place: nothing was reported to it yet), at most twice; then on the compare-and-swap path.
@@ -451,9 +474,10 @@ extern "C" int lime_get_stats(lime_ctx *c, lime_stats_t *out, void *stream)
                             false, l.st);
         c->timing = timing; c->upd_pref = pref;
         if (rc) return rc;
-        if ((rc = read_stats(c, &s, l.st))) return rc;
+        if ((rc = read_stats(c, &s, l.st, &unsettled))) return rc;
+        if (unsettled) HIP_TRY(hipMemsetAsync(c->d_sticky, 0, 4, l.st));        // settled here (or reported through the flags below)
     }
-    if (l.valid && l.n_own) { c->density = (double)s.n_updates / (double)l.n_own; c->density_known = true; }
+    if (l.valid && l.own_total) { c->density = (double)s.n_updates / (double)l.own_total; c->density_known = true; }
     if (out) *out = s;
     if (c->big_cap && s.n_big > c->big_cap)
         return fail(LIME_ERR_NOMEM, "more clusters longer than %u symbols (%u) than the list holds (%u)", SMALL_MAX, s.n_big, c->big_cap);
@@ -797,7 +821,8 @@ extern "C" int lime_fused_stream(lime_ctx *c, const uint32_t *lcp, const uint32_
         HIP_TRY(hipEventRecord(pp.copied[b], pp.copy));
         HIP_TRY(hipStreamWaitEvent(pp.comp, pp.copied[b], 0));
         rc = fused_dev_impl(c, (const uint32_t *)dl[b].p, (const uint32_t *)dd[b].p, ebwt ? (const uint8_t *)de[b].p : nullptr,
-                            own, avail, eof, n_reads, n_refs, alpha, (uint8_t *)ds.p, k == 0, k != 0, pp.comp, (uint32_t *)dedge.p + k);
+                            own, avail, eof, n_reads, n_refs, alpha, (uint8_t *)ds.p, k == 0, k != 0, pp.comp, (uint32_t *)dedge.p + k,
+                            n_chunks > 1);
         if (rc) { (void)hipDeviceSynchronize(); return rc; }
         HIP_TRY(hipEventRecord(pp.consumed[b], pp.comp));
     }

@@ -62,6 +62,7 @@ struct ScanArgs {
     uint32_t *tile_cnt; uint64_t *tile_off; CrossRec *cross; lime_cluster_t *out;   // detect only
     WinMasks *wmask;                             // detect only: count pass -> emit pass
     uint32_t *edge;                              // LIME_EDGE_* word of this shard (default: &stats->edge)
+    uint32_t *sticky;                            // passes whose record pool overflowed and that lime_get_stats has not settled yet (never cleared by a pass)
     int ablate;                                  // timing experiments only (LIME_ABLATE_BUILD): 0 = full kernel
     // binned table updates (upd_mode 1; 0 = compare-and-swap on the table)
     int upd_mode;

@@ -17,6 +17,7 @@
 // modulo 256 like the reference's unsigned char.
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <atomic>
 #include "lime_device.h"
 #include "lime_kernels.h"
 
@@ -69,6 +70,10 @@ struct alignas(16) WaveLds {
 #define PT_DECL uint64_t pt_t = __builtin_readcyclecounter(), pt_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0}, pt_m[4] = {0, 0, 0, 0}; uint32_t pt_nwin = 0;
 #define PT(i) { const uint64_t n_ = __builtin_readcyclecounter(); pt_acc[i] += n_ - pt_t; pt_t = n_; }
 #define PT_WAITVM asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#elif defined(LIME_MARK)     // ISA reading aid: phase borders as comments in the assembly (tools/isa_count.py)
+#define PT_DECL
+#define PT(i) asm volatile("; LIMEMARK " #i);
+#define PT_WAITVM
 #else
 #define PT_DECL
 #define PT(i)
@@ -952,7 +957,10 @@ __global__ __launch_bounds__(SCANK_WG) __attribute__((amdgpu_waves_per_eu(ScanCf
         if (lane == 0) {
             a.wave_cnt[wave_gid] = qu.out_n < a.cap_w ? qu.out_n : a.cap_w;
             atomicMax(&a.stats->wave_records_max, qu.out_n);
-            if (qu.out_n > a.cap_w) atomicOr(&a.stats->flags, LIME_FLAG_POOL_FULL);
+            if (qu.out_n > a.cap_w) {                          // the pass's first overflow also counts the pass as unsettled
+                const uint32_t old = atomicOr(&a.stats->flags, LIME_FLAG_POOL_FULL);
+                if (!(old & LIME_FLAG_POOL_FULL)) atomicAdd(a.sticky, 1u);
+            }
         }
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
         uint32_t old = 0;
@@ -1862,10 +1870,16 @@ template <typename K> static uint32_t resident_blocks(K kernel, int block)
 }
 
 // ID: one per instantiation of k_scan (they share one function type, so K alone would share the static)
+// per-device caches of the launch wrappers (one process may drive several GPUs from several host threads)
+constexpr int MAX_DEV = 64;
+static int cur_device() { int d = 0; (void)hipGetDevice(&d); return d >= 0 && d < MAX_DEV ? d : 0; }
+
 template <int ID, typename K> static uint32_t scan_grid_of(K kernel, uint32_t n_tiles, uint32_t max_blocks)
 {
-    static uint32_t resident = 0;
-    if (!resident) resident = resident_blocks(kernel, SCANK_WG);
+    static std::atomic<uint32_t> resident_of[MAX_DEV];
+    std::atomic<uint32_t> &slot = resident_of[cur_device()];
+    uint32_t resident = slot.load(std::memory_order_relaxed);
+    if (!resident) { resident = resident_blocks(kernel, SCANK_WG); slot.store(resident, std::memory_order_relaxed); }
     const uint32_t want = (n_tiles + SCANK_WG / 64 - 1) / (SCANK_WG / 64), cap = max_blocks ? max_blocks : resident;
     const uint32_t grid = want < cap ? want : cap;
     return grid ? grid : 1u;
@@ -1891,10 +1905,11 @@ void launch_bin_rowscan(uint32_t *counts, uint32_t *totals, uint32_t n_bins, uin
 
 void launch_part(const ScanArgs &a, uint32_t n_prod, const uint64_t *binbase, uint32_t *out, hipStream_t st)
 {
-    static bool attr_set = false;
-    if (!attr_set) {
+    static std::atomic<bool> attr_set[MAX_DEV];              // the attribute is per device
+    std::atomic<bool> &set = attr_set[cur_device()];
+    if (!set.load(std::memory_order_relaxed)) {
         (void)hipFuncSetAttribute(reinterpret_cast<const void *>(k_part), hipFuncAttributeMaxDynamicSharedMemorySize, (int)(BIN_MAX * 12u));
-        attr_set = true;
+        set.store(true, std::memory_order_relaxed);
     }
     hipLaunchKernelGGL(k_part, dim3(n_prod), dim3(PART_WG), (size_t)a.n_bins * 12u, st, a, binbase, out);
 }

@@ -1,0 +1,162 @@
+// tools/load_bench.hip -- microbenchmark of the scan's window load patterns on MI355X (not product code).
+// Persistent waves, one 1024-position window of lcp + da (u32) per wave and step, the next window's loads in
+// flight while the current one is "consumed" (xor + ballot so nothing is optimised away).  Prints GB/s per pattern.
+//   A  lane-strided dword loads (the scan's layout: register j of lane l = position 64 j + l), non-temporal
+//   B  lcp: every lane its own 16 consecutive positions as 4 x dwordx4; da as in A
+//   C  both arrays as per-lane 4 x dwordx4
+//   D  coalesced dwordx4 (lane l = positions 4 l .. 4 l + 3 of a 256-position block)
+//   E  A with two windows in flight
+//   F  plain grid-stride dwordx4 kernel, no persistence (the chip's read rate)
+// build: hipcc -O3 --offload-arch=gfx950 tools/load_bench.hip -o tools/load_bench
+#include <hip/hip_runtime.h>
+#include <stdio.h>
+#include <stdint.h>
+#include <stdlib.h>
+#define CK(x) do { hipError_t e = (x); if (e != hipSuccess) { printf("%s: %s\n", #x, hipGetErrorString(e)); exit(1);} } while (0)
+
+constexpr uint32_t WIN = 1024;
+typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+
+template <int PAT> struct Regs { uint32_t l[16], d[16]; };
+
+template <int PAT>
+__device__ __forceinline__ void load_win(Regs<PAT> &r, const uint32_t *lcp, const uint32_t *da, uint64_t lo, uint32_t lane)
+{
+    if (PAT == 0 || PAT == 4) {
+        const uint32_t *lp = lcp + lo + lane, *dp = da + lo + lane;
+#pragma unroll
+        for (int j = 0; j < 16; ++j) { r.l[j] = __builtin_nontemporal_load(lp + 64 * j); r.d[j] = __builtin_nontemporal_load(dp + 64 * j); }
+    } else if (PAT == 1) {
+        const u32x4 *lp = reinterpret_cast<const u32x4 *>(lcp + lo + 16u * lane);
+        const uint32_t *dp = da + lo + lane;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) { const u32x4 v = __builtin_nontemporal_load(lp + j); r.l[4 * j] = v.x; r.l[4 * j + 1] = v.y; r.l[4 * j + 2] = v.z; r.l[4 * j + 3] = v.w; }
+#pragma unroll
+        for (int j = 0; j < 16; ++j) r.d[j] = __builtin_nontemporal_load(dp + 64 * j);
+    } else if (PAT == 2) {
+        const u32x4 *lp = reinterpret_cast<const u32x4 *>(lcp + lo + 16u * lane), *dp = reinterpret_cast<const u32x4 *>(da + lo + 16u * lane);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const u32x4 v = __builtin_nontemporal_load(lp + j), w = __builtin_nontemporal_load(dp + j);
+            r.l[4 * j] = v.x; r.l[4 * j + 1] = v.y; r.l[4 * j + 2] = v.z; r.l[4 * j + 3] = v.w;
+            r.d[4 * j] = w.x; r.d[4 * j + 1] = w.y; r.d[4 * j + 2] = w.z; r.d[4 * j + 3] = w.w;
+        }
+    } else {
+        const u32x4 *lp = reinterpret_cast<const u32x4 *>(lcp + lo) + lane, *dp = reinterpret_cast<const u32x4 *>(da + lo) + lane;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const u32x4 v = __builtin_nontemporal_load(lp + 64 * j), w = __builtin_nontemporal_load(dp + 64 * j);
+            r.l[4 * j] = v.x; r.l[4 * j + 1] = v.y; r.l[4 * j + 2] = v.z; r.l[4 * j + 3] = v.w;
+            r.d[4 * j] = w.x; r.d[4 * j + 1] = w.y; r.d[4 * j + 2] = w.z; r.d[4 * j + 3] = w.w;
+        }
+    }
+}
+
+template <int PAT> __device__ __forceinline__ uint32_t consume(const Regs<PAT> &r, uint32_t alpha)
+{
+    uint32_t acc = 0;
+#pragma unroll
+    for (int j = 0; j < 16; ++j) { acc += (uint32_t)__popcll(__ballot(r.l[j] < alpha)); acc ^= r.d[j]; }
+    return acc;
+}
+
+// LDSKB: static LDS per workgroup, to pin the number of resident workgroups per CU like the scan (48 KB -> 3)
+template <int PAT, int LDSKB>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))) void k_win(const uint32_t *lcp, const uint32_t *da, uint32_t n_win, uint32_t alpha, uint32_t *out)
+{
+    __shared__ uint32_t pad[LDSKB * 256];
+    const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
+    if (alpha == 0xFFFFFFFFu) pad[threadIdx.x] = lane;            // never: keeps the array
+    const uint32_t stride = gridDim.x * 4u;
+    uint32_t win = blockIdx.x * 4u + wave, acc = 0;
+    if (win >= n_win) return;
+    Regs<PAT> a, b;
+    load_win<PAT>(a, lcp, da, (uint64_t)win * WIN, lane);
+    if (PAT == 4) {
+        uint32_t w2 = win + stride;
+        if (w2 < n_win) load_win<PAT>(b, lcp, da, (uint64_t)w2 * WIN, lane);
+        for (;;) {
+            acc += consume<PAT>(a, alpha);
+            const uint32_t w3 = w2 + stride;
+            if (w2 >= n_win) break;
+            if (w3 < n_win) load_win<PAT>(a, lcp, da, (uint64_t)w3 * WIN, lane);
+            acc += consume<PAT>(b, alpha);
+            const uint32_t w4 = w3 + stride;
+            if (w3 >= n_win) break;
+            if (w4 < n_win) load_win<PAT>(b, lcp, da, (uint64_t)w4 * WIN, lane);
+            w2 = w4;
+        }
+    } else {
+        for (;;) {
+            Regs<PAT> cur = a;
+            const uint32_t next = win + stride;
+            // the scan issues the next window's loads after the current registers have been staged: same here
+            uint32_t part = consume<PAT>(cur, alpha);
+            if (next < n_win) load_win<PAT>(a, lcp, da, (uint64_t)next * WIN, lane);
+            acc += part;
+            if (next >= n_win) break;
+            win = next;
+        }
+    }
+    if (acc == 0x12345678u || alpha == 0xFFFFFFFFu) out[0] = acc + pad[lane];
+}
+
+__global__ __launch_bounds__(256) void k_plain(const u32x4 *lcp, const u32x4 *da, uint64_t n4, uint32_t *out)
+{
+    uint32_t acc = 0;
+    const uint64_t stride = (uint64_t)gridDim.x * 256u;
+    for (uint64_t i = (uint64_t)blockIdx.x * 256u + threadIdx.x; i < n4; i += stride) {
+        const u32x4 v = __builtin_nontemporal_load(lcp + i), w = __builtin_nontemporal_load(da + i);
+        acc ^= v.x ^ v.y ^ v.z ^ v.w ^ w.x ^ w.y ^ w.z ^ w.w;
+    }
+    if (acc == 0x12345678u) out[0] = acc;
+}
+
+__global__ void k_fill(uint32_t *p, uint64_t n, uint32_t seed)
+{
+    const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
+    for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) p[i] = (uint32_t)(i * 2654435761u + seed) >> 8;
+}
+
+template <typename F> static void timeit(const char *name, uint64_t bytes, F launch)
+{
+    hipEvent_t a, b; CK(hipEventCreate(&a)); CK(hipEventCreate(&b));
+    launch(); CK(hipDeviceSynchronize());
+    float best = 1e30f, sum = 0;
+    const int R = 5;
+    for (int r = 0; r < R; ++r) {
+        CK(hipEventRecord(a)); launch(); CK(hipEventRecord(b)); CK(hipEventSynchronize(b));
+        float ms; CK(hipEventElapsedTime(&ms, a, b)); if (ms < best) best = ms; sum += ms;
+    }
+    printf("%-44s best %7.3f ms  avg %7.3f ms  %7.1f GB/s (best)\n", name, best, sum / R, bytes / best / 1e6);
+    fflush(stdout);
+}
+
+int main(int argc, char **argv)
+{
+    const uint64_t n = argc > 1 ? strtoull(argv[1], 0, 10) : 1000000000ull;
+    const uint32_t n_win = (uint32_t)(n / WIN);
+    const uint64_t nn = (uint64_t)n_win * WIN;
+    uint32_t *lcp, *da, *out;
+    CK(hipMalloc(&lcp, nn * 4 + 64)); CK(hipMalloc(&da, nn * 4 + 64)); CK(hipMalloc(&out, 64));
+    hipLaunchKernelGGL(k_fill, dim3(4096), dim3(256), 0, 0, lcp, nn, 1u);
+    hipLaunchKernelGGL(k_fill, dim3(4096), dim3(256), 0, 0, da, nn, 7u);
+    CK(hipDeviceSynchronize());
+    hipDeviceProp_t prop; CK(hipGetDeviceProperties(&prop, 0));
+    const uint32_t cus = (uint32_t)prop.multiProcessorCount;
+    printf("device %s, %u CUs, N = %llu symbols (%.1f GB read per launch)\n", prop.name, cus, (unsigned long long)nn, nn * 8 / 1e9);
+    const uint64_t bytes = nn * 8;
+    const dim3 g3(cus * 3), g2(cus * 2), g4(cus * 4), blk(256);
+    timeit("A lane-strided dword, 3 WG/CU", bytes, [&] { hipLaunchKernelGGL((k_win<0, 48>), g3, blk, 0, 0, lcp, da, n_win, 16u, out); });
+    timeit("B lcp per-lane 4x dwordx4, da strided, 3 WG/CU", bytes, [&] { hipLaunchKernelGGL((k_win<1, 48>), g3, blk, 0, 0, lcp, da, n_win, 16u, out); });
+    timeit("C both per-lane 4x dwordx4, 3 WG/CU", bytes, [&] { hipLaunchKernelGGL((k_win<2, 48>), g3, blk, 0, 0, lcp, da, n_win, 16u, out); });
+    timeit("D coalesced dwordx4, 3 WG/CU", bytes, [&] { hipLaunchKernelGGL((k_win<3, 48>), g3, blk, 0, 0, lcp, da, n_win, 16u, out); });
+    timeit("E lane-strided dword, 2 windows in flight, 3 WG/CU", bytes, [&] { hipLaunchKernelGGL((k_win<4, 48>), g3, blk, 0, 0, lcp, da, n_win, 16u, out); });
+    timeit("A lane-strided dword, 4 WG/CU", bytes, [&] { hipLaunchKernelGGL((k_win<0, 36>), g4, blk, 0, 0, lcp, da, n_win, 16u, out); });
+    timeit("A lane-strided dword, 2 WG/CU", bytes, [&] { hipLaunchKernelGGL((k_win<0, 72>), g2, blk, 0, 0, lcp, da, n_win, 16u, out); });
+    timeit("C both per-lane 4x dwordx4, 4 WG/CU", bytes, [&] { hipLaunchKernelGGL((k_win<2, 36>), g4, blk, 0, 0, lcp, da, n_win, 16u, out); });
+    timeit("E 2 windows in flight, 2 WG/CU", bytes, [&] { hipLaunchKernelGGL((k_win<4, 72>), g2, blk, 0, 0, lcp, da, n_win, 16u, out); });
+    timeit("F plain grid-stride dwordx4 (16384 WGs)", bytes, [&] { hipLaunchKernelGGL(k_plain, dim3(16384), blk, 0, 0, (const u32x4 *)lcp, (const u32x4 *)da, nn / 4, out); });
+    timeit("F plain grid-stride dwordx4 (2048 WGs)", bytes, [&] { hipLaunchKernelGGL(k_plain, dim3(2048), blk, 0, 0, (const u32x4 *)lcp, (const u32x4 *)da, nn / 4, out); });
+    return 0;
+}
