@@ -374,7 +374,7 @@ static int fused_dev_impl(lime_ctx *c, const uint32_t *d_lcp, const uint32_t *d_
                 while (bin_shift < REGION_SHIFT + 6 && bin_shift < BIN_SHIFT_MAX && bins_at(bin_shift + 1) >= 256) ++bin_shift;
         }
         n_bins = (uint32_t)bins_at(bin_shift);           // <= BIN_MAX: want_binned checked the table size
-        if ((rc = ensure_binned(c, n_own, grid * (SCAN_WG / 64), grid, n_bins, bin_shift, &cap_w, st))) return rc;
+        if ((rc = ensure_binned(c, n_own, grid * scan_waves_per_wg(ebwt, 0), grid, n_bins, bin_shift, &cap_w, st))) return rc;
     }
     if ((rc = timing_mark(c, st))) return rc;
     if (keep_stats) {
@@ -388,7 +388,7 @@ static int fused_dev_impl(lime_ctx *c, const uint32_t *d_lcp, const uint32_t *d_
     if (d_edge) a.edge = d_edge;                          // a chunk of a stream: its own (cleared) word
     if (binned) {
         a.upd_mode = 1; a.pool = c->d_pool; a.cap_w = cap_w; a.wave_cnt = c->d_wave_cnt; a.counts = c->d_counts;
-        a.n_bins = n_bins; a.bin_shift = bin_shift;
+        a.n_bins = n_bins; a.bin_shift = bin_shift; a.prod_waves = scan_waves_per_wg(ebwt, 0);
     }
     if ((rc = timing_mark(c, st))) return rc;
     launch_tile(ebwt, 0, a, c->max_blocks, st);
@@ -416,7 +416,7 @@ static int fused_dev_impl(lime_ctx *c, const uint32_t *d_lcp, const uint32_t *d_
         lime_ctx::Last &l = c->last;
         l.valid = true; l.binned = binned; l.lcp = d_lcp; l.da = d_da; l.ebwt = d_ebwt; l.n_own = n_own; l.n_avail = n_avail;
         l.eof = eof; l.n_reads = n_reads; l.n_refs = n_refs; l.alpha = alpha; l.sim = d_sim; l.zero_sim = zero_sim; l.st = st;
-        l.n_waves = grid * (SCAN_WG / 64);
+        l.n_waves = grid * scan_waves_per_wg(ebwt, 0);
         l.own_total = n_own;
     } else {
         c->last.own_total += n_own;         // a later chunk of a stream: the update counter keeps accumulating
@@ -1215,6 +1215,16 @@ extern "C" int lime_score_choose_multi(int n_dev, const int *devices, const uint
     cleanup();
     return rc ? fail(rc, "%s", err.c_str()) : LIME_OK;
 }
+
+#ifdef LIME_DEBUG_CNT
+// debug builds only: the per-window counts of accepted clusters the last scan left (see k_scan)
+extern "C" int lime_debug_tile_counts(lime_ctx *c, uint32_t *out, uint32_t n)
+{
+    HIP_TRY(hipDeviceSynchronize());
+    HIP_TRY(hipMemcpy(out, c->d_tile_cnt, (size_t)n * 4, hipMemcpyDeviceToHost));
+    return LIME_OK;
+}
+#endif
 
 // ---- pure host helpers ------------------------------------------------------------------
 extern "C" uint8_t lime_sym_index(uint8_t b) { return (uint8_t)sym_index(b); }

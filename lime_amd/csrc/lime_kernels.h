@@ -12,7 +12,21 @@ constexpr uint32_t PPL = WIN / 64;           // consecutive positions per lane (
 constexpr uint32_t NW = WIN / 64;            // 64-bit mask words per window
 constexpr uint32_t HALO = 16;                // read-ahead positions behind a window (>= SMALL_MAX)
 constexpr uint32_t WPOS = WIN + HALO;
-constexpr int SCAN_WG = 256;                 // 4 independent waves per workgroup of the scan kernels
+constexpr int SCAN_WG = 256;                 // 4 independent waves per workgroup of k_score_list
+// k_scan: threads per workgroup (its waves work independently: the workgroup only shares lookup tables and the binned
+// path's histogram) and waves per SIMD it is compiled for.  The scan is bound by the latency of each wave's chain of
+// dependent steps, so waves per SIMD count (measured, configs[2]: 2 -> 2.94 ms, 3 -> 1.90 ms): without ebwt the window
+// state fits 8 waves x 2 workgroups per CU (<= 128 VGPRs, <= 80 KB of LDS per workgroup); with ebwt it stays at 3 x 4.
+#ifndef LIME_SCAN_WG0
+#define LIME_SCAN_WG0 512
+#define LIME_SCAN_WAVES0 4
+#endif
+#ifndef LIME_SCAN_WG1
+#define LIME_SCAN_WG1 256
+#define LIME_SCAN_WAVES1 3
+#endif
+template <int EBWT> struct ScanCfg { static constexpr int wg = EBWT ? LIME_SCAN_WG1 : LIME_SCAN_WG0, waves = EBWT ? LIME_SCAN_WAVES1 : LIME_SCAN_WAVES0; };
+inline uint32_t scan_waves_per_wg(int ebwt, int mode) { return (uint32_t)((ebwt && mode == 0 ? ScanCfg<1>::wg : ScanCfg<0>::wg) / 64); }
 constexpr int WGSZ = 512;                    // workgroup of the helper kernels (big clusters, choose, synth)
 constexpr uint32_t SMALL_MAX = 16;           // longest cluster scored inside a window
 constexpr uint32_t NONE32 = 0xFFFFFFFFu;
@@ -68,6 +82,7 @@ struct ScanArgs {
     int upd_mode;
     uint64_t *pool; uint32_t cap_w;              // records of wave w: pool[w * cap_w ..), at most cap_w
     uint32_t *wave_cnt;                          // records wave w wrote
+    uint32_t prod_waves;                         // waves per workgroup of the scan that made them
     uint32_t *counts;                            // [n_bins][gridDim.x]: records of bin b counted by workgroup p
     uint32_t n_bins, bin_shift;                  // bin of a cell = cell >> bin_shift
 };

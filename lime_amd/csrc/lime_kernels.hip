@@ -81,24 +81,32 @@ struct alignas(16) WaveLds {
 #endif
 
 // LDS of one wave of k_scan (kept small: it bounds the waves a CU holds)
-#ifndef LIME_SCANK_WG
-#define LIME_SCANK_WG 256
-#endif
-#ifndef LIME_SCAN_WAVES
-#define LIME_SCAN_WAVES 3
-#endif
-constexpr int SCANK_WG = LIME_SCANK_WG;   // threads per workgroup of k_scan; its waves work independently
+// threads per workgroup of k_scan (its waves work independently) and waves per SIMD it is compiled for: ScanCfg in
+// lime_kernels.h (EBWT = 0: 8 waves, two workgroups per CU = 4 waves per SIMD; EBWT = 1: 4 waves, three workgroups)
 constexpr uint32_t DUP_SLOTS = 8;     // clusters with a repeated document a wave of k_scan holds before scoring them
 constexpr uint32_t QCAP_SCAN = 256;   // >= the 256 hits one batch of 64 clusters of <= 4 symbols can add
 
 __device__ __forceinline__ uint32_t lane_id() { return threadIdx.x & 63u; }
 __device__ __forceinline__ uint64_t brev64(uint64_t x) { return __builtin_bitreverse64(x); }
 __device__ __forceinline__ uint32_t rl32(uint32_t v, uint32_t l) { return (uint32_t)__builtin_amdgcn_readlane((int)v, (int)l); }
-// v with lane L replaced by the wave-uniform value s
+// v with lane L replaced by the wave-uniform value s (this compiler has no v_writelane builtin).  On gfx940/gfx950 a
+// vector instruction that reads an SGPR / VCC written by the vector instruction just before it -- here the v_cmp whose
+// ballot is s -- needs two wait states.  The compiler's hazard recognizer inserts them for instructions it knows; inline
+// assembly is opaque to it, and whenever the scheduler happened to put a bare `v_writelane` right behind its v_cmp it read
+// the PREVIOUS ballot: round 2's "wrong cluster counts" of the build with the runtime update-path flag, and round 3's of the
+// first lean EBWT=1 binned scan (`v_cmp_gt_u32 vcc, ..` / `v_writelane_b32 v2, vcc_lo, 1` back to back).
+// So the wait states are part of the assembly: `s_nop 1` (two wait states) in front, and the four writes of a mask word
+// share one statement and one nop.
 template <int L> __device__ __forceinline__ uint32_t write_lane(uint32_t v, uint32_t s)
 {
-    asm("v_writelane_b32 %0, %1, %2" : "+v"(v) : "s"(s), "n"(L));
+    asm("s_nop 1\n\tv_writelane_b32 %0, %1, %2" : "+v"(v) : "s"(s), "n"(L));
     return v;
+}
+template <int L> __device__ __forceinline__ void write_lane4(uint32_t &v0, uint32_t &v1, uint32_t &v2, uint32_t &v3,
+                                                            uint32_t s0, uint32_t s1, uint32_t s2, uint32_t s3)
+{
+    asm("s_nop 1\n\tv_writelane_b32 %0, %4, %8\n\tv_writelane_b32 %1, %5, %8\n\tv_writelane_b32 %2, %6, %8\n\tv_writelane_b32 %3, %7, %8"
+        : "+v"(v0), "+v"(v1), "+v"(v2), "+v"(v3) : "s"(s0), "s"(s1), "s"(s2), "s"(s3), "n"(L));
 }
 __device__ __forceinline__ uint64_t rl64(uint64_t v, uint32_t l)
 {
@@ -107,6 +115,19 @@ __device__ __forceinline__ uint64_t rl64(uint64_t v, uint32_t l)
 __device__ __forceinline__ uint64_t shfl64(uint64_t v, int l)
 {
     return ((uint64_t)(uint32_t)__shfl((int)(v >> 32), l) << 32) | (uint32_t)__shfl((int)(uint32_t)v, l);
+}
+// number of set bits of the wave mask m in lanes below this one (v_mbcnt_lo/hi: two instructions)
+__device__ __forceinline__ uint32_t rank_in(uint64_t m)
+{
+    return __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u));
+}
+// 32 mask bits starting at bit `pos` of a bit array in LDS (8-byte aligned, at least (pos >> 5) + 2 words long):
+// two aligned words and one v_alignbit
+typedef uint32_t __attribute__((may_alias)) u32a;
+__device__ __forceinline__ uint32_t bits_at(const uint8_t *bits, uint32_t pos)
+{
+    const u32a *w = reinterpret_cast<const u32a *>(bits) + (pos >> 5);
+    return __builtin_amdgcn_alignbit(w[1], w[0], pos & 31u);
 }
 __device__ __forceinline__ uint32_t wave_sum(uint32_t v)
 {
@@ -138,7 +159,10 @@ __device__ __forceinline__ uint32_t wave_incl_scan(uint32_t v)
 // pairlut[rmask | (len-1) << 4] for a cluster of len = 2..4 symbols with read bits rmask: bit k = position
 // pair k of (0,1)(0,2)(0,3)(1,2)(1,3)(2,3) joins a read with a genome inside the cluster, bit 8+k =
 // the pair's FIRST position is the read
-struct WgTables { uint8_t symidx[256]; uint16_t compat[16]; uint16_t pairlut[64]; uint16_t compatb[256]; };   // compatb[byte] = compat[symidx[byte]]
+// pairs[rmask | (len-1) << 4]: the read x genome pairs of a cluster of len = 2..4 symbols with read bits rmask, as a
+// list of up to four slots of 7 bits (read position | genome position << 2 | number of the position pair << 4) and
+// their count in bits 28..30
+struct WgTables { uint8_t symidx[256]; uint16_t compat[16]; uint16_t pairlut[64]; uint16_t compatb[256]; uint32_t pairs[64]; };   // compatb[byte] = compat[symidx[byte]]
 
 __device__ __forceinline__ void tables_init(WgTables &T)
 {
@@ -164,6 +188,14 @@ __device__ __forceinline__ void tables_init(WgTables &T)
                 v |= ri << (8u + k);
             }
         T.pairlut[e] = (uint16_t)v;
+        uint32_t pv = 0, np = 0;
+        k = 0;
+        for (uint32_t i = 0; i < 4u; ++i)
+            for (uint32_t j = i + 1u; j < 4u; ++j, ++k) {
+                const uint32_t ri = (r >> i) & 1u, rj = (r >> j) & 1u, gi = (g >> i) & 1u, gj = (g >> j) & 1u;
+                if ((ri & gj) | (gi & rj)) { pv |= ((ri ? i : j) | ((ri ? j : i) << 2) | (k << 4)) << (7u * np); ++np; }
+            }
+        T.pairs[e] = pv | (np << 28);
     }
     __syncthreads();
 }
@@ -195,6 +227,7 @@ struct UpdQueue { uint32_t *qr, *qg; uint32_t n, cap;
     bool async = false;
     uint32_t *fr = nullptr, *fg = nullptr, *fe = nullptr;   // entry (read, genome | t) and the word value its CAS expected
     uint32_t f_old[4], f_pend = 0;               // f_pend: bit j = slot j occupied, bit 4+j = its word was only LOADED so far
+    uint32_t nj = 4;                             // in-flight slots per lane (a constant of the kernel: 4, or 2 where LDS is short)
     // dense tables: once 1 in 4 of the first tries (which expect an empty word) has lost, new entries first load
     // their word (a load is much cheaper than a lost compare-and-swap) and try with what they saw one drain later
     uint32_t f_first = 0, f_lost = 0; bool load_first = false;
@@ -217,6 +250,7 @@ __device__ __forceinline__ void drain_async(UpdQueue &q, const ScanArgs &a)
     const uint64_t lt = (1ull << lane) - 1ull;
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
+        if ((uint32_t)j >= q.nj) break;
         const bool pend = (q.f_pend >> j) & 1u, fresh = (q.f_pend >> (4 + j)) & 1u;
         const uint32_t e = pend ? q.fe[64u * (uint32_t)j + lane] : 0u;
         const bool tried = pend && !fresh, lost = tried && q.f_old[j] != e;
@@ -231,14 +265,19 @@ __device__ __forceinline__ void drain_async(UpdQueue &q, const ScanArgs &a)
     uint32_t n = q.n;
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
+        if ((uint32_t)j >= q.nj) break;
         const bool fre = !((q.f_pend >> j) & 1u);
         const uint64_t m = __ballot(fre);
         const uint32_t r = (uint32_t)__popcll(m & lt), c = (uint32_t)__popcll(m);
         if (fre && r < n) {
             const uint32_t k = n - 1u - r;
-            q.fr[64u * (uint32_t)j + lane] = q.qr[k]; q.fg[64u * (uint32_t)j + lane] = q.qg[k];
-            q.fe[64u * (uint32_t)j + lane] = 0u;
-            q.f_pend |= (q.load_first ? 17u : 1u) << j;
+            const uint32_t gt = q.qg[k];
+            if ((gt & ((1u << T_SHIFT) - 1u)) >= a.n_refs) atomicOr(&a.stats->flags, LIME_FLAG_DOCID);   // dropped: see drain_bin
+            else {
+                q.fr[64u * (uint32_t)j + lane] = q.qr[k]; q.fg[64u * (uint32_t)j + lane] = gt;
+                q.fe[64u * (uint32_t)j + lane] = 0u;
+                q.f_pend |= (q.load_first ? 17u : 1u) << j;
+            }
         }
         n -= c < n ? c : n;
     }
@@ -246,7 +285,7 @@ __device__ __forceinline__ void drain_async(UpdQueue &q, const ScanArgs &a)
     if (ABL(5)) { q.f_pend = 0; return; }
 #pragma unroll
     for (int j = 0; j < 4; ++j)
-        if ((q.f_pend >> j) & 1u) {
+        if ((uint32_t)j < q.nj && ((q.f_pend >> j) & 1u)) {
             const uint32_t gt = q.fg[64u * (uint32_t)j + lane];
             const uint64_t cell = (uint64_t)q.fr[64u * (uint32_t)j + lane] * a.n_refs + (gt & ((1u << T_SHIFT) - 1u));
             uint32_t *w = reinterpret_cast<uint32_t *>(a.sim + (cell & ~3ull));
@@ -269,8 +308,13 @@ __device__ __forceinline__ void drain_bin(UpdQueue &q, const ScanArgs &a)
     for (uint32_t k0 = 0; k0 < q.n; k0 += 64u) {
         const uint32_t k = k0 + lane;
         const bool on = k < q.n;
-        const uint32_t gt = q.qg[on ? k : 0u];
-        const uint64_t cell = (uint64_t)q.qr[on ? k : 0u] * a.n_refs + (gt & (MAX_REFS - 1u));
+        uint32_t gt = q.qg[on ? k : 0u], rd = q.qr[on ? k : 0u];
+        // the scan's fast emitters do not look at the document ids: a genome id beyond the table is caught here, on
+        // full waves (the record becomes "cell 0, t = 0", which the later stages skip; the pass fails with LIME_ERR_DOCID)
+        const bool bad = on && (gt & (MAX_REFS - 1u)) >= a.n_refs;
+        if (__ballot(bad)) { if (bad) atomicOr(&a.stats->flags, LIME_FLAG_DOCID); }
+        if (bad) { gt = 0u; rd = 0u; }
+        const uint64_t cell = (uint64_t)rd * a.n_refs + (gt & (MAX_REFS - 1u));
         const uint32_t slot = q.out_n + k;
         if (on && slot < a.cap_w) {
             atomicAdd(&q.hist[(uint32_t)(cell >> a.bin_shift)], 1u);
@@ -763,6 +807,129 @@ __device__ __forceinline__ uint32_t score_medium(LDS &L, const WgTables &T, UpdQ
     return nupd;
 }
 
+
+// =========================================================================================
+// Round 3 back end of the scan: the same results with about a third of the vector instructions.
+// (PMC, configs[2], per 1024-position window, round 2: staging 131, chunk acceptance 82, cluster list 159,
+// 2-4-symbol round 214, rows 212 vector instructions; the six predicated emission blocks of score_small alone
+// compiled to 26 each.)
+// =========================================================================================
+
+// Clusters of 2..4 symbols, one lane per cluster.  The pairs that join a read with a genome come as a LIST from a
+// table indexed by (read bits, length): at most four slots, so the emission is four short blocks with static queue
+// offsets instead of six; the documents of a slot are re-read from the staged window by position (a per-lane
+// register index would cost a select chain).  Documents are not range-checked here: the drains do that on full
+// waves.  Two equal documents (only documents of one kind can be equal: six plain compares, positions past the
+// cluster carry impossible ids) hand the cluster to the wave's repeat store.
+template <int EBWT, typename LDS>
+__device__ __forceinline__ uint32_t score_small3(LDS &L, const WgTables &T, UpdQueue &qu, uint32_t &n_dup, const ScanArgs &a,
+                                                 bool on, uint32_t p, uint32_t len)
+{
+    const uint32_t rmask = bits_at(L.rb, p) & ((1u << len) - 1u);
+    const uint32_t pl = T.pairs[rmask | (((len - 1u) & 3u) << 4)];          // len == 0 (lane off): an entry without pairs
+    uint32_t d[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) d[i] = L.da[p + i];
+    d[2] = len > 2u ? d[2] : 0xFFFFFFFEu;
+    d[3] = len > 3u ? d[3] : 0xFFFFFFFFu;
+    const bool dup = on && ((d[0] == d[1]) | (d[0] == d[2]) | (d[0] == d[3]) | (d[1] == d[2]) | (d[1] == d[3]) | (d[2] == d[3]));
+    const uint32_t nflush = dup_push<EBWT>(L, n_dup, a, T, qu, dup, p, len);
+    const uint32_t np = pl >> 28;
+    uint32_t hits = (1u << np) - 1u;                                          // bit e: slot e of the list scores
+    if (EBWT) {
+        uint32_t sy[4], cs[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) { const uint32_t by = L.fl[p + i]; sy[i] = T.symidx[by]; cs[i] = T.compatb[by]; }
+        uint32_t compat6 = 0;
+        {
+            int pi = 0;
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int j = i + 1; j < 4; ++j, ++pi) compat6 |= ((cs[i] >> sy[j]) & 1u) << pi;
+        }
+        uint32_t h = 0;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) h |= ((compat6 >> ((pl >> (7 * e + 4)) & 7u)) & 1u) << e;
+        hits &= h;
+    }
+    if (dup || !on) hits = 0u;
+    const uint32_t nh = (uint32_t)__popc(hits);
+    const uint32_t incl = wave_incl_scan(nh), total = rl32(incl, 63);
+    while (qu.n + total > qu.cap) drain(qu, a);                               // total <= 4 per lane = 256 <= cap
+    const uint32_t slot0 = qu.n + incl - nh;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+        const bool he = (hits >> e) & 1u;
+        if (e >= 2 && !__ballot(he)) continue;                                // wave-uniform: most rounds have no cluster with 3 or 4 pairs
+        if (he) {
+            const uint32_t rp = (pl >> (7 * e)) & 3u, gp = (pl >> (7 * e + 2)) & 3u;
+            const uint32_t slot = EBWT ? slot0 + (uint32_t)__popc(hits & ((1u << e) - 1u)) : slot0 + (uint32_t)e;
+            qu.qr[slot] = L.da[p + rp];
+            qu.qg[slot] = (L.da[p + gp] - a.n_reads) | (1u << T_SHIFT);
+        }
+    }
+    qu.n += total;
+    return nh + nflush;
+}
+
+// Clusters of 5..SMALL_MAX symbols by ROWS in fixed lane groups: G lanes per cluster (G = 8 for 5..8 symbols, 16 for
+// 9..16), lane i of a group = position i of its cluster -- no prefix sums, no flags in LDS, and all rows of a cluster
+// sit in one pass.  A row compares its document with those of the positions after it (equal: the whole cluster goes to
+// the repeat store -- the group learns it from one ballot) and, if it is of the cluster's MORE COMMON kind, emits its
+// pairs with the elements of the rarer kind, before and after it: the emission loop runs min(reads, genomes) times
+// (usually once) instead of once per partner of a lone read.  `list`: entries position | (len-1) << 12.
+template <int EBWT, int G, typename LDS>
+__device__ __forceinline__ uint32_t score_rows3(LDS &L, const WgTables &T, UpdQueue &qu, uint32_t &n_dup, const ScanArgs &a,
+                                                const uint16_t *list, uint32_t n)
+{
+    constexpr uint32_t LG = G == 8 ? 3u : 4u, PER = 64u / (uint32_t)G;
+    static_assert(G == 8 || G == 16, "groups of 8 or 16 lanes");
+    const uint32_t lane = lane_id(), g = lane >> LG, i = lane & ((uint32_t)G - 1u);
+    uint32_t nupd = 0;
+#pragma unroll 1
+    for (uint32_t c0 = 0; c0 < n; c0 += PER) {
+        const bool valid = c0 + g < n;
+        const uint32_t it = valid ? list[c0 + g] : 0u;                          // one address per group: a broadcast read
+        const uint32_t p = it & 0xFFFu, cl = valid ? (it >> 12) + 1u : 0u;
+        const bool on = i < cl;
+        const uint32_t q = p + i;
+        const uint32_t di = L.da[q];
+        const uint32_t clm = (1u << cl) - 1u;
+        const uint32_t rbc = bits_at(L.rb, p) & clm;                            // the cluster's read bits
+        uint32_t dupb = 0;
+#pragma unroll
+        for (int k = 1; k < G; ++k) dupb |= (uint32_t)(L.da[q + (uint32_t)k] == di) << k;
+        const uint32_t rem = on ? cl - 1u - i : 0u;                             // positions after i in the cluster
+        const uint64_t dm = __ballot(on && (dupb & ((2u << rem) - 2u)));
+        const bool gdup = (uint32_t)(dm >> (lane & ~((uint32_t)G - 1u))) & ((1u << G) - 1u);    // a row of my group met its document again
+        const uint32_t ri = (rbc >> i) & 1u, nr = (uint32_t)__popc(rbc);
+        const bool reads_common = 2u * nr > cl;
+        // rows of the more common kind emit; partners: the elements of the other kind
+        uint32_t partners = (on && !gdup && (ri != 0u) == reads_common) ? (ri ? ~rbc & clm : rbc) : 0u;
+        const uint32_t ci = EBWT ? T.compatb[L.fl[q]] : 0xFFFFu;
+        while (__ballot(partners != 0u)) {
+            const bool act = partners != 0u;
+            const uint32_t k = act ? (uint32_t)__builtin_ctz(partners) : 0u;
+            partners &= partners - 1u;
+            const uint32_t dj = L.da[p + k];
+            bool hit = act;
+            if (EBWT) hit = act && ((ci >> T.symidx[L.fl[p + k]]) & 1u);
+            const uint64_t m = __ballot(hit);
+            while (qu.n + 64u > qu.cap) drain(qu, a);
+            if (hit) {
+                const uint32_t slot = qu.n + rank_in(m);
+                qu.qr[slot] = ri ? di : dj;
+                qu.qg[slot] = ((ri ? dj : di) - a.n_reads) | (1u << T_SHIFT);
+            }
+            qu.n += (uint32_t)__popcll(m);
+            nupd += (uint32_t)hit;
+        }
+        if (dm) nupd += dup_push<EBWT>(L, n_dup, a, T, qu, valid && gdup && i == 0u, p, cl);
+    }
+    return nupd;
+}
+
 // ---- window loads: lane l holds positions 64 j + l (j < PPL) of the window -- every load
 // instruction reads 64 consecutive elements, and the wave ballot of a comparison on register j IS
 // mask word j -- the ebwt bytes 256 k + 4 l .. + 3 (k < PPL/4), and position WIN + l of the
@@ -844,9 +1011,7 @@ struct alignas(16) ScanLdsT {
     // entries at a time and write the list of the clusters of 5..SMALL_MAX symbols (start | (len-1) << 12) over
     // its already consumed head: the k-th such cluster is at most the k-th cluster read.
     uint16_t listM[WIN / 2];
-    uint32_t listX[64];
-    uint16_t m_tstart[64];
-    uint8_t m_flag[64], m_dup[64];
+    uint16_t m_tstart[64];                   // the round's clusters of 9..SMALL_MAX symbols (position | (len-1) << 12)
     uint32_t q_read[QCAP_SCAN], q_gen[QCAP_SCAN];
     uint32_t g_doc[DUP_SLOTS][SMALL_MAX];
     uint8_t g_sym[EBWT ? DUP_SLOTS : 1][SMALL_MAX], g_len[DUP_SLOTS];
@@ -922,18 +1087,19 @@ __device__ __forceinline__ Ctx16 chunk_context(uint32_t h, uint32_t r, uint32_t 
 // waves per SIMD the kernel is compiled for.  (The binned EBWT=0 scan was tried at four -- 128 VGPRs, 39.6 KB of LDS per
 // workgroup with a 1024-bin histogram, no spills: same time as at three, 2.08 vs 2.10 ms on configs[2]; the scan is
 // bound by the vector ALU's issue rate and the memory system together, not by latency a fourth wave would hide.)
-template <int EBWT, int BIN> struct ScanCfg { static constexpr int waves = LIME_SCAN_WAVES; };
 
 template <int EBWT, int MODE, int BIN>
-__global__ __launch_bounds__(SCANK_WG) __attribute__((amdgpu_waves_per_eu(ScanCfg<EBWT, BIN>::waves, ScanCfg<EBWT, BIN>::waves))) void k_scan(ScanArgs a)
+__global__ __launch_bounds__(ScanCfg<EBWT>::wg) __attribute__((amdgpu_waves_per_eu(ScanCfg<EBWT>::waves, ScanCfg<EBWT>::waves))) void k_scan(ScanArgs a)
 {
+    constexpr int SCANK_WG = ScanCfg<EBWT>::wg;
     static_assert(BIN == 0 || MODE == 0, "records are made by the scoring scan only");
     typedef ScanLdsT<EBWT> ScanLds;
     __shared__ ScanLds lds[SCANK_WG / 64];
     __shared__ WgTables T;
-    // per wave the in-flight compare-and-swap slots (entry read, genome | t, expected word: 3 x 256 words); in
-    // binned mode the workgroup's histogram of update records per table bin instead
-    constexpr uint32_t FS = BIN ? BIN_MAX : (SCANK_WG / 64) * 768u;
+    // per wave the in-flight compare-and-swap slots (entry read, genome | t, expected word: 3 x 64 NJ words, NJ slots per
+    // lane: 4, or 2 in the 8-wave workgroup); in binned mode the workgroup's histogram of update records per table bin instead
+    constexpr uint32_t NJ = SCANK_WG > 256 ? 2u : 4u;
+    constexpr uint32_t FS = BIN ? BIN_MAX : (SCANK_WG / 64) * 192u * NJ;
     __shared__ uint32_t fslots[FS];
     __shared__ uint32_t wg_done;
     const uint32_t lane = lane_id(), wave = (uint32_t)__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));   // wave-uniform: LDS bases stay scalar
@@ -948,7 +1114,7 @@ __global__ __launch_bounds__(SCANK_WG) __attribute__((amdgpu_waves_per_eu(ScanCf
     uint32_t win = blockIdx.x * (SCANK_WG / 64) + wave;
     UpdQueue qu; qu.qr = L.q_read; qu.qg = L.q_gen; qu.n = 0; qu.cap = QCAP_SCAN;
     qu.async = true;
-    if (!binned) { qu.fr = fslots + 768u * wave; qu.fg = qu.fr + 256; qu.fe = qu.fr + 512; }
+    if (!binned) { qu.nj = NJ; qu.fr = fslots + 192u * NJ * wave; qu.fg = qu.fr + 64u * NJ; qu.fe = qu.fr + 128u * NJ; }
     const uint32_t wave_gid = blockIdx.x * (SCANK_WG / 64) + wave;
     qu.binned = binned;
     if (binned) { qu.out = a.pool + (size_t)wave_gid * a.cap_w; qu.hist = fslots; }
@@ -994,8 +1160,7 @@ __global__ __launch_bounds__(SCANK_WG) __attribute__((amdgpu_waves_per_eu(ScanCf
             uint32_t hlo = 0, hhi = 0, rlo = 0, rhi = 0;
             static_assert(PPL == 16 && WIN / 64 == 16, "mask words are written lane by lane below");
 #define LIME_WORD(J) { const uint64_t bh = __ballot(regs.lv[J] < a.alpha), br = __ballot(regs.dv[J] < a.n_reads); \
-                       hlo = write_lane<J>(hlo, (uint32_t)bh); hhi = write_lane<J>(hhi, (uint32_t)(bh >> 32)); \
-                       rlo = write_lane<J>(rlo, (uint32_t)br); rhi = write_lane<J>(rhi, (uint32_t)(br >> 32)); }
+                       write_lane4<J>(hlo, hhi, rlo, rhi, (uint32_t)bh, (uint32_t)(bh >> 32), (uint32_t)br, (uint32_t)(br >> 32)); }
             LIME_WORD(0) LIME_WORD(1) LIME_WORD(2) LIME_WORD(3) LIME_WORD(4) LIME_WORD(5) LIME_WORD(6) LIME_WORD(7)
             LIME_WORD(8) LIME_WORD(9) LIME_WORD(10) LIME_WORD(11) LIME_WORD(12) LIME_WORD(13) LIME_WORD(14) LIME_WORD(15)
 #undef LIME_WORD
@@ -1072,101 +1237,102 @@ __global__ __launch_bounds__(SCANK_WG) __attribute__((amdgpu_waves_per_eu(ScanCf
         }
         PT(2)
         if (!ABL(3)) {
-        // ---- every lane lists the accepted clusters of its chunk: slots from a wave prefix sum ---------
+        // ---- the accepted clusters of the window: every lane lists the positions of its chunk's accepted heads at
+        // the slots a wave prefix sum gives it (a short loop over its <= 8 head bits: six vector instructions a turn;
+        // lengths are taken from the staged head bits later, by full waves) --------------------------------------
         const uint32_t cnt = (uint32_t)__popc(c.ah);
-        // heads of 2-symbol clusters: the next head of the chunk is two positions on; the chunk's last head by its segment's end
-        uint32_t m2 = c.ah & ~(c.h >> 1) & (c.h >> 2);
-        {
-            const uint32_t lhb = (c.info >> 5) & 31u;
-            if (MODE == 0 && ((c.ah >> lhb) & 1u) && c.e_suf - (c0 + lhb) == 2u) m2 |= 1u << lhb;
-        }
-        const uint32_t cnt2 = (uint32_t)__popc(m2);
-        // one prefix sum for both lists: 2-symbol clusters in the low half, the others in the high half
-        const uint32_t incl = wave_incl_scan(MODE == 0 ? cnt2 | ((cnt - cnt2) << 16) : cnt);
-        const uint32_t tot2 = rl32(incl, 63);
-        const uint32_t n2 = MODE == 0 ? tot2 & 0xFFFFu : 0u, total = MODE == 0 ? n2 + (tot2 >> 16) : tot2;
+        const uint32_t incl = wave_incl_scan(cnt);
+        const uint32_t total = rl32(incl, 63);
         acc_n += cnt;
+#ifdef LIME_DEBUG_CNT          // debug builds: the window's count of accepted clusters (tools/dbg_golden.py reads it back)
+        if (MODE == 0 && lane == 0) a.tile_cnt[win] = total;
+#endif
         if (MODE == 0) {
             {
-                // the window's list: the 2-symbol clusters first ([0, n2)), then the others
-                uint32_t m = c.ah, k2 = (incl & 0xFFFFu) - cnt2, ko = n2 + (incl >> 16) - (cnt - cnt2);
+                uint32_t m = c.ah, k = incl - cnt;
                 while (__ballot(m != 0u)) {
-                    if (m) {
-                        const uint32_t b = (uint32_t)__builtin_ctz(m);
-                        m &= m - 1u;
-                        const uint32_t p = c0 + b, hi = c.h >> (b + 1u);
-                        const uint32_t e = hi ? p + 1u + (uint32_t)__builtin_ctz(hi) : c.e_suf;
-                        const uint32_t len = e - p;
-                        acc_max = len > acc_max ? len : acc_max;
-                        const uint32_t slot = (m2 >> b) & 1u ? k2++ : ko++;
-                        L.listM[slot] = (uint16_t)(p | ((len < 63u ? len : 63u) << 10));
-                    }
+                    if (m) { L.listM[k++] = (uint16_t)(c0 | (uint32_t)__builtin_ctz(m)); m &= m - 1u; }
                 }
             }
-            uint32_t nM = 0, nX = 0;
             PT(3)
-            // more clusters than one round takes: the 2-symbol ones go first, in rounds of their own (one pair each)
-            uint32_t first = 0;
-            if (total > 64u && !ABL(4) && !ABL(10)) {
-                for (uint32_t base = 0; base < n2; base += 64u) {
-                    const uint32_t t = base + lane;
-                    const bool on = t < n2;
-                    acc_upd += score_len2<EBWT>(L, T, qu, a, on, on ? (uint32_t)L.listM[t] & 1023u : 0u);
-                }
-                first = n2;
-            }
+            // Rounds of 64 clusters.  Phase 0 reads the positions and takes every cluster's length from the head bits
+            // (the next head after it).  A window with at most 64 clusters scores the short ones (<= 4 symbols) at once;
+            // one with more (real collections: hundreds, 98 % of them of 2 symbols) scores its 2-symbol clusters in
+            // phase 0 -- one pair each -- and files the others (position | (len-1) << 12, over the already consumed head
+            // of the list) for phase 1.  Clusters of 5..SMALL_MAX symbols are filed the same way for the rows routine.
+            uint32_t nM = 0, nD = 0;
+            const bool defer = total > 64u;
             if (!ABL(4))
-            for (uint32_t base = first; base < total; base += 64u) {
-                const uint32_t t = base + lane;
-                const bool on = t < total;
-                const uint32_t item = on ? L.listM[t] : 0u;
-                const uint32_t p = item & 1023u;
-                uint32_t len = item >> 10;
-                if (__ballot(len > SMALL_MAX)) {
-                    if (len >= 63u) {                                 // rare: walk the head bytes to the end of the run
-                        uint32_t q = p + 17u, e = WPOS;               // an accepted cluster closes before WPOS
-                        while (q < WPOS) {
-                            const uint32_t hbq = (uint32_t)L.hb[q >> 3] >> (q & 7u);
-                            if (hbq) { e = q + (uint32_t)__builtin_ctz(hbq); break; }
-                            q = (q | 7u) + 1u;
-                        }
-                        len = e - p;
-                        if (len > MID_MAX) {                          // one workgroup per such cluster later
-                            const uint32_t kk = atomicAdd(&a.stats->n_big, 1u);
-                            if (kk < a.big_cap) { a.big[kk].pStart = lo + p; a.big[kk].len = len; }
-                        }
-                    }
-                    // SMALL_MAX+1 .. MID_MAX symbols: noted, scored after the rounds (at most 61 per window)
-                    const bool cX = len > SMALL_MAX && len <= MID_MAX;
-                    const uint64_t mX = __ballot(cX);
-                    if (cX) L.listX[nX + (uint32_t)__popcll(mX & lt)] = p | (len << 16);
-                    nX += (uint32_t)__popcll(mX);
-                }
-                const bool cM = on && len > 4u && len <= SMALL_MAX;
-                const uint64_t mM = __ballot(cM);
-                if (mM) {
-                    if (cM) L.listM[nM + (uint32_t)__popcll(mM & lt)] = (uint16_t)(p | ((len - 1u) << 12));
-                    nM += (uint32_t)__popcll(mM);
-                }
-                const bool sm4 = on && len <= 4u;
-                PT(4)
-                if (!ABL(10)) acc_upd += score_small<EBWT>(L, T, qu, n_dup, a, sm4, sm4 ? p : 0u, sm4 ? len : 0u);
-                PT(5)
-            }
-            if (nM && !ABL(10) && !ABL(11)) {
-#ifdef LIME_PHASE_TIMING
-                acc_upd += score_medium<EBWT>(L, T, qu, n_dup, a, nM, pt_m); ++pt_nwin;
-#else
-                acc_upd += score_medium<EBWT>(L, T, qu, n_dup, a, nM);
-#endif
-            }
-            // 17..64 symbols: the whole wave is one lane group on the staged window
 #pragma unroll 1
-            for (uint32_t k = 0; k < nX; ++k) {
-                const uint32_t it = L.listX[k], p0 = it & 0xFFFFu, len0 = it >> 16;
-                const bool hvv = lane < len0;
-                acc_upd += group_score<EBWT, 64>(a, T, qu, hvv ? L.da[p0 + lane] : 0u, (EBWT && hvv) ? L.fl[p0 + lane] : 0u, len0);
+            for (uint32_t phase = 0; phase < (defer ? 2u : 1u); ++phase) {
+                const uint32_t n_items = phase ? nD : total;
+#pragma unroll 1
+                for (uint32_t base = 0; base < n_items; base += 64u) {
+                    const uint32_t t = base + lane;
+                    const bool on = t < n_items;
+                    const uint32_t item = on ? L.listM[t] : 0u;
+                    uint32_t p = item & 0xFFFu, len = (item >> 12) + 1u;
+                    if (phase == 0u) {
+                        const uint32_t w = bits_at(L.hb, p + 1u);             // head bits of p+1 .. p+32
+                        len = w ? (uint32_t)__builtin_ctz(w) + 1u : 33u;
+                        if (!on) len = 0u;
+                        if (__ballot(len > SMALL_MAX)) {
+                            if (len >= 33u) {                                 // rare: walk the head bytes to the end of the run
+                                uint32_t q = p + 33u, e = WPOS;               // an accepted cluster closes before WPOS
+                                while (q < WPOS) {
+                                    const uint32_t hbq = (uint32_t)L.hb[q >> 3] >> (q & 7u);
+                                    if (hbq) { e = q + (uint32_t)__builtin_ctz(hbq); break; }
+                                    q = (q | 7u) + 1u;
+                                }
+                                len = e - p;
+                                if (len > MID_MAX) {                          // one workgroup per such cluster later
+                                    const uint32_t kk = atomicAdd(&a.stats->n_big, 1u);
+                                    if (kk < a.big_cap) { a.big[kk].pStart = lo + p; a.big[kk].len = len; }
+                                }
+                            }
+                            // SMALL_MAX+1 .. MID_MAX symbols (rare): the whole wave is one lane group on the staged window, one cluster at a time
+                            uint64_t mX = __ballot(len > SMALL_MAX && len <= MID_MAX);
+                            while (mX) {
+                                const uint32_t src = (uint32_t)__builtin_ctzll(mX);
+                                mX &= mX - 1ull;
+                                const uint32_t p0 = rl32(p, src), len0 = rl32(len, src);
+                                const bool hvv = lane < len0;
+                                acc_upd += group_score<EBWT, 64>(a, T, qu, hvv ? L.da[p0 + lane] : 0u, (EBWT && hvv) ? L.fl[p0 + lane] : 0u, len0);
+                            }
+                        }
+                        acc_max = len > acc_max ? len : acc_max;
+                    } else if (!on) len = 0u;
+                    PT(4)
+                    if (ABL(10)) continue;
+                    if (phase == 0u && defer) {
+                        const bool is2 = len == 2u;
+                        acc_upd += score_len2<EBWT>(L, T, qu, a, is2, is2 ? p : 0u);
+                        const bool cD = len > 2u && len <= SMALL_MAX;
+                        const uint64_t mD = __ballot(cD);
+                        if (mD) {
+                            if (cD) L.listM[nD + rank_in(mD)] = (uint16_t)(p | ((len - 1u) << 12));
+                            nD += (uint32_t)__popcll(mD);
+                        }
+                        continue;
+                    }
+                    const bool cM = len > 4u && len <= 8u;                     // rows in groups of 8 lanes, after the rounds
+                    const uint64_t mM = __ballot(cM);
+                    if (mM) {
+                        if (cM) L.listM[nM + rank_in(mM)] = (uint16_t)(p | ((len - 1u) << 12));
+                        nM += (uint32_t)__popcll(mM);
+                    }
+                    const bool cL = len > 8u && len <= SMALL_MAX;              // rare: groups of 16 lanes, at once (the list holds one round's worth)
+                    const uint64_t mL = __ballot(cL);
+                    const bool sm4 = len >= 2u && len <= 4u;
+                    acc_upd += score_small3<EBWT>(L, T, qu, n_dup, a, sm4, sm4 ? p : 0u, sm4 ? len : 0u);
+                    if (mL && !ABL(11)) {
+                        if (cL) L.m_tstart[rank_in(mL)] = (uint16_t)(p | ((len - 1u) << 12));
+                        acc_upd += score_rows3<EBWT, 16>(L, T, qu, n_dup, a, L.m_tstart, (uint32_t)__popcll(mL));
+                    }
+                    PT(5)
+                }
             }
+            if (nM && !ABL(10) && !ABL(11) && !ABL(4)) acc_upd += score_rows3<EBWT, 8>(L, T, qu, n_dup, a, L.listM, nM);
             if (n_dup >= DUP_SLOTS / 2u) acc_upd += dup_flush<EBWT>(L, n_dup, a, T, qu);
             PT(6)
         } else {
@@ -1414,12 +1580,11 @@ __global__ __launch_bounds__(PART_WG) void k_part(ScanArgs a, const uint64_t *bi
     static_assert(BIN_MAX <= 4096 && PART_TILE <= (1u << 20), "bin | rank << 12 must fit 32 bits");
     // the producer's four wave regions as one sequence of tiles; the next tile's records are loaded while the
     // current one goes through LDS
-    uint32_t n_w[SCANK_WG / 64];
-#pragma unroll
-    for (uint32_t w = 0; w < SCANK_WG / 64; ++w) n_w[w] = a.wave_cnt[blockIdx.x * (SCANK_WG / 64) + w];
-    auto seg_n = [&](uint32_t w) { return w == 0 ? n_w[0] : w == 1 ? n_w[1] : w == 2 ? n_w[2] : n_w[3]; };
+    // the producer's wave regions (wpp of them) as one sequence of tiles
+    const uint32_t wpp = a.prod_waves;
+    auto seg_n = [&](uint32_t w) { return a.wave_cnt[blockIdx.x * wpp + w]; };
     auto load_tile = [&](uint32_t w, uint32_t t0, uint64_t (&rec)[PART_PER]) {
-        const uint64_t *src = a.pool + (size_t)(blockIdx.x * (SCANK_WG / 64) + w) * a.cap_w + t0;
+        const uint64_t *src = a.pool + (size_t)(blockIdx.x * wpp + w) * a.cap_w + t0;
         const uint32_t n = seg_n(w), tn = n - t0 < PART_TILE ? n - t0 : PART_TILE;
 #pragma unroll
         for (uint32_t j = 0; j < PART_PER; ++j) {
@@ -1428,10 +1593,10 @@ __global__ __launch_bounds__(PART_WG) void k_part(ScanArgs a, const uint64_t *bi
         }
     };
     uint32_t w = 0, t0 = 0;
-    while (w < SCANK_WG / 64 && seg_n(w) == 0u) ++w;
+    while (w < wpp && seg_n(w) == 0u) ++w;
     uint64_t rec[PART_PER];
-    if (w < SCANK_WG / 64) load_tile(w, t0, rec);
-    while (w < SCANK_WG / 64) {
+    if (w < wpp) load_tile(w, t0, rec);
+    while (w < wpp) {
         const uint32_t n = seg_n(w), tn = n - t0 < PART_TILE ? n - t0 : PART_TILE;
         uint32_t val[PART_PER], dr[PART_PER];
 #pragma unroll
@@ -1445,8 +1610,8 @@ __global__ __launch_bounds__(PART_WG) void k_part(ScanArgs a, const uint64_t *bi
             }
         }
         t0 += PART_TILE;                                     // the next tile, if any: its loads go out now
-        if (t0 >= n) { t0 = 0; ++w; while (w < SCANK_WG / 64 && seg_n(w) == 0u) ++w; }
-        if (w < SCANK_WG / 64) load_tile(w, t0, rec);
+        if (t0 >= n) { t0 = 0; ++w; while (w < wpp && seg_n(w) == 0u) ++w; }
+        if (w < wpp) load_tile(w, t0, rec);
         __syncthreads();
         part_scan(cnt, toff, a.n_bins, wsum);
 #pragma unroll
@@ -1874,8 +2039,9 @@ template <typename K> static uint32_t resident_blocks(K kernel, int block)
 constexpr int MAX_DEV = 64;
 static int cur_device() { int d = 0; (void)hipGetDevice(&d); return d >= 0 && d < MAX_DEV ? d : 0; }
 
-template <int ID, typename K> static uint32_t scan_grid_of(K kernel, uint32_t n_tiles, uint32_t max_blocks)
+template <int ID, int WG, typename K> static uint32_t scan_grid_of(K kernel, uint32_t n_tiles, uint32_t max_blocks)
 {
+    constexpr int SCANK_WG = WG;
     static std::atomic<uint32_t> resident_of[MAX_DEV];
     std::atomic<uint32_t> &slot = resident_of[cur_device()];
     uint32_t resident = slot.load(std::memory_order_relaxed);
@@ -1885,17 +2051,17 @@ template <int ID, typename K> static uint32_t scan_grid_of(K kernel, uint32_t n_
     return grid ? grid : 1u;
 }
 
-template <int ID, typename K> static void launch_scan_kernel(K kernel, const ScanArgs &a, uint32_t max_blocks, hipStream_t st)
+template <int ID, int WG, typename K> static void launch_scan_kernel(K kernel, const ScanArgs &a, uint32_t max_blocks, hipStream_t st)
 {
     // persistent grid: as many workgroups as fit the device at once (per instantiation), or fewer for short inputs
-    hipLaunchKernelGGL(kernel, dim3(scan_grid_of<ID>(kernel, a.n_tiles, max_blocks)), dim3(SCANK_WG), 0, st, a);
+    hipLaunchKernelGGL(kernel, dim3(scan_grid_of<ID, WG>(kernel, a.n_tiles, max_blocks)), dim3(WG), 0, st, a);
 }
 
 uint32_t scan_grid(int ebwt, int mode, int binned, uint32_t n_tiles, uint32_t max_blocks)
 {
-    if (mode != 0) return scan_grid_of<2>(k_scan<0, 1, 0>, n_tiles, max_blocks);
-    if (binned) return ebwt ? scan_grid_of<4>(k_scan<1, 0, 1>, n_tiles, max_blocks) : scan_grid_of<3>(k_scan<0, 0, 1>, n_tiles, max_blocks);
-    return ebwt ? scan_grid_of<1>(k_scan<1, 0, 0>, n_tiles, max_blocks) : scan_grid_of<0>(k_scan<0, 0, 0>, n_tiles, max_blocks);
+    if (mode != 0) return scan_grid_of<2, ScanCfg<0>::wg>(k_scan<0, 1, 0>, n_tiles, max_blocks);
+    if (binned) return ebwt ? scan_grid_of<4, ScanCfg<1>::wg>(k_scan<1, 0, 1>, n_tiles, max_blocks) : scan_grid_of<3, ScanCfg<0>::wg>(k_scan<0, 0, 1>, n_tiles, max_blocks);
+    return ebwt ? scan_grid_of<1, ScanCfg<1>::wg>(k_scan<1, 0, 0>, n_tiles, max_blocks) : scan_grid_of<0, ScanCfg<0>::wg>(k_scan<0, 0, 0>, n_tiles, max_blocks);
 }
 
 void launch_bin_rowscan(uint32_t *counts, uint32_t *totals, uint32_t n_bins, uint32_t n_prod, hipStream_t st)
@@ -1928,13 +2094,13 @@ void launch_apply(uint8_t *sim, size_t sim_bytes, const uint32_t *recs, const ui
 
 void launch_tile(int ebwt, int mode, const ScanArgs &a, uint32_t max_blocks, hipStream_t st)
 {
-    if (mode != 0) launch_scan_kernel<2>(k_scan<0, 1, 0>, a, max_blocks, st);
+    if (mode != 0) launch_scan_kernel<2, ScanCfg<0>::wg>(k_scan<0, 1, 0>, a, max_blocks, st);
     else if (a.upd_mode) {
-        if (ebwt) launch_scan_kernel<4>(k_scan<1, 0, 1>, a, max_blocks, st);
-        else      launch_scan_kernel<3>(k_scan<0, 0, 1>, a, max_blocks, st);
+        if (ebwt) launch_scan_kernel<4, ScanCfg<1>::wg>(k_scan<1, 0, 1>, a, max_blocks, st);
+        else      launch_scan_kernel<3, ScanCfg<0>::wg>(k_scan<0, 0, 1>, a, max_blocks, st);
     } else {
-        if (ebwt) launch_scan_kernel<1>(k_scan<1, 0, 0>, a, max_blocks, st);
-        else      launch_scan_kernel<0>(k_scan<0, 0, 0>, a, max_blocks, st);
+        if (ebwt) launch_scan_kernel<1, ScanCfg<1>::wg>(k_scan<1, 0, 0>, a, max_blocks, st);
+        else      launch_scan_kernel<0, ScanCfg<0>::wg>(k_scan<0, 0, 0>, a, max_blocks, st);
     }
 }
 

@@ -1,0 +1,17 @@
+#!/usr/bin/env python3
+"""tools/kres.py FILE.s [regex] -- per-kernel resources from the amdhsa metadata of hipcc's assembly output:
+VGPRs, SGPRs, spills, LDS bytes, scratch; waves per SIMD the register count allows."""
+import re, sys, json
+txt = open(sys.argv[1]).read()
+pat = re.compile(sys.argv[2]) if len(sys.argv) > 2 else None
+md = txt[txt.index("amdhsa.kernels:"):]
+out = {}
+for blk in re.split(r"\n  - \.agpr_count:", md)[1:]:
+    g = lambda k: (re.search(r"\." + k + r":\s+(\S+)", blk) or [None, None])[1]
+    name = g("name")
+    if pat and not pat.search(name): continue
+    v = int(g("vgpr_count")); alloc = (v + 7) // 8 * 8
+    out[name] = dict(vgpr=v, sgpr=int(g("sgpr_count")), sgpr_spill=int(g("sgpr_spill_count")), vgpr_spill=int(g("vgpr_spill_count")),
+                     lds=int(g("group_segment_fixed_size")), scratch=int(g("private_segment_fixed_size")), waves_by_vgpr=min(8, 512 // alloc))
+    print(f"{name[:60]:60s} vgpr {v:4d} sgpr {out[name]['sgpr']:4d} sspill {out[name]['sgpr_spill']:3d} vspill {out[name]['vgpr_spill']:3d} lds {out[name]['lds']:6d} scratch {out[name]['scratch']:4d} waves/simd {out[name]['waves_by_vgpr']}")
+if len(sys.argv) > 3: json.dump(out, open(sys.argv[3], "w"), indent=1)
