@@ -154,6 +154,11 @@ def run_pass_series(torch, lime_amd, ldist, wl, n_total, steps, warmup, world, r
             done[b] = None
         ctx.fused_dev(lcp, da, eb, n_own, n_avail, hi_halo == n_total, wl["nr"], wl["ng"], ALPHA, sims[b], True, stream)
         if world > 1:
+            # the pass is final only once lime_get_stats has returned (a record pool that proved too small is repaired there):
+            # settle it before its table goes into the exchange
+            _s, _rc = ctx.stats(stream)
+            if _rc:
+                sys.exit(f"scan failed: rc={_rc}")
             if ex_stream is None:              # exposed: the exchange follows the pass on the same stream
                 comm.reduce_scatter_tables(sims[b], blks[b], blk_bytes, stream)
             else:                              # overlapped: on its own stream, under the next step's scan
@@ -170,9 +175,9 @@ def run_pass_series(torch, lime_amd, ldist, wl, n_total, steps, warmup, world, r
 
     for _ in range(warmup):
         step()
-    s, rc = ctx.stats(stream)                  # also settles the update path / pool size before the timed region
-    if rc:
-        sys.exit(f"scan failed: rc={rc}")
+        s, rc = ctx.stats(stream)              # settles the pass: update path, pool size (a pass that overflowed its record pool is repeated here)
+        if rc:
+            sys.exit(f"scan failed: rc={rc}")
     for _ in range(2 if warmup else 0):
         step()
     s, rc = ctx.stats(stream)
@@ -252,7 +257,7 @@ def main():
             comm = ldist.HostComm(rank, world, dev)
         comm.check_uint8_sum_wraps()
 
-    scaling = args.scaling or ("strong" if world > 1 else "weak")
+    scaling = args.scaling or "strong"         # the series is strong scaling (fixed 10^10 symbols); on one GPU the label says which series the line belongs to
     wname = args.workload or ("c3" if (world == 1 or scaling == "weak") else "n1e10")
     wl = dict(WORKLOADS[wname])
     if world > 1 and scaling == "strong":

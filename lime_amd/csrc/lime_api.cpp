@@ -226,7 +226,7 @@ static ScanArgs base_args(lime_ctx *c, const uint32_t *lcp, const uint32_t *da, 
     a.n_own = n_own; a.n_avail = n_avail; a.pos_base = 0; a.eof = eof;
     a.n_reads = n_reads; a.n_refs = n_refs; a.alpha = alpha;
     a.n_tiles = (uint32_t)((n_avail + WIN - 1) / WIN);
-    a.sim = sim; a.summ = c->d_summ; a.stats = c->d_stats;
+    a.sim = sim; a.summ = c->d_summ; a.open = reinterpret_cast<OpenRec *>(c->d_summ); a.stats = c->d_stats;
     a.small = c->d_small; a.cross_cap = c->small_cap; a.big = c->d_big; a.big_cap = c->big_cap;
     a.tile_cnt = c->d_tile_cnt; a.tile_off = c->d_tile_off; a.cross = c->d_cross; a.out = c->d_out;
     a.wmask = c->d_wmask;
@@ -309,8 +309,8 @@ static int ensure_binned(lime_ctx *c, uint64_t n_own, uint32_t n_waves, uint32_t
 {
     int rc;
     const double per_wave = (double)n_own * c->pool_density / (double)n_waves;
-    uint64_t cw = ((uint64_t)(per_wave * 1.10) + 512u) & ~1ull;           // even: a wave's region starts 16-byte aligned
-    if (c->pool_cap / n_waves > cw) cw = (c->pool_cap / n_waves) & ~1ull;  // grow-only: use all of what is there
+    uint64_t cw = ((uint64_t)(per_wave * 1.10) + 512u) & ~15ull;          // a multiple of 16 records: a wave's region starts on a 128-byte line
+    if (c->pool_cap / n_waves > cw) cw = (c->pool_cap / n_waves) & ~15ull; // grow-only: use all of what is there
     if (cw * n_waves > 0xF0000000ull) return fail(LIME_ERR_ARG, "update record pool too large for one shard");   // per-bin record counts are 32-bit
     const size_t want = (size_t)cw * n_waves;
     if (want > c->pool_cap) {
@@ -379,6 +379,7 @@ static int fused_dev_impl(lime_ctx *c, const uint32_t *d_lcp, const uint32_t *d_
     if ((rc = timing_mark(c, st))) return rc;
     if (keep_stats) {
         HIP_TRY(hipMemsetAsync(&c->d_stats->n_cross, 0, 2 * sizeof(uint32_t), st));      // n_cross, n_big
+        HIP_TRY(hipMemsetAsync(&c->d_stats->n_open, 0, sizeof(uint32_t), st));
     } else {
         HIP_TRY(hipMemsetAsync(c->d_stats, 0, sizeof(DevStats), st));
     }
@@ -394,7 +395,7 @@ static int fused_dev_impl(lime_ctx *c, const uint32_t *d_lcp, const uint32_t *d_
     launch_tile(ebwt, 0, a, c->max_blocks, st);
     if ((rc = timing_mark(c, st))) return rc;
     launch_resolve(0, a, st);
-    if (binned) {
+    if (binned && !c->ablate) {                          // (timing experiments cut the scan short: nothing to partition)
         launch_bin_rowscan(c->d_counts, c->d_totals, n_bins, grid, st);
         launch_scan_tiles(c->d_totals, c->d_binbase, n_bins, reinterpret_cast<unsigned long long *>(c->d_binbase + n_bins), st);
         launch_part(a, grid, c->d_binbase, c->d_recs, st);

@@ -52,10 +52,11 @@ constexpr size_t BIG_SCRATCH_WORDS = (size_t)HT_SIZE + (size_t)HT_SIZE * 16u + 2
 
 struct TileSummary { uint32_t first_head, last_head, pre, suf; };   // per window: offsets in window; flags bit0 read, bit1 genome
 struct CrossRec { uint64_t start, len; };                          // len == 0: none
+struct OpenRec { uint64_t start; uint32_t flags, pad; };           // scoring scan: a window's last head whose run has no head in the read-ahead; flags bit0 read, bit1 genome so far
 
 struct DevStats {                            // same layout as lime_stats_t
     unsigned long long n_clusters, max_len, n_updates;
-    uint32_t n_cross, n_big, flags, wave_records_max, edge, reserved;
+    uint32_t n_cross, n_big, flags, wave_records_max, edge, n_open;    // n_open (lime_stats_t.reserved): records in ScanArgs::open
 };
 static_assert(sizeof(DevStats) == sizeof(lime_stats_t), "DevStats must mirror lime_stats_t");
 
@@ -69,7 +70,7 @@ struct ScanArgs {
     int eof;
     uint32_t n_reads, n_refs, alpha, n_tiles;    // n_tiles: number of WIN-position windows
     uint8_t *sim;
-    TileSummary *summ;
+    TileSummary *summ; OpenRec *open;            // detection pass: a summary per window; scoring scan: the noted open segments (the same buffer)
     DevStats *stats;
     lime_cluster_t *small; uint32_t cross_cap;   // tile-crossing clusters <= SMALL_MAX
     lime_cluster_t *big; uint32_t big_cap;       // clusters > SMALL_MAX

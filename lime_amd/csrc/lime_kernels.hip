@@ -84,7 +84,7 @@ struct alignas(16) WaveLds {
 // threads per workgroup of k_scan (its waves work independently) and waves per SIMD it is compiled for: ScanCfg in
 // lime_kernels.h (EBWT = 0: 8 waves, two workgroups per CU = 4 waves per SIMD; EBWT = 1: 4 waves, three workgroups)
 constexpr uint32_t DUP_SLOTS = 8;     // clusters with a repeated document a wave of k_scan holds before scoring them
-constexpr uint32_t QCAP_SCAN = 256;   // >= the 256 hits one batch of 64 clusters of <= 4 symbols can add
+constexpr uint32_t QCAP_SCAN = 272;   // >= the 256 hits one batch of 64 clusters of <= 4 symbols can add + the 15 records a binned drain leaves behind
 
 __device__ __forceinline__ uint32_t lane_id() { return threadIdx.x & 63u; }
 __device__ __forceinline__ uint64_t brev64(uint64_t x) { return __builtin_bitreverse64(x); }
@@ -233,7 +233,7 @@ struct UpdQueue { uint32_t *qr, *qg; uint32_t n, cap;
     uint32_t f_first = 0, f_lost = 0; bool load_first = false;
     // binned mode (ScanArgs::upd_mode): drains append (cell, t) records to the wave's region of the pool and count
     // them per table bin in the workgroup's LDS histogram; no table access from the scan at all
-    bool binned = false; uint64_t *out = nullptr; uint32_t out_n = 0; uint32_t *hist = nullptr;
+    bool binned = false; uint64_t *out = nullptr; uint32_t out_n = 0; uint32_t *hist = nullptr; bool flush_all = false;
 #ifdef LIME_PHASE_TIMING
     uint64_t t_drain = 0; uint32_t n_drain = 0;
 #endif
@@ -305,9 +305,14 @@ __device__ __forceinline__ void drain_async(UpdQueue &q, const ScanArgs &a)
 __device__ __forceinline__ void drain_bin(UpdQueue &q, const ScanArgs &a)
 {
     const uint32_t lane = lane_id();
-    for (uint32_t k0 = 0; k0 < q.n; k0 += 64u) {
+    // Only whole 128-byte lines leave (16 records; the wave's region starts line-aligned and out_n stays a multiple of
+    // 16): a store burst that starts or ends inside a line is a partial line write for the memory system.  The up to 15
+    // records left over move to the front of the queue; the last drain of the kernel (flush_all) takes everything.
+    const uint32_t nw = q.flush_all ? q.n : q.n & ~15u;
+    if (!nw) return;
+    for (uint32_t k0 = 0; k0 < nw; k0 += 64u) {
         const uint32_t k = k0 + lane;
-        const bool on = k < q.n;
+        const bool on = k < nw;
         uint32_t gt = q.qg[on ? k : 0u], rd = q.qr[on ? k : 0u];
         // the scan's fast emitters do not look at the document ids: a genome id beyond the table is caught here, on
         // full waves (the record becomes "cell 0, t = 0", which the later stages skip; the pass fails with LIME_ERR_DOCID)
@@ -317,11 +322,16 @@ __device__ __forceinline__ void drain_bin(UpdQueue &q, const ScanArgs &a)
         const uint64_t cell = (uint64_t)rd * a.n_refs + (gt & (MAX_REFS - 1u));
         const uint32_t slot = q.out_n + k;
         if (on && slot < a.cap_w) {
-            atomicAdd(&q.hist[(uint32_t)(cell >> a.bin_shift)], 1u);
-            __builtin_nontemporal_store(cell | ((uint64_t)(gt >> T_SHIFT) << CELL_BITS), &q.out[slot]);
+            if (!ABL(7) && !ABL(9)) atomicAdd(&q.hist[(uint32_t)(cell >> a.bin_shift)], 1u);
+            if (!ABL(6) && !ABL(7)) __builtin_nontemporal_store(cell | ((uint64_t)(gt >> T_SHIFT) << CELL_BITS), &q.out[slot]);   // LIME_ABLATE=6: everything but the record stores
         }
     }
-    q.out_n += q.n; q.n = 0;
+    const uint32_t left = q.n - nw;
+    if (left) {                                                   // wave-uniform
+        const uint32_t g2 = q.qg[nw + (lane < left ? lane : 0u)], r2 = q.qr[nw + (lane < left ? lane : 0u)];
+        if (lane < left) { q.qg[lane] = g2; q.qr[lane] = r2; }
+    }
+    q.out_n += nw; q.n = left;
 }
 
 __device__ __forceinline__ void drain(UpdQueue &q, const ScanArgs &a)
@@ -1193,6 +1203,14 @@ __global__ __launch_bounds__(ScanCfg<EBWT>::wg) __attribute__((amdgpu_waves_per_
             gb = vb & ~rb;
         }
         const uint32_t c0 = PPL * lane;
+        // ---- the table updates queued while the PREVIOUS window was scored leave now, before the next window's loads:
+        // vmcnt counts stores and atomics with the loads, so a store issued after the loads keeps the wave waiting for
+        // its acknowledgement when it wants to stage the loaded window (measured on configs[2]: 0.34 of 2.06 ms with the
+        // stores issued from the scoring rounds).  Issued here they are older than the loads and long done by then.
+        if (MODE == 0 && !ABL(8)) {
+            drain(qu, a);
+            asm volatile("" ::: "memory");                    // the loads below stay below
+        }
         // ---- the next window's loads go out now and land while this one is processed ----------
         const uint32_t next = win + stride;
         if (next < n_win) window_load<EBWT>(regs, a, (uint64_t)next * WIN);
@@ -1200,8 +1218,25 @@ __global__ __launch_bounds__(ScanCfg<EBWT>::wg) __attribute__((amdgpu_waves_per_
         PT(1)
         if (!ABL(1)) {                               // LIME_ABLATE: timing experiments, cut after a phase
         const Ctx16 c = chunk_context(hb, rb, gb, H64, R64, G64, own_lim);
-        // ---- window summary for the segment that is still open after the read-ahead ------------
+        // ---- the segment of the window's last head may still be open after the read-ahead (no head there): rare.
+        // The scoring scan only notes it (start, what the window holds of it) for k_resolve_open, which walks the arrays
+        // from the end of the window on; the detection pass keeps a summary per window for k_resolve<1> and k_emit.
         {
+            if (MODE == 0) {
+                if (H64 == 0u && c.HW != 0ull) {                                // wave-uniform
+                    const uint32_t lw = 63u - (uint32_t)__clzll((long long)c.HW);
+                    const uint32_t li = rl32(c.info, lw), last = PPL * lw + ((li >> 5) & 31u);
+                    if (last < own_lim) {                                       // owned by this shard
+                        const uint64_t whigh = (lw == 63u) ? 0ull : (~0ull << (lw + 1u));
+                        const uint32_t suf = (((c.RW & whigh) || ((li >> 12) & 1u)) ? 1u : 0u) | (((c.GW & whigh) || ((li >> 13) & 1u)) ? 2u : 0u);
+                        if (lane == 0) {
+                            const uint32_t k = atomicAdd(&a.stats->n_open, 1u);  // at most one per window: the list holds n_tiles records
+                            OpenRec orec; orec.start = lo + last; orec.flags = suf; orec.pad = 0u;
+                            a.open[k] = orec;
+                        }
+                    }
+                }
+            } else {
             TileSummary sm;
             sm.first_head = NONE32; sm.last_head = NONE32;
             uint32_t pre = (c.RW ? 1u : 0u) | (c.GW ? 2u : 0u), suf = 0u;       // no head: the whole window is "prefix"
@@ -1214,6 +1249,7 @@ __global__ __launch_bounds__(ScanCfg<EBWT>::wg) __attribute__((amdgpu_waves_per_
                 suf = (((c.RW & whigh) || ((li >> 12) & 1u)) ? 1u : 0u) | (((c.GW & whigh) || ((li >> 13) & 1u)) ? 2u : 0u);
             }
             if (lane == 0) { sm.pre = pre; sm.suf = suf; a.summ[win] = sm; }
+            }
             // a run closed by padding instead of data while more data exists beyond the shard's
             // halo: the last data head in sight is owned and nothing but padding follows it
             if (!a.eof && lim < WPOS && Hd64 == 0u) {
@@ -1356,6 +1392,7 @@ __global__ __launch_bounds__(ScanCfg<EBWT>::wg) __attribute__((amdgpu_waves_per_
     }
     if (MODE == 0) {
         if (n_dup) acc_upd += dup_flush<EBWT>(L, n_dup, a, T, qu);
+        qu.flush_all = true;
         do drain(qu, a); while (qu.n != 0u || __ballot(qu.f_pend != 0u));      // until every update has landed
         if (binned) finish_binned();
     }
@@ -1465,6 +1502,54 @@ __global__ __launch_bounds__(256) void k_resolve(ScanArgs a)
         if (len > LIME_MAX_CLUSTER) { atomicOr(&a.stats->flags, LIME_FLAG_MAXLEN); return; }
         const uint32_t k = atomicAdd(&a.stats->n_big, 1u);
         if (k < a.big_cap) { a.big[k].pStart = s; a.big[k].len = len; }
+    }
+}
+
+// =========================================================================================
+// k_resolve_open (scoring scan): a wave per noted segment -- the last head of a window whose run has no head in the
+// window's read-ahead.  The wave walks lcp / da from the end of that window to the run's end (the reference's straddle
+// loop, ClusterLCP.cpp:246-264; EOF closure :244-245) and decides like k_resolve.  Wave 0 first leaves in the shard's
+// edge word what lies before the shard's first head (it belongs to a run of an earlier shard).
+// =========================================================================================
+__global__ __launch_bounds__(256) void k_resolve_open(ScanArgs a)
+{
+    const uint32_t lane = lane_id();
+    const uint32_t wave = blockIdx.x * 4u + (threadIdx.x >> 6), n_waves = gridDim.x * 4u;
+    // positions [from, n_avail): where the first head is (n_avail: none) and what the positions before it hold
+    auto walk = [&](uint64_t from, uint32_t &fl) -> uint64_t {
+        for (uint64_t i = from; i < a.n_avail; i += 64u) {
+            const uint64_t p = i + lane;
+            const bool ok = p < a.n_avail;
+            const bool head = ok && a.lcp[p] < a.alpha;
+            const bool isr = ok && a.da[p] < a.n_reads;
+            const uint64_t mh = __ballot(head);
+            const uint64_t below = mh ? ((1ull << (uint32_t)__builtin_ctzll(mh)) - 1ull) : ~0ull;
+            if (__ballot(ok && isr) & below) fl |= 1u;
+            if (__ballot(ok && !isr) & below) fl |= 2u;
+            if (mh) return i + (uint32_t)__builtin_ctzll(mh);
+        }
+        return a.n_avail;
+    };
+    if (wave == 0) {
+        uint32_t fl = 0;
+        const uint64_t h0 = walk(0, fl);
+        if (lane == 0) atomicOr(a.edge, ((fl & 1u) ? LIME_EDGE_LEAD_R : 0u) | ((fl & 2u) ? LIME_EDGE_LEAD_G : 0u) | (h0 < a.n_avail ? LIME_EDGE_LEAD_HEAD : 0u));
+    }
+    const uint32_t n_open = a.stats->n_open < a.n_tiles ? a.stats->n_open : a.n_tiles;
+    for (uint32_t k = wave; k < n_open; k += n_waves) {
+        const uint64_t s = a.open[k].start;
+        uint32_t fl = a.open[k].flags;
+        const uint64_t e = walk((s / WIN + 1u) * WIN, fl);
+        if (lane != 0) continue;
+        if (e >= a.n_avail && !a.eof) { open_run_at_end(a, e - s, (fl & 1u) != 0u, (fl & 2u) != 0u); continue; }   // still open where the shard's arrays end
+        const uint64_t len = e - s;
+        if (fl != 3u || len < 2u) continue;
+        atomicAdd(&a.stats->n_clusters, 1ull);
+        atomicMax(&a.stats->max_len, (unsigned long long)len);
+        atomicAdd(&a.stats->n_cross, 1u);
+        if (len > LIME_MAX_CLUSTER) { atomicOr(&a.stats->flags, LIME_FLAG_MAXLEN); continue; }
+        const uint32_t kb = atomicAdd(&a.stats->n_big, 1u);
+        if (kb < a.big_cap) { a.big[kb].pStart = s; a.big[kb].len = len; }
     }
 }
 
@@ -2112,7 +2197,7 @@ void launch_emit(const ScanArgs &a, hipStream_t st)
 void launch_resolve(int mode, const ScanArgs &a, hipStream_t st)
 {
     const dim3 grid((a.n_tiles + 255) / 256), block(256);
-    if (mode == 0) hipLaunchKernelGGL((k_resolve<0>), grid, block, 0, st, a);
+    if (mode == 0) hipLaunchKernelGGL(k_resolve_open, dim3(64), block, 0, st, a);     // a wave per noted open segment (rare), 256 waves
     else           hipLaunchKernelGGL((k_resolve<1>), grid, block, 0, st, a);
 }
 

@@ -101,6 +101,77 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))) voi
     if (acc == 0x12345678u || alpha == 0xFFFFFFFFu) out[0] = acc + pad[lane];
 }
 
+// pattern A loads + `recs` 8-byte records per window and wave appended to the wave's own region (what the binned scan does):
+// SMODE 0 none, 1 nt 8 B per lane (64 records per instruction), 2 plain, 3 nt 16 B per lane (two records per lane), 4 stores
+// issued BEFORE the next window's loads instead of after
+template <int SMODE>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))) void k_mix(const uint32_t *lcp, const uint32_t *da, uint32_t n_win, uint32_t alpha,
+                                                                                         uint64_t *pool, uint32_t cap_w, uint32_t recs, uint32_t *out)
+{
+    __shared__ uint32_t pad[48 * 256];
+    const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
+    if (alpha == 0xFFFFFFFFu) pad[threadIdx.x] = lane;
+    const uint32_t stride = gridDim.x * 4u;
+    uint32_t win = blockIdx.x * 4u + wave, acc = 0, out_n = 0;
+    if (win >= n_win) return;
+    uint64_t *reg = pool + (size_t)(blockIdx.x * 4u + wave) * cap_w;
+    Regs<0> a;
+    load_win<0>(a, lcp, da, (uint64_t)win * WIN, lane);
+    auto stores = [&](uint32_t v) {
+        if (SMODE == 3) {
+            for (uint32_t k0 = 0; k0 < recs; k0 += 128u) {
+                const uint32_t k = k0 + 2u * lane;
+                if (k + 1u < recs && out_n + k + 1u < cap_w) {
+                    typedef unsigned long long u64x2 __attribute__((ext_vector_type(2)));
+                    u64x2 r; r.x = ((uint64_t)v << 8) | k; r.y = ((uint64_t)v << 9) | k;
+                    __builtin_nontemporal_store(r, reinterpret_cast<u64x2 *>(reg + out_n + k));
+                }
+            }
+        } else {
+            for (uint32_t k0 = 0; k0 < recs; k0 += 64u) {
+                const uint32_t k = k0 + lane;
+                if (k < recs && out_n + k < cap_w) {
+                    const uint64_t r = ((uint64_t)v << 8) | k;
+                    if (SMODE == 2) reg[out_n + k] = r; else __builtin_nontemporal_store(r, reg + out_n + k);
+                }
+            }
+        }
+        out_n += recs;
+    };
+    uint32_t iter = 0;
+    uint64_t *wg_reg = pool + (size_t)blockIdx.x * 4u * cap_w;      // SMODE 6: the workgroup's four regions as one stream
+    unsigned long long *cursor = reinterpret_cast<unsigned long long *>(out + 4);
+    for (;;) {
+        Regs<0> cur = a;
+        const uint32_t next = win + stride;
+        uint32_t part = consume<0>(cur, alpha);
+        if (SMODE == 4) { stores(part); asm volatile("" ::: "memory"); }
+        if (next < n_win) load_win<0>(a, lcp, da, (uint64_t)next * WIN, lane);
+        if (SMODE == 5) { if ((iter & 3u) == 3u) { stores(part); stores(part); stores(part); stores(part); } }
+        else if (SMODE == 6) {
+            for (uint32_t k0 = 0; k0 < recs; k0 += 64u) {
+                const size_t at = ((size_t)iter * 4u + wave) * recs + k0 + lane;
+                if (at < (size_t)4u * cap_w) __builtin_nontemporal_store(((uint64_t)part << 8) | lane, wg_reg + at);
+            }
+        } else if (SMODE == 7) {
+            unsigned long long base = 0;
+            if (lane == 0) base = atomicAdd(cursor, (unsigned long long)recs);
+            base = ((unsigned long long)__builtin_amdgcn_readfirstlane((int)(base >> 32)) << 32) | (unsigned)__builtin_amdgcn_readfirstlane((int)base);
+            for (uint32_t k0 = 0; k0 < recs; k0 += 64u) __builtin_nontemporal_store(((uint64_t)part << 8) | lane, pool + (base + k0 + lane) % ((size_t)gridDim.x * 4u * cap_w));
+        } else if (SMODE == 8) {
+            uint32_t *r4 = reinterpret_cast<uint32_t *>(reg);
+            for (uint32_t k0 = 0; k0 < recs; k0 += 64u) if (out_n + k0 + lane < 2u * cap_w) __builtin_nontemporal_store(part + lane, r4 + out_n + k0 + lane);
+            out_n += recs;
+        } else
+        if (SMODE != 0 && SMODE != 4) stores(part);
+        ++iter;
+        acc += part;
+        if (next >= n_win) break;
+        win = next;
+    }
+    if (acc == 0x12345678u || alpha == 0xFFFFFFFFu) out[0] = acc + pad[lane];
+}
+
 __global__ __launch_bounds__(256) void k_plain(const u32x4 *lcp, const u32x4 *da, uint64_t n4, uint32_t *out)
 {
     uint32_t acc = 0;
@@ -156,6 +227,24 @@ int main(int argc, char **argv)
     timeit("A lane-strided dword, 2 WG/CU", bytes, [&] { hipLaunchKernelGGL((k_win<0, 72>), g2, blk, 0, 0, lcp, da, n_win, 16u, out); });
     timeit("C both per-lane 4x dwordx4, 4 WG/CU", bytes, [&] { hipLaunchKernelGGL((k_win<2, 36>), g4, blk, 0, 0, lcp, da, n_win, 16u, out); });
     timeit("E 2 windows in flight, 2 WG/CU", bytes, [&] { hipLaunchKernelGGL((k_win<4, 72>), g2, blk, 0, 0, lcp, da, n_win, 16u, out); });
+    {
+        const uint32_t recs = 128u, n_waves = cus * 3 * 4, cap_w = ((n_win / n_waves + 2) * recs + 15u) & ~15u;
+        uint64_t *pool; CK(hipMalloc(&pool, (size_t)n_waves * cap_w * 8 + 64));
+        const uint64_t b2 = bytes + (uint64_t)n_win * recs * 8;
+        printf("record stores: %u per window and wave (%.2f GB per launch), region %u records\n", recs, n_win * (double)recs * 8 / 1e9, cap_w);
+        timeit("A + no stores", bytes, [&] { hipLaunchKernelGGL((k_mix<0>), g3, blk, 0, 0, lcp, da, n_win, 16u, pool, cap_w, recs, out); });
+        timeit("A + nt 8-B record stores (bytes incl. stores)", b2, [&] { hipLaunchKernelGGL((k_mix<1>), g3, blk, 0, 0, lcp, da, n_win, 16u, pool, cap_w, recs, out); });
+        timeit("A + plain 8-B record stores", b2, [&] { hipLaunchKernelGGL((k_mix<2>), g3, blk, 0, 0, lcp, da, n_win, 16u, pool, cap_w, recs, out); });
+        timeit("A + nt 16-B-per-lane record stores", b2, [&] { hipLaunchKernelGGL((k_mix<3>), g3, blk, 0, 0, lcp, da, n_win, 16u, pool, cap_w, recs, out); });
+        timeit("A + nt 8-B stores issued before the loads", b2, [&] { hipLaunchKernelGGL((k_mix<4>), g3, blk, 0, 0, lcp, da, n_win, 16u, pool, cap_w, recs, out); });
+        timeit("A + 4 KB bursts every 4th window", b2, [&] { hipLaunchKernelGGL((k_mix<5>), g3, blk, 0, 0, lcp, da, n_win, 16u, pool, cap_w, recs, out); });
+        timeit("A + one stream per workgroup (4 x 1 KB adjacent)", b2, [&] { hipLaunchKernelGGL((k_mix<6>), g3, blk, 0, 0, lcp, da, n_win, 16u, pool, cap_w, recs, out); });
+        timeit("A + ONE global stream (atomic cursor)", b2, [&] { CK(hipMemsetAsync(out, 0, 64)); hipLaunchKernelGGL((k_mix<7>), g3, blk, 0, 0, lcp, da, n_win, 16u, pool, cap_w, recs, out); });
+        timeit("A + 4-byte records (0.5 GB)", bytes + (uint64_t)n_win * recs * 4, [&] { hipLaunchKernelGGL((k_mix<8>), g3, blk, 0, 0, lcp, da, n_win, 16u, pool, cap_w, recs, out); });
+        timeit("A + 64 records per window (0.5 GB)", bytes + (uint64_t)n_win * 64 * 8, [&] { hipLaunchKernelGGL((k_mix<1>), g3, blk, 0, 0, lcp, da, n_win, 16u, pool, cap_w, 64u, out); });
+        timeit("A + 32 records per window (0.25 GB)", bytes + (uint64_t)n_win * 32 * 8, [&] { hipLaunchKernelGGL((k_mix<1>), g3, blk, 0, 0, lcp, da, n_win, 16u, pool, cap_w, 32u, out); });
+        CK(hipFree(pool));
+    }
     timeit("F plain grid-stride dwordx4 (16384 WGs)", bytes, [&] { hipLaunchKernelGGL(k_plain, dim3(16384), blk, 0, 0, (const u32x4 *)lcp, (const u32x4 *)da, nn / 4, out); });
     timeit("F plain grid-stride dwordx4 (2048 WGs)", bytes, [&] { hipLaunchKernelGGL(k_plain, dim3(2048), blk, 0, 0, (const u32x4 *)lcp, (const u32x4 *)da, nn / 4, out); });
     return 0;
