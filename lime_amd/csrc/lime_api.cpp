@@ -61,7 +61,7 @@ struct lime_ctx {
     uint32_t list_blocks = 8192;
     int ablate = 0;                         // LIME_ABLATE (only in a -DLIME_ABLATE_BUILD library): kernel timing experiments, results invalid when != 0
     // binned table updates (bin-then-apply): record pool, per-bin counters, binned records
-    uint64_t *d_pool = nullptr; size_t pool_cap = 0;          // records
+    uint32_t *d_pool = nullptr; size_t pool_cap = 0;          // 32-bit records (n_waves x n_sub x cap_w)
     uint32_t *d_recs = nullptr; size_t recs_cap = 0;
     uint32_t *d_wave_cnt = nullptr; size_t wave_cap = 0;
     uint32_t *d_counts = nullptr; size_t counts_cap = 0;
@@ -296,7 +296,7 @@ extern "C" int lime_get_timing(lime_ctx *c, double *scan_ms_avg, uint64_t *launc
 static bool want_binned(const lime_ctx *c, uint64_t n_own, size_t sim_bytes, int zero_sim, bool keep_stats, int ebwt)
 {
     if (!zero_sim || keep_stats || !n_own) return false;
-    if (sim_bytes > ((size_t)BIN_MAX << BIN_SHIFT_MAX) || sim_bytes >= (1ull << CELL_BITS)) return false;
+    if (sim_bytes > ((size_t)BIN_MAX << BIN_SHIFT_MAX) || sim_bytes >= (1ull << CELL_BITS) || sim_bytes > ((uint64_t)MAX_SUB << 32)) return false;
     if (c->upd_pref >= 0) return c->upd_pref == 1;
     if (n_own < (1u << 24)) return false;                 // short passes: the extra launches cost more than they save
     if (sim_bytes < (1u << 20)) return false;             // tiny tables: all updates would land in one or two bins
@@ -305,21 +305,22 @@ static bool want_binned(const lime_ctx *c, uint64_t n_own, size_t sim_bytes, int
 }
 
 static int ensure_binned(lime_ctx *c, uint64_t n_own, uint32_t n_waves, uint32_t n_prod, uint32_t n_bins, uint32_t bin_shift,
-                         uint32_t *cap_w, hipStream_t st)
+                         uint32_t n_sub, uint32_t *cap_w, hipStream_t st)
 {
     int rc;
     const double per_wave = (double)n_own * c->pool_density / (double)n_waves;
-    uint64_t cw = ((uint64_t)(per_wave * 1.10) + 512u) & ~15ull;          // a multiple of 16 records: a wave's region starts on a 128-byte line
-    if (c->pool_cap / n_waves > cw) cw = (c->pool_cap / n_waves) & ~15ull; // grow-only: use all of what is there
-    if (cw * n_waves > 0xF0000000ull) return fail(LIME_ERR_ARG, "update record pool too large for one shard");   // per-bin record counts are 32-bit
-    const size_t want = (size_t)cw * n_waves;
+    uint64_t cw = ((uint64_t)(per_wave * 1.10) + 512u) & ~15ull;          // a multiple of 16 records: sub-regions start on a 64-byte line
+    const size_t segs = (size_t)n_waves * n_sub;                          // every sub-region can take a wave's whole share (no assumption on how the cells spread)
+    if (c->pool_cap / segs > cw) cw = (c->pool_cap / segs) & ~15ull;      // grow-only: use all of what is there
+    if (cw * segs > 0xF0000000ull) return fail(LIME_ERR_ARG, "update record pool too large for one shard");   // record positions are 32-bit
+    const size_t want = (size_t)cw * segs;
     if (want > c->pool_cap) {
         HIP_TRY(hipStreamSynchronize(st));
-        if ((rc = regrow(c->d_pool, want + 8))) return rc;       // slack: k_part2 / k_apply read aligned groups of four 4-byte records
-        if ((rc = regrow(c->d_recs, want + 8))) return rc;
+        if ((rc = regrow(c->d_pool, want + 16))) return rc;      // slack: k_part2 / k_apply read aligned groups of four 4-byte records
+        if ((rc = regrow(c->d_recs, want + 16))) return rc;
         c->pool_cap = want; c->recs_cap = want;
     }
-    if (n_waves > c->wave_cap) { HIP_TRY(hipStreamSynchronize(st)); if ((rc = regrow(c->d_wave_cnt, (size_t)n_waves))) return rc; c->wave_cap = n_waves; }
+    if (segs > c->wave_cap) { HIP_TRY(hipStreamSynchronize(st)); if ((rc = regrow(c->d_wave_cnt, segs))) return rc; c->wave_cap = segs; }
     const size_t want_counts = (size_t)n_bins * n_prod;
     if (want_counts > c->counts_cap) { HIP_TRY(hipStreamSynchronize(st)); if ((rc = regrow(c->d_counts, want_counts))) return rc; c->counts_cap = want_counts; }
     if (!c->d_totals) {
@@ -357,8 +358,9 @@ static int fused_dev_impl(lime_ctx *c, const uint32_t *d_lcp, const uint32_t *d_
     // no_bin: a chunk of a multi-chunk stream -- its device buffers are reused by later chunks, so the pass could not be
     // repeated after a pool overflow, and the later chunks add to the table by compare-and-swap
     bool binned = n_avail && !no_bin && want_binned(c, n_own, sim_bytes, zero_sim, keep_stats, ebwt);
-    if (binned && (double)n_own * c->pool_density * 1.10 + 512.0 * 4096.0 > 3.9e9) binned = false;   // more records than 32-bit counts hold: compare-and-swap path
-    uint32_t grid = 0, cap_w = 0, n_bins = 0, bin_shift = REGION_SHIFT;
+    const uint32_t n_sub_want = (uint32_t)((sim_bytes + 0xFFFFFFFFull) >> 32);
+    if (binned && ((double)n_own * c->pool_density * 1.10 + 512.0 * 4096.0) * n_sub_want > 3.9e9) binned = false;   // more records than 32-bit positions hold: compare-and-swap path
+    uint32_t grid = 0, cap_w = 0, n_bins = 0, bin_shift = REGION_SHIFT, n_sub = 1;
     if (binned) {
         grid = scan_grid(ebwt, 0, 1, n_tiles, c->max_blocks);
         // one bin per 64 KB region for small tables; else as few levels of fan-out as fit: at most 2048 bins of 2^k
@@ -374,7 +376,8 @@ static int fused_dev_impl(lime_ctx *c, const uint32_t *d_lcp, const uint32_t *d_
                 while (bin_shift < REGION_SHIFT + 6 && bin_shift < BIN_SHIFT_MAX && bins_at(bin_shift + 1) >= 256) ++bin_shift;
         }
         n_bins = (uint32_t)bins_at(bin_shift);           // <= BIN_MAX: want_binned checked the table size
-        if ((rc = ensure_binned(c, n_own, grid * scan_waves_per_wg(ebwt, 0), grid, n_bins, bin_shift, &cap_w, st))) return rc;
+        n_sub = (uint32_t)((sim_bytes + 0xFFFFFFFFull) >> 32);
+        if ((rc = ensure_binned(c, n_own, grid * scan_waves_per_wg(ebwt, 0), grid, n_bins, bin_shift, n_sub, &cap_w, st))) return rc;
     }
     if ((rc = timing_mark(c, st))) return rc;
     if (keep_stats) {
@@ -388,7 +391,7 @@ static int fused_dev_impl(lime_ctx *c, const uint32_t *d_lcp, const uint32_t *d_
     ScanArgs a = base_args(c, d_lcp, d_da, d_ebwt, n_own, n_avail, eof, n_reads, n_refs, alpha, d_sim);
     if (d_edge) a.edge = d_edge;                          // a chunk of a stream: its own (cleared) word
     if (binned) {
-        a.upd_mode = 1; a.pool = c->d_pool; a.cap_w = cap_w; a.wave_cnt = c->d_wave_cnt; a.counts = c->d_counts;
+        a.upd_mode = 1; a.pool = c->d_pool; a.cap_w = cap_w; a.n_sub = n_sub; a.wave_cnt = c->d_wave_cnt; a.counts = c->d_counts;
         a.n_bins = n_bins; a.bin_shift = bin_shift; a.prod_waves = scan_waves_per_wg(ebwt, 0);
     }
     if ((rc = timing_mark(c, st))) return rc;
@@ -400,7 +403,7 @@ static int fused_dev_impl(lime_ctx *c, const uint32_t *d_lcp, const uint32_t *d_
         launch_scan_tiles(c->d_totals, c->d_binbase, n_bins, reinterpret_cast<unsigned long long *>(c->d_binbase + n_bins), st);
         launch_part(a, grid, c->d_binbase, c->d_recs, st);
         if (bin_shift > REGION_SHIFT) {                   // second level into the (by now free) pool, then regions from there
-            uint32_t *recs2 = reinterpret_cast<uint32_t *>(c->d_pool);
+            uint32_t *recs2 = c->d_pool;
             launch_part2(c->d_recs, c->d_binbase, n_bins, bin_shift, c->d_regbase, recs2, st);
             // the base after the last region = the total (regions past the table's end hold no records)
             HIP_TRY(hipMemcpyAsync(c->d_regbase + ((size_t)n_bins << (bin_shift - REGION_SHIFT)), c->d_binbase + n_bins, sizeof(uint64_t),

@@ -44,7 +44,8 @@ constexpr uint32_t REGION_SHIFT = 16;        // k_apply builds 2^16 = 64 KB of t
 constexpr uint32_t BIN_ONE_LEVEL = 1024;     // tables of up to this many regions: one bin per region, no second level
 constexpr uint32_t BIN_TWO_LEVEL = 2048;     // larger tables: at most this many bins of 2^k regions each (while k allows); measured best of 256..2048 on configs[2]
 constexpr uint32_t BIN_SHIFT_MAX = 25;       // bin-relative cell offset + 7 bits of t must fit 32 bits
-constexpr uint32_t CELL_BITS = 40;           // pool record: cell | t << 40
+constexpr uint32_t CELL_BITS = 40;           // a cell (byte index of the table) has at most this many bits
+constexpr uint32_t MAX_SUB = 8;              // binned updates: a pool record is the cell's low 32 bits, its high part the number of the wave's sub-region: tables up to 32 GB
 constexpr int APPLY_WG = 512;
 
 constexpr uint32_t BIG_GRID = 32;            // workgroups of k_score_big (each owns a scratch table)
@@ -81,8 +82,8 @@ struct ScanArgs {
     int ablate;                                  // timing experiments only (LIME_ABLATE_BUILD): 0 = full kernel
     // binned table updates (upd_mode 1; 0 = compare-and-swap on the table)
     int upd_mode;
-    uint64_t *pool; uint32_t cap_w;              // records of wave w: pool[w * cap_w ..), at most cap_w
-    uint32_t *wave_cnt;                          // records wave w wrote
+    uint32_t *pool; uint32_t cap_w, n_sub;       // 32-bit records of wave w, sub-region s (= high part of the cell): pool[(w * n_sub + s) * cap_w ..), at most cap_w each
+    uint32_t *wave_cnt;                          // [wave * n_sub + s]: records in that sub-region
     uint32_t prod_waves;                         // waves per workgroup of the scan that made them
     uint32_t *counts;                            // [n_bins][gridDim.x]: records of bin b counted by workgroup p
     uint32_t n_bins, bin_shift;                  // bin of a cell = cell >> bin_shift

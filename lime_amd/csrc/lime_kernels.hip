@@ -38,6 +38,7 @@ constexpr uint32_t CAP_D = 256;       // of those, clusters with a repeated docu
 // LDS is written and read through differently typed pointers (bytes as u16/u64, words as uint4):
 // these may_alias types keep the compiler from reordering such accesses under type-based aliasing.
 typedef volatile uint8_t __attribute__((address_space(3))) lds_vu8;
+typedef volatile uint32_t __attribute__((address_space(3))) lds_vu32;
 typedef uint16_t __attribute__((may_alias)) u16a;
 typedef uint64_t __attribute__((may_alias)) u64a;
 typedef uint4 __attribute__((may_alias)) u4a;
@@ -84,7 +85,7 @@ struct alignas(16) WaveLds {
 // threads per workgroup of k_scan (its waves work independently) and waves per SIMD it is compiled for: ScanCfg in
 // lime_kernels.h (EBWT = 0: 8 waves, two workgroups per CU = 4 waves per SIMD; EBWT = 1: 4 waves, three workgroups)
 constexpr uint32_t DUP_SLOTS = 8;     // clusters with a repeated document a wave of k_scan holds before scoring them
-constexpr uint32_t QCAP_SCAN = 272;   // >= the 256 hits one batch of 64 clusters of <= 4 symbols can add + the 15 records a binned drain leaves behind
+constexpr uint32_t QCAP_SCAN = 256;   // >= the 256 hits one batch of 64 clusters of <= 4 symbols can add
 
 __device__ __forceinline__ uint32_t lane_id() { return threadIdx.x & 63u; }
 __device__ __forceinline__ uint64_t brev64(uint64_t x) { return __builtin_bitreverse64(x); }
@@ -233,7 +234,7 @@ struct UpdQueue { uint32_t *qr, *qg; uint32_t n, cap;
     uint32_t f_first = 0, f_lost = 0; bool load_first = false;
     // binned mode (ScanArgs::upd_mode): drains append (cell, t) records to the wave's region of the pool and count
     // them per table bin in the workgroup's LDS histogram; no table access from the scan at all
-    bool binned = false; uint64_t *out = nullptr; uint32_t out_n = 0; uint32_t *hist = nullptr; bool flush_all = false;
+    bool binned = false; uint32_t *out = nullptr; lds_vu32 *sub_n = nullptr; uint32_t *hist = nullptr;   // out: the wave's n_sub sub-regions; sub_n: records in each (LDS)
 #ifdef LIME_PHASE_TIMING
     uint64_t t_drain = 0; uint32_t n_drain = 0;
 #endif
@@ -305,33 +306,37 @@ __device__ __forceinline__ void drain_async(UpdQueue &q, const ScanArgs &a)
 __device__ __forceinline__ void drain_bin(UpdQueue &q, const ScanArgs &a)
 {
     const uint32_t lane = lane_id();
-    // Only whole 128-byte lines leave (16 records; the wave's region starts line-aligned and out_n stays a multiple of
-    // 16): a store burst that starts or ends inside a line is a partial line write for the memory system.  The up to 15
-    // records left over move to the front of the queue; the last drain of the kernel (flush_all) takes everything.
-    const uint32_t nw = q.flush_all ? q.n : q.n & ~15u;
-    if (!nw) return;
-    for (uint32_t k0 = 0; k0 < nw; k0 += 64u) {
+    // A record is the LOW 32 bits of the cell; the high part picks one of the wave's n_sub sub-regions (one for tables
+    // below 4 GB) and the score is implicit: a pair that scores t > 1 (repeated documents only) leaves t records.  Every
+    // byte the scan stores costs its read stream dearly -- a gigabyte of appended records slows 8 GB of loads from 1.15 to
+    // 1.76 ms whatever the layout of the stores (tools/load_bench.hip) -- so the records are as short as they can be.
+    for (uint32_t k0 = 0; k0 < q.n; k0 += 64u) {
         const uint32_t k = k0 + lane;
-        const bool on = k < nw;
-        uint32_t gt = q.qg[on ? k : 0u], rd = q.qr[on ? k : 0u];
+        const bool on = k < q.n;
+        const uint32_t gt = q.qg[on ? k : 0u], rd = q.qr[on ? k : 0u];
         // the scan's fast emitters do not look at the document ids: a genome id beyond the table is caught here, on
-        // full waves (the record becomes "cell 0, t = 0", which the later stages skip; the pass fails with LIME_ERR_DOCID)
+        // full waves (the entry is dropped; the pass fails with LIME_ERR_DOCID)
         const bool bad = on && (gt & (MAX_REFS - 1u)) >= a.n_refs;
         if (__ballot(bad)) { if (bad) atomicOr(&a.stats->flags, LIME_FLAG_DOCID); }
-        if (bad) { gt = 0u; rd = 0u; }
         const uint64_t cell = (uint64_t)rd * a.n_refs + (gt & (MAX_REFS - 1u));
-        const uint32_t slot = q.out_n + k;
-        if (on && slot < a.cap_w) {
-            if (!ABL(7) && !ABL(9)) atomicAdd(&q.hist[(uint32_t)(cell >> a.bin_shift)], 1u);
-            if (!ABL(6) && !ABL(7)) __builtin_nontemporal_store(cell | ((uint64_t)(gt >> T_SHIFT) << CELL_BITS), &q.out[slot]);   // LIME_ABLATE=6: everything but the record stores
+        const uint32_t hi = (uint32_t)(cell >> 32);
+        uint32_t left = (on && !bad) ? gt >> T_SHIFT : 0u;
+        if (left && !ABL(7)) atomicAdd(&q.hist[(uint32_t)(cell >> a.bin_shift)], left);
+        while (__ballot(left != 0u)) {                            // once, unless a pair scored more than 1
+            for (uint32_t sub = 0; sub < a.n_sub; ++sub) {        // wave-uniform; one sub-region for tables below 4 GB
+                const bool mine = left != 0u && hi == sub;
+                const uint64_t m = __ballot(mine);
+                if (!m) continue;
+                const uint32_t base = q.sub_n[sub];               // LDS, one address: a broadcast read
+                const uint32_t slot = base + rank_in(m);
+                if (mine && slot < a.cap_w && !ABL(6) && !ABL(7))
+                    __builtin_nontemporal_store((uint32_t)cell, q.out + (size_t)sub * a.cap_w + slot);
+                if (lane == 0) q.sub_n[sub] = base + (uint32_t)__popcll(m);
+            }
+            left -= (uint32_t)(left != 0u);
         }
     }
-    const uint32_t left = q.n - nw;
-    if (left) {                                                   // wave-uniform
-        const uint32_t g2 = q.qg[nw + (lane < left ? lane : 0u)], r2 = q.qr[nw + (lane < left ? lane : 0u)];
-        if (lane < left) { q.qg[lane] = g2; q.qr[lane] = r2; }
-    }
-    q.out_n += nw; q.n = left;
+    q.n = 0;
 }
 
 __device__ __forceinline__ void drain(UpdQueue &q, const ScanArgs &a)
@@ -1023,6 +1028,7 @@ struct alignas(16) ScanLdsT {
     uint16_t listM[WIN / 2];
     uint16_t m_tstart[64];                   // the round's clusters of 9..SMALL_MAX symbols (position | (len-1) << 12)
     uint32_t q_read[QCAP_SCAN], q_gen[QCAP_SCAN];
+    uint32_t sub_n[MAX_SUB];                 // binned updates: records in each of the wave's sub-regions
     uint32_t g_doc[DUP_SLOTS][SMALL_MAX];
     uint8_t g_sym[EBWT ? DUP_SLOTS : 1][SMALL_MAX], g_len[DUP_SLOTS];
 };
@@ -1127,13 +1133,17 @@ __global__ __launch_bounds__(ScanCfg<EBWT>::wg) __attribute__((amdgpu_waves_per_
     if (!binned) { qu.nj = NJ; qu.fr = fslots + 192u * NJ * wave; qu.fg = qu.fr + 64u * NJ; qu.fe = qu.fr + 128u * NJ; }
     const uint32_t wave_gid = blockIdx.x * (SCANK_WG / 64) + wave;
     qu.binned = binned;
-    if (binned) { qu.out = a.pool + (size_t)wave_gid * a.cap_w; qu.hist = fslots; }
+    if (binned) {
+        qu.out = a.pool + (size_t)wave_gid * a.n_sub * a.cap_w; qu.hist = fslots; qu.sub_n = (lds_vu32 *)L.sub_n;
+        if (lane < MAX_SUB) L.sub_n[lane] = 0u;
+    }
     // binned mode, end of a wave: its record count; the workgroup's last wave writes the bin histogram
     auto finish_binned = [&]() {
-        if (lane == 0) {
-            a.wave_cnt[wave_gid] = qu.out_n < a.cap_w ? qu.out_n : a.cap_w;
-            atomicMax(&a.stats->wave_records_max, qu.out_n);
-            if (qu.out_n > a.cap_w) {                          // the pass's first overflow also counts the pass as unsettled
+        if (lane < a.n_sub) {
+            const uint32_t n = qu.sub_n[lane];
+            a.wave_cnt[(size_t)wave_gid * a.n_sub + lane] = n < a.cap_w ? n : a.cap_w;
+            atomicMax(&a.stats->wave_records_max, n);
+            if (n > a.cap_w) {                                 // the pass's first overflow also counts the pass as unsettled
                 const uint32_t old = atomicOr(&a.stats->flags, LIME_FLAG_POOL_FULL);
                 if (!(old & LIME_FLAG_POOL_FULL)) atomicAdd(a.sticky, 1u);
             }
@@ -1392,7 +1402,6 @@ __global__ __launch_bounds__(ScanCfg<EBWT>::wg) __attribute__((amdgpu_waves_per_
     }
     if (MODE == 0) {
         if (n_dup) acc_upd += dup_flush<EBWT>(L, n_dup, a, T, qu);
-        qu.flush_all = true;
         do drain(qu, a); while (qu.n != 0u || __ballot(qu.f_pend != 0u));      // until every update has landed
         if (binned) finish_binned();
     }
@@ -1660,43 +1669,42 @@ __global__ __launch_bounds__(PART_WG) void k_part(ScanArgs a, const uint64_t *bi
         cnt[b] = 0u;
     }
     __syncthreads();
-    const uint64_t cmask = (1ull << CELL_BITS) - 1ull;
     const uint32_t omask = (1u << a.bin_shift) - 1u;
     static_assert(BIN_MAX <= 4096 && PART_TILE <= (1u << 20), "bin | rank << 12 must fit 32 bits");
-    // the producer's four wave regions as one sequence of tiles; the next tile's records are loaded while the
-    // current one goes through LDS
-    // the producer's wave regions (wpp of them) as one sequence of tiles
-    const uint32_t wpp = a.prod_waves;
-    auto seg_n = [&](uint32_t w) { return a.wave_cnt[blockIdx.x * wpp + w]; };
-    auto load_tile = [&](uint32_t w, uint32_t t0, uint64_t (&rec)[PART_PER]) {
-        const uint64_t *src = a.pool + (size_t)(blockIdx.x * wpp + w) * a.cap_w + t0;
+    // the producer's segments -- (wave, sub-region): 32-bit records, the cell's high part is the sub-region's number --
+    // as one sequence of tiles; the next tile's records are loaded while the current one goes through LDS
+    const uint32_t n_seg = a.prod_waves * a.n_sub, seg0 = blockIdx.x * n_seg;
+    auto seg_n = [&](uint32_t w) { return a.wave_cnt[seg0 + w]; };
+    auto load_tile = [&](uint32_t w, uint32_t t0, uint32_t (&rec)[PART_PER]) {
+        const uint32_t *src = a.pool + (size_t)(seg0 + w) * a.cap_w + t0;
         const uint32_t n = seg_n(w), tn = n - t0 < PART_TILE ? n - t0 : PART_TILE;
 #pragma unroll
         for (uint32_t j = 0; j < PART_PER; ++j) {
             const uint32_t i = j * PART_WG + tid;
-            rec[j] = i < tn ? __builtin_nontemporal_load(src + i) : ~0ull;
+            rec[j] = i < tn ? __builtin_nontemporal_load(src + i) : 0u;
         }
     };
     uint32_t w = 0, t0 = 0;
-    while (w < wpp && seg_n(w) == 0u) ++w;
-    uint64_t rec[PART_PER];
-    if (w < wpp) load_tile(w, t0, rec);
-    while (w < wpp) {
+    while (w < n_seg && seg_n(w) == 0u) ++w;
+    uint32_t rec[PART_PER];
+    if (w < n_seg) load_tile(w, t0, rec);
+    while (w < n_seg) {
         const uint32_t n = seg_n(w), tn = n - t0 < PART_TILE ? n - t0 : PART_TILE;
+        const uint64_t hi = (uint64_t)(w % a.n_sub) << 32;
         uint32_t val[PART_PER], dr[PART_PER];
 #pragma unroll
         for (uint32_t j = 0; j < PART_PER; ++j) {
             dr[j] = ~0u; val[j] = 0u;
-            if (rec[j] != ~0ull) {
-                const uint64_t cell = rec[j] & cmask;
+            if (j * PART_WG + tid < tn) {
+                const uint64_t cell = hi | rec[j];
                 const uint32_t d = (uint32_t)(cell >> a.bin_shift);
                 dr[j] = d | (atomicAdd(&cnt[d], 1u) << 12);
-                val[j] = ((uint32_t)cell & omask) | ((uint32_t)(rec[j] >> CELL_BITS) << a.bin_shift);
+                val[j] = ((uint32_t)cell & omask) | (1u << a.bin_shift);     // t = 1
             }
         }
         t0 += PART_TILE;                                     // the next tile, if any: its loads go out now
-        if (t0 >= n) { t0 = 0; ++w; while (w < wpp && seg_n(w) == 0u) ++w; }
-        if (w < wpp) load_tile(w, t0, rec);
+        if (t0 >= n) { t0 = 0; ++w; while (w < n_seg && seg_n(w) == 0u) ++w; }
+        if (w < n_seg) load_tile(w, t0, rec);
         __syncthreads();
         part_scan(cnt, toff, a.n_bins, wsum);
 #pragma unroll
@@ -1846,7 +1854,7 @@ __global__ __launch_bounds__(APPLY_WG) void k_apply(uint8_t *sim, size_t sim_byt
     __syncthreads();
     uint4 *dst = reinterpret_cast<uint4 *>(sim + reg_base);
     const size_t left = (sim_bytes - reg_base) / 16u;            // sim_bytes is a multiple of 16
-    for (uint32_t i = threadIdx.x; i < RW / 4 && i < left; i += APPLY_WG) dst[i] = reg4[i];
+    for (uint32_t i = threadIdx.x; i < RW / 4 && i < left; i += APPLY_WG) dst[i] = reg4[i];     // (non-temporal stores here: no gain, tools/r03_ab2.sh)
 }
 
 // =========================================================================================

@@ -158,6 +158,13 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))) voi
             if (lane == 0) base = atomicAdd(cursor, (unsigned long long)recs);
             base = ((unsigned long long)__builtin_amdgcn_readfirstlane((int)(base >> 32)) << 32) | (unsigned)__builtin_amdgcn_readfirstlane((int)base);
             for (uint32_t k0 = 0; k0 < recs; k0 += 64u) __builtin_nontemporal_store(((uint64_t)part << 8) | lane, pool + (base + k0 + lane) % ((size_t)gridDim.x * 4u * cap_w));
+        } else if (SMODE == 9 || SMODE == 10) {
+            const uint32_t ring = cap_w;                       // records in the wave's ring (the launch passes a small cap_w)
+            for (uint32_t k0 = 0; k0 < recs; k0 += 64u) {
+                const uint32_t at = (out_n + k0 + lane) % ring;
+                if (SMODE == 9) __builtin_nontemporal_store(((uint64_t)part << 8) | lane, reg + at); else reg[at] = ((uint64_t)part << 8) | lane;
+            }
+            out_n += recs;
         } else if (SMODE == 8) {
             uint32_t *r4 = reinterpret_cast<uint32_t *>(reg);
             for (uint32_t k0 = 0; k0 < recs; k0 += 64u) if (out_n + k0 + lane < 2u * cap_w) __builtin_nontemporal_store(part + lane, r4 + out_n + k0 + lane);
@@ -165,6 +172,44 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))) voi
         } else
         if (SMODE != 0 && SMODE != 4) stores(part);
         ++iter;
+        acc += part;
+        if (next >= n_win) break;
+        win = next;
+    }
+    if (acc == 0x12345678u || alpha == 0xFFFFFFFFu) out[0] = acc + pad[lane];
+}
+
+// decoupled: waves 0..2 of a workgroup only load (pattern A); wave 3 only stores, at the pace of its siblings (3 x recs records per step)
+template <int NT>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))) void k_split(const uint32_t *lcp, const uint32_t *da, uint32_t n_win, uint32_t alpha,
+                                                                                           uint64_t *pool, uint32_t cap_w, uint32_t recs, uint32_t *out)
+{
+    __shared__ uint32_t pad[48 * 256];
+    const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
+    if (alpha == 0xFFFFFFFFu) pad[threadIdx.x] = lane;
+    const uint32_t stride = gridDim.x * 3u;
+    if (wave == 3u) {
+        uint64_t *reg = pool + (size_t)blockIdx.x * 4u * cap_w;
+        uint32_t out_n = 0;
+        for (uint32_t w = blockIdx.x * 3u; w < n_win; w += stride) {
+            for (uint32_t k0 = 0; k0 < 3u * recs; k0 += 64u) {
+                const uint32_t k = out_n + k0 + lane;
+                if (k < 4u * cap_w) { if (NT) __builtin_nontemporal_store(((uint64_t)w << 8) | lane, reg + k); else reg[k] = ((uint64_t)w << 8) | lane; }
+            }
+            out_n += 3u * recs;
+            __builtin_amdgcn_s_sleep(64);
+        }
+        return;
+    }
+    uint32_t win = blockIdx.x * 3u + wave, acc = 0;
+    if (win >= n_win) return;
+    Regs<0> a;
+    load_win<0>(a, lcp, da, (uint64_t)win * WIN, lane);
+    for (;;) {
+        Regs<0> cur = a;
+        const uint32_t next = win + stride;
+        uint32_t part = consume<0>(cur, alpha);
+        if (next < n_win) load_win<0>(a, lcp, da, (uint64_t)next * WIN, lane);
         acc += part;
         if (next >= n_win) break;
         win = next;
@@ -240,6 +285,16 @@ int main(int argc, char **argv)
         timeit("A + 4 KB bursts every 4th window", b2, [&] { hipLaunchKernelGGL((k_mix<5>), g3, blk, 0, 0, lcp, da, n_win, 16u, pool, cap_w, recs, out); });
         timeit("A + one stream per workgroup (4 x 1 KB adjacent)", b2, [&] { hipLaunchKernelGGL((k_mix<6>), g3, blk, 0, 0, lcp, da, n_win, 16u, pool, cap_w, recs, out); });
         timeit("A + ONE global stream (atomic cursor)", b2, [&] { CK(hipMemsetAsync(out, 0, 64)); hipLaunchKernelGGL((k_mix<7>), g3, blk, 0, 0, lcp, da, n_win, 16u, pool, cap_w, recs, out); });
+        for (uint32_t ring : {512u, 2048u, 8192u}) {
+            char nm[128];
+            snprintf(nm, sizeof nm, "A + nt stores into a %u-record ring per wave (%.0f MB pool)", ring, n_waves * (double)ring * 8 / 1e6);
+            timeit(nm, b2, [&] { hipLaunchKernelGGL((k_mix<9>), g3, blk, 0, 0, lcp, da, n_win, 16u, pool, ring, recs, out); });
+            snprintf(nm, sizeof nm, "A + plain stores into a %u-record ring per wave (%.0f MB pool)", ring, n_waves * (double)ring * 8 / 1e6);
+            timeit(nm, b2, [&] { hipLaunchKernelGGL((k_mix<10>), g3, blk, 0, 0, lcp, da, n_win, 16u, pool, ring, recs, out); });
+        }
+        timeit("split: 3 loading waves + 1 storing wave per workgroup, no stores", bytes, [&] { hipLaunchKernelGGL((k_split<1>), g3, blk, 0, 0, lcp, da, n_win, 16u, pool, cap_w, 0u, out); });
+        timeit("split: 3 loading waves + 1 storing wave (nt, 1 GB)", b2, [&] { hipLaunchKernelGGL((k_split<1>), g3, blk, 0, 0, lcp, da, n_win, 16u, pool, cap_w, recs, out); });
+        timeit("split: 3 loading waves + 1 storing wave (plain, 1 GB)", b2, [&] { hipLaunchKernelGGL((k_split<0>), g3, blk, 0, 0, lcp, da, n_win, 16u, pool, cap_w, recs, out); });
         timeit("A + 4-byte records (0.5 GB)", bytes + (uint64_t)n_win * recs * 4, [&] { hipLaunchKernelGGL((k_mix<8>), g3, blk, 0, 0, lcp, da, n_win, 16u, pool, cap_w, recs, out); });
         timeit("A + 64 records per window (0.5 GB)", bytes + (uint64_t)n_win * 64 * 8, [&] { hipLaunchKernelGGL((k_mix<1>), g3, blk, 0, 0, lcp, da, n_win, 16u, pool, cap_w, 64u, out); });
         timeit("A + 32 records per window (0.25 GB)", bytes + (uint64_t)n_win * 32 * 8, [&] { hipLaunchKernelGGL((k_mix<1>), g3, blk, 0, 0, lcp, da, n_win, 16u, pool, cap_w, 32u, out); });
