@@ -88,6 +88,15 @@ constexpr uint32_t DUP_SLOTS = 8;     // clusters with a repeated document a wav
 constexpr uint32_t QCAP_SCAN = 256;   // >= the 256 hits one batch of 64 clusters of <= 4 symbols can add
 
 __device__ __forceinline__ uint32_t lane_id() { return threadIdx.x & 63u; }
+// The kernel's ScanArgs (always its first argument) re-read from the kernarg segment at the point of use: fields that only
+// rare paths need (counters, flags, the long-cluster list ...) then cost a scalar load there instead of SGPRs held through
+// the whole window loop -- the scan kernels were 2..40 SGPRs over budget and spilled them into VGPR lanes.
+__device__ __forceinline__ const ScanArgs &cold(const ScanArgs &)
+{
+    const ScanArgs __attribute__((address_space(4))) *p = (const ScanArgs __attribute__((address_space(4))) *)__builtin_amdgcn_kernarg_segment_ptr();
+    asm volatile("" : "+s"(p));                               // opaque: not merged with the by-value copy, not hoisted
+    return *(const ScanArgs *)p;
+}
 __device__ __forceinline__ uint64_t brev64(uint64_t x) { return __builtin_bitreverse64(x); }
 __device__ __forceinline__ uint32_t rl32(uint32_t v, uint32_t l) { return (uint32_t)__builtin_amdgcn_readlane((int)v, (int)l); }
 // v with lane L replaced by the wave-uniform value s (this compiler has no v_writelane builtin).  On gfx940/gfx950 a
@@ -273,7 +282,7 @@ __device__ __forceinline__ void drain_async(UpdQueue &q, const ScanArgs &a)
         if (fre && r < n) {
             const uint32_t k = n - 1u - r;
             const uint32_t gt = q.qg[k];
-            if ((gt & ((1u << T_SHIFT) - 1u)) >= a.n_refs) atomicOr(&a.stats->flags, LIME_FLAG_DOCID);   // dropped: see drain_bin
+            if ((gt & ((1u << T_SHIFT) - 1u)) >= a.n_refs) atomicOr(&cold(a).stats->flags, LIME_FLAG_DOCID);   // dropped: see drain_bin
             else {
                 q.fr[64u * (uint32_t)j + lane] = q.qr[k]; q.fg[64u * (uint32_t)j + lane] = gt;
                 q.fe[64u * (uint32_t)j + lane] = 0u;
@@ -317,7 +326,7 @@ __device__ __forceinline__ void drain_bin(UpdQueue &q, const ScanArgs &a)
         // the scan's fast emitters do not look at the document ids: a genome id beyond the table is caught here, on
         // full waves (the entry is dropped; the pass fails with LIME_ERR_DOCID)
         const bool bad = on && (gt & (MAX_REFS - 1u)) >= a.n_refs;
-        if (__ballot(bad)) { if (bad) atomicOr(&a.stats->flags, LIME_FLAG_DOCID); }
+        if (__ballot(bad)) { if (bad) atomicOr(&cold(a).stats->flags, LIME_FLAG_DOCID); }
         const uint64_t cell = (uint64_t)rd * a.n_refs + (gt & (MAX_REFS - 1u));
         const uint32_t hi = (uint32_t)(cell >> 32);
         uint32_t left = (on && !bad) ? gt >> T_SHIFT : 0u;
@@ -389,7 +398,7 @@ __device__ __forceinline__ uint32_t emit(UpdQueue &q, const ScanArgs &a, bool on
     while (q.n + 64u > q.cap) drain(q, a);
     const uint32_t g = gdoc - a.n_reads;
     const bool bad = on && (g >= a.n_refs || rdoc >= a.n_reads);
-    if (__ballot(bad)) { if (bad) atomicOr(&a.stats->flags, LIME_FLAG_DOCID); }
+    if (__ballot(bad)) { if (bad) atomicOr(&cold(a).stats->flags, LIME_FLAG_DOCID); }
     on = on && !bad;
     const uint64_t m = __ballot(on);
     if (on) {
@@ -632,7 +641,7 @@ __device__ __forceinline__ uint32_t score_len2(LDS &L, const WgTables &T, UpdQue
     if (EBWT) hit = hit && ((T.compatb[L.fl[p]] >> T.symidx[L.fl[p + 1u]]) & 1u);
     const uint32_t rd = r0 ? d0 : d1, gd = (r0 ? d1 : d0) - a.n_reads;
     const bool bad = hit && gd >= a.n_refs;
-    if (__ballot(bad)) { if (bad) atomicOr(&a.stats->flags, LIME_FLAG_DOCID); }
+    if (__ballot(bad)) { if (bad) atomicOr(&cold(a).stats->flags, LIME_FLAG_DOCID); }
     hit = hit && !bad;
     const uint64_t m = __ballot(hit);
     const uint32_t tot = (uint32_t)__popcll(m);
@@ -702,7 +711,7 @@ __device__ __forceinline__ uint32_t score_small(LDS &L, const WgTables &T, UpdQu
                 }
             }
     }
-    if (__ballot(bad != 0u)) { if (bad) atomicOr(&a.stats->flags, LIME_FLAG_DOCID); }
+    if (__ballot(bad != 0u)) { if (bad) atomicOr(&cold(a).stats->flags, LIME_FLAG_DOCID); }
     qu.n += total;
     return nh + nflush;
 }
@@ -809,7 +818,7 @@ __device__ __forceinline__ uint32_t score_medium(LDS &L, const WgTables &T, UpdQ
                                 qu.qr[slot] = ri ? di : dj; qu.qg[slot] = gd | (1u << T_SHIFT);
                                 ++slot;
                             }
-                        if (__ballot(bad != 0u)) { if (bad) atomicOr(&a.stats->flags, LIME_FLAG_DOCID); }
+                        if (__ballot(bad != 0u)) { if (bad) atomicOr(&cold(a).stats->flags, LIME_FLAG_DOCID); }
                         qu.n += tot; nupd += take;
                     }
                 }
@@ -964,22 +973,23 @@ template <int EBWT>
 __device__ __forceinline__ void window_load(WinRegs &t, const ScanArgs &a, uint64_t lo)
 {
     const uint32_t lane = lane_id();
-    const uint32_t *lp = a.lcp + lo + lane, *dp = a.da + lo + lane;
-    if (lo + WIN <= a.n_avail) {                           // wave-uniform: the whole window is data
+    const ScanArgs &c = EBWT ? cold(a) : a;                // EBWT = 1 (SGPRs short): array pointers and length as scalar loads per window, not held through the loop
+    const uint32_t *lp = c.lcp + lo + lane, *dp = c.da + lo + lane;
+    if (lo + WIN <= c.n_avail) {                           // wave-uniform: the whole window is data
 #pragma unroll
         for (int j = 0; j < (int)PPL; ++j) { t.lv[j] = LIME_STREAM_LOAD(lp + 64 * j); t.dv[j] = LIME_STREAM_LOAD(dp + 64 * j); }
 #pragma unroll
         for (int k = 0; k < (int)PPL / 4; ++k)
-            t.bv[k] = EBWT ? LIME_STREAM_LOAD(reinterpret_cast<const u32u *>(a.ebwt + lo + 256u * (uint32_t)k + 4u * lane)) : 0u;
+            t.bv[k] = EBWT ? LIME_STREAM_LOAD(reinterpret_cast<const u32u *>(c.ebwt + lo + 256u * (uint32_t)k + 4u * lane)) : 0u;
     } else {
         // the last window of the data: addresses clamped to the last element (what the padding
         // positions read is never used: the masks mark them), ebwt byte by byte
-        const uint64_t left = a.n_avail > lo ? a.n_avail - lo : 0ull;      // valid positions of the window (> 0)
+        const uint64_t left = c.n_avail > lo ? c.n_avail - lo : 0ull;      // valid positions of the window (> 0)
         const uint32_t last = (uint32_t)left - 1u;
 #pragma unroll
         for (int j = 0; j < (int)PPL; ++j) {
             const uint32_t p = 64u * (uint32_t)j + lane, q = p < last ? p : last;
-            t.lv[j] = a.lcp[lo + q]; t.dv[j] = a.da[lo + q];
+            t.lv[j] = c.lcp[lo + q]; t.dv[j] = c.da[lo + q];
             // opaque to the optimiser: otherwise it folds these loads with the fast path's into one load
             // through a selected 64-bit address per register (32 address pairs of VGPRs, no `nt`)
             asm volatile("" : "+v"(t.lv[j]), "+v"(t.dv[j]));
@@ -991,17 +1001,17 @@ __device__ __forceinline__ void window_load(WinRegs &t, const ScanArgs &a, uint6
 #pragma unroll
                 for (int b = 0; b < 4; ++b) {
                     const uint32_t p = 256u * (uint32_t)k + 4u * lane + (uint32_t)b;
-                    w |= (uint32_t)a.ebwt[lo + (p < last ? p : last)] << (8 * b);
+                    w |= (uint32_t)c.ebwt[lo + (p < last ? p : last)] << (8 * b);
                 }
             asm volatile("" : "+v"(w));
             t.bv[k] = w;
         }
     }
     const uint64_t hp = lo + WIN + lane;
-    const bool hok = lane < HALO && hp < a.n_avail;
-    t.hl = hok ? a.lcp[hp] : 0u;
-    t.hd = hok ? a.da[hp] : 0u;
-    t.hb = (EBWT && hok) ? a.ebwt[hp] : 0u;
+    const bool hok = lane < HALO && hp < c.n_avail;
+    t.hl = hok ? c.lcp[hp] : 0u;
+    t.hd = hok ? c.da[hp] : 0u;
+    t.hb = (EBWT && hok) ? c.ebwt[hp] : 0u;
 }
 
 // =========================================================================================
@@ -1048,9 +1058,9 @@ struct Ctx16 {
 // Shorter (a caller with a halo below LIME_MAX_CLUSTER): cannot be decided here -> LIME_FLAG_HALO.
 __device__ __forceinline__ void open_run_at_end(const ScanArgs &a, uint64_t len_so_far, bool has_r, bool has_g)
 {
-    if (len_so_far <= LIME_MAX_CLUSTER) { atomicOr(&a.stats->flags, LIME_FLAG_HALO); return; }
-    if (has_r && has_g) { atomicOr(&a.stats->flags, LIME_FLAG_MAXLEN); return; }
-    atomicOr(a.edge, LIME_EDGE_OPEN | (has_r ? LIME_EDGE_OPEN_R : 0u) | (has_g ? LIME_EDGE_OPEN_G : 0u));
+    if (len_so_far <= LIME_MAX_CLUSTER) { atomicOr(&cold(a).stats->flags, LIME_FLAG_HALO); return; }
+    if (has_r && has_g) { atomicOr(&cold(a).stats->flags, LIME_FLAG_MAXLEN); return; }
+    atomicOr(cold(a).edge, LIME_EDGE_OPEN | (has_r ? LIME_EDGE_OPEN_R : 0u) | (has_g ? LIME_EDGE_OPEN_G : 0u));
 }
 
 // H64 / R64 / G64: the read-ahead chunk (16 bits, wave-uniform).  own_lim <= WIN.
@@ -1141,11 +1151,11 @@ __global__ __launch_bounds__(ScanCfg<EBWT>::wg) __attribute__((amdgpu_waves_per_
     auto finish_binned = [&]() {
         if (lane < a.n_sub) {
             const uint32_t n = qu.sub_n[lane];
-            a.wave_cnt[(size_t)wave_gid * a.n_sub + lane] = n < a.cap_w ? n : a.cap_w;
-            atomicMax(&a.stats->wave_records_max, n);
+            cold(a).wave_cnt[(size_t)wave_gid * a.n_sub + lane] = n < a.cap_w ? n : a.cap_w;
+            atomicMax(&cold(a).stats->wave_records_max, n);
             if (n > a.cap_w) {                                 // the pass's first overflow also counts the pass as unsettled
-                const uint32_t old = atomicOr(&a.stats->flags, LIME_FLAG_POOL_FULL);
-                if (!(old & LIME_FLAG_POOL_FULL)) atomicAdd(a.sticky, 1u);
+                const uint32_t old = atomicOr(&cold(a).stats->flags, LIME_FLAG_POOL_FULL);
+                if (!(old & LIME_FLAG_POOL_FULL)) atomicAdd(cold(a).sticky, 1u);
             }
         }
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
@@ -1154,7 +1164,7 @@ __global__ __launch_bounds__(ScanCfg<EBWT>::wg) __attribute__((amdgpu_waves_per_
         old = (uint32_t)__builtin_amdgcn_readfirstlane((int)old);
         if (old == SCANK_WG / 64 - 1) {
             __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
-            for (uint32_t b = lane; b < a.n_bins; b += 64u) a.counts[(size_t)b * gridDim.x + blockIdx.x] = qu.hist[b];
+            for (uint32_t b = lane; b < cold(a).n_bins; b += 64u) cold(a).counts[(size_t)b * gridDim.x + blockIdx.x] = qu.hist[b];
         }
     };
     if (win >= n_win) { if (binned) finish_binned(); return; }
@@ -1162,13 +1172,13 @@ __global__ __launch_bounds__(ScanCfg<EBWT>::wg) __attribute__((amdgpu_waves_per_
     window_load<EBWT>(regs, a, (uint64_t)win * WIN);
     uint32_t acc_n = 0, acc_max = 0, acc_upd = 0;          // per-lane partial counters, reduced once at the end
     uint32_t n_dup = 0;                                    // clusters waiting in the wave's dup store
-    const uint64_t lt = (1ull << lane) - 1ull;
     PT_DECL
     for (;;) {
         PT_WAITVM PT(0)
         const uint64_t lo = (uint64_t)win * WIN;
-        const uint32_t own_lim = (uint32_t)(a.n_own > lo ? (a.n_own - lo < WIN ? a.n_own - lo : (uint64_t)WIN) : 0ull);
-        const uint64_t lim64 = a.n_avail - lo;             // valid positions of the window + read-ahead: [0, lim)
+        const uint64_t n_own_ = (EBWT ? cold(a) : a).n_own;
+        const uint32_t own_lim = (uint32_t)(n_own_ > lo ? (n_own_ - lo < WIN ? n_own_ - lo : (uint64_t)WIN) : 0ull);
+        const uint64_t lim64 = (EBWT ? cold(a) : a).n_avail - lo;             // valid positions of the window + read-ahead: [0, lim)
         const uint32_t lim = (uint32_t)(lim64 < WPOS ? lim64 : (uint64_t)WPOS);
         // ---- stage the window in LDS and build the masks.  Loads are lane-strided (register j of lane l =
         // position 64 j + l: every load instruction reads 64 consecutive elements -- a lane reading its own 16
@@ -1223,7 +1233,8 @@ __global__ __launch_bounds__(ScanCfg<EBWT>::wg) __attribute__((amdgpu_waves_per_
         }
         // ---- the next window's loads go out now and land while this one is processed ----------
         const uint32_t next = win + stride;
-        if (next < n_win) window_load<EBWT>(regs, a, (uint64_t)next * WIN);
+        const uint32_t n_win_ = (EBWT ? cold(a) : a).n_tiles;
+        if (next < n_win_) window_load<EBWT>(regs, a, (uint64_t)next * WIN);
 
         PT(1)
         if (!ABL(1)) {                               // LIME_ABLATE: timing experiments, cut after a phase
@@ -1240,9 +1251,9 @@ __global__ __launch_bounds__(ScanCfg<EBWT>::wg) __attribute__((amdgpu_waves_per_
                         const uint64_t whigh = (lw == 63u) ? 0ull : (~0ull << (lw + 1u));
                         const uint32_t suf = (((c.RW & whigh) || ((li >> 12) & 1u)) ? 1u : 0u) | (((c.GW & whigh) || ((li >> 13) & 1u)) ? 2u : 0u);
                         if (lane == 0) {
-                            const uint32_t k = atomicAdd(&a.stats->n_open, 1u);  // at most one per window: the list holds n_tiles records
+                            const uint32_t k = atomicAdd(&cold(a).stats->n_open, 1u);  // at most one per window: the list holds n_tiles records
                             OpenRec orec; orec.start = lo + last; orec.flags = suf; orec.pad = 0u;
-                            a.open[k] = orec;
+                            cold(a).open[k] = orec;
                         }
                     }
                 }
@@ -1262,7 +1273,7 @@ __global__ __launch_bounds__(ScanCfg<EBWT>::wg) __attribute__((amdgpu_waves_per_
             }
             // a run closed by padding instead of data while more data exists beyond the shard's
             // halo: the last data head in sight is owned and nothing but padding follows it
-            if (!a.eof && lim < WPOS && Hd64 == 0u) {
+            if (lim < WPOS && Hd64 == 0u && !cold(a).eof) {
                 const uint32_t dh = hb & vb;
                 const uint64_t dw = __ballot(dh != 0u);
                 if (dw) {
@@ -1270,13 +1281,13 @@ __global__ __launch_bounds__(ScanCfg<EBWT>::wg) __attribute__((amdgpu_waves_per_
                     const uint32_t hl2 = rl32(dh, lw2);
                     const uint32_t bp = 31u - (uint32_t)__builtin_clz(hl2), sstar = PPL * lw2 + bp;
                     if (MODE == 1) {                           // detection alone has no length limit: the host starts over with one chunk
-                        if (lane == 0 && sstar < own_lim) atomicOr(&a.stats->flags, LIME_FLAG_HALO);
+                        if (lane == 0 && sstar < own_lim) atomicOr(&cold(a).stats->flags, LIME_FLAG_HALO);
                     } else {
                         // what the open run holds so far: its head's chunk from the head on, the chunks after it, the read-ahead
                         const uint32_t cm = lane > lw2 ? 0xFFFFu : (lane == lw2 ? (0xFFFFu << bp) & 0xFFFFu : 0u);
                         const bool hr = __ballot((rb & vb & cm) != 0u) != 0ull || R64 != 0u;
                         const bool hg = __ballot((gb & cm) != 0u) != 0ull || G64 != 0u;
-                        if (lane == 0 && sstar < own_lim) open_run_at_end(a, a.n_avail - (lo + sstar), hr, hg);
+                        if (lane == 0 && sstar < own_lim) open_run_at_end(a, cold(a).n_avail - (lo + sstar), hr, hg);
                     }
                 }
             }
@@ -1332,8 +1343,8 @@ __global__ __launch_bounds__(ScanCfg<EBWT>::wg) __attribute__((amdgpu_waves_per_
                                 }
                                 len = e - p;
                                 if (len > MID_MAX) {                          // one workgroup per such cluster later
-                                    const uint32_t kk = atomicAdd(&a.stats->n_big, 1u);
-                                    if (kk < a.big_cap) { a.big[kk].pStart = lo + p; a.big[kk].len = len; }
+                                    const uint32_t kk = atomicAdd(&cold(a).stats->n_big, 1u);
+                                    if (kk < cold(a).big_cap) { cold(a).big[kk].pStart = lo + p; cold(a).big[kk].len = len; }
                                 }
                             }
                             // SMALL_MAX+1 .. MID_MAX symbols (rare): the whole wave is one lane group on the staged window, one cluster at a time
@@ -1397,7 +1408,7 @@ __global__ __launch_bounds__(ScanCfg<EBWT>::wg) __attribute__((amdgpu_waves_per_
         }
         }
         }
-        if (next >= n_win) break;
+        if (next >= n_win_) break;
         win = next;
     }
     if (MODE == 0) {
@@ -1415,9 +1426,9 @@ __global__ __launch_bounds__(ScanCfg<EBWT>::wg) __attribute__((amdgpu_waves_per_
     {
         const uint32_t tn = wave_sum(acc_n), tm = wave_max(acc_max), tu = wave_sum(acc_upd);
         if (lane == 0) {
-            if (tn) atomicAdd(&a.stats->n_clusters, (unsigned long long)tn);
-            if (tm) atomicMax(&a.stats->max_len, (unsigned long long)tm);
-            if (MODE == 0 && tu) atomicAdd(&a.stats->n_updates, (unsigned long long)tu);
+            if (tn) atomicAdd(&cold(a).stats->n_clusters, (unsigned long long)tn);
+            if (tm) atomicMax(&cold(a).stats->max_len, (unsigned long long)tm);
+            if (MODE == 0 && tu) atomicAdd(&cold(a).stats->n_updates, (unsigned long long)tu);
         }
     }
 }

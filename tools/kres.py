@@ -15,3 +15,16 @@ for blk in re.split(r"\n  - \.agpr_count:", md)[1:]:
                      lds=int(g("group_segment_fixed_size")), scratch=int(g("private_segment_fixed_size")), waves_by_vgpr=min(8, 512 // alloc))
     print(f"{name[:60]:60s} vgpr {v:4d} sgpr {out[name]['sgpr']:4d} sspill {out[name]['sgpr_spill']:3d} vspill {out[name]['vgpr_spill']:3d} lds {out[name]['lds']:6d} scratch {out[name]['scratch']:4d} waves/simd {out[name]['waves_by_vgpr']}")
 if len(sys.argv) > 3: json.dump(out, open(sys.argv[3], "w"), indent=1)
+if "--gate" in sys.argv:
+    bad = []
+    for name, r in out.items():
+        if "k_scanI" not in name: continue
+        ebwt = "k_scanILi1" in name
+        want_waves = 3 if ebwt else 4
+        if r["vgpr_spill"] or r["scratch"]: bad.append(f"{name}: VGPR spills / scratch")
+        if r["waves_by_vgpr"] < want_waves: bad.append(f"{name}: {r['vgpr']} VGPRs allow {r['waves_by_vgpr']} waves per SIMD, planned {want_waves}")
+        if r["lds"] * (2 if not ebwt else 3) > 160 * 1024: bad.append(f"{name}: {r['lds']} B of LDS do not fit the planned workgroups per CU")
+        if r["sgpr_spill"] > (8 if ebwt else 0): bad.append(f"{name}: {r['sgpr_spill']} SGPR spills")
+    if bad:
+        print("RESOURCE GATE FAILED:\n  " + "\n  ".join(bad)); sys.exit(1)
+    print("resource gate ok")
