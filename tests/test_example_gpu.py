@@ -1,0 +1,49 @@
+"""BASELINE.json configs[0] at the example's full size (README.md:125-131): all 20 000 example reads, paired-end, the four
+collections of LiME_paired.sh:44-79 -- four ClusterLCP started together, four ClusterBWT_DA one after the other, Classify 4 --
+with the drop-in programs (GPU for the two cluster steps).  Every file must be byte-identical to what the reference's own
+programs wrote for the same inputs (tests/golden/example_full.npz: sha256 of the intermediates, the whole classification file;
+made by tests/golden/make_golden_example.py with oracle/_ref), and every read of a database genome must be assigned to its
+source's species, every control read to none.  example/refs.fasta is absent: the genomes are surrogates built from the reads
+(see the generating script)."""
+import hashlib
+import os
+import sys
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.join(ROOT, "tests", "golden"))
+OURS = os.path.join(ROOT, "lime_amd", "bin")
+
+
+def test_example_paired_end_chain_matches_reference(tmp_path):
+    import make_golden_example as G
+    z = np.load(os.path.join(ROOT, "tests", "golden", "example_full.npz"))
+    genomes, sets = G.collections(z["reads_1"], z["reads_2"], z["src"])
+    files = G.run_chain(OURS, str(tmp_path), genomes, sets, len(z["reads_1"]), bytes(z["lineage"]), concurrent=True)
+    want = dict(zip([str(x) for x in z["file_names"]], zip([str(x) for x in z["file_sha256"]], [int(x) for x in z["file_sizes"]])))
+    assert sorted(files) == sorted(want)
+    for name, data in files.items():
+        assert (hashlib.sha256(data).hexdigest(), len(data)) == want[name], name
+    assert files["classification.txt"] == bytes(z["classification"])
+    # the assignments themselves: species of the source genome (LineageFile column 2), none for the control accession
+    tax = {}
+    for row in bytes(z["lineage"]).decode().splitlines()[1:]:
+        f = row.split(";")
+        tax[f[0]] = f[1]
+    species = [tax[a] for a in G.DB]
+    right = wrong = ctrl_hit = 0
+    for ln in files["classification.txt"].decode().splitlines()[1:]:
+        kind, rid, taxid, _ = ln.split(",")
+        s = int(z["src"][int(rid)])
+        if s >= 0:
+            if kind == "C" and taxid == species[s]:
+                right += 1
+            else:
+                wrong += 1
+        elif kind != "U":
+            ctrl_hit += 1
+    assert (right, wrong, ctrl_hit) == (int((z["src"] >= 0).sum()), 0, 0)

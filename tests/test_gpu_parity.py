@@ -404,7 +404,7 @@ def test_position_range_shards_sum_to_whole(ctx, n_shards):
     assert np.array_equal(total, exp)
 
 
-@pytest.mark.parametrize("shape", ["C2", "C3", "C4"])
+@pytest.mark.parametrize("shape", ["C2", "C3", "C4", "C5"])
 def test_full_size_paths_agree(ctx, shape):
     """BASELINE.json's full sizes (configs[1]: 10^8 symbols, 10^5 x 500, EBWT=1; configs[2]: 10^9 symbols,
     10^6 x 5000, EBWT=0), inputs generated on the device.  Too big for the oracle, so size-independent
@@ -418,9 +418,12 @@ def test_full_size_paths_agree(ctx, shape):
     from lime_amd.dist import shard_ranges
     # C4: the shapes of configs[3] (setB2: 20 249 373 reads x 930 genomes = 18.8 GB table, README.md:137) on 2*10^9
     # synthetic symbols, EBWT=1; its four position-range shards run one after the other on this one GPU
+    # C5: the shapes of configs[4] (SRR1804065 fwd + rc over the full reference database, Datasets/README.md:67: about 10^10
+    # symbols, 3 423 genomes; 3 * 10^6 reads -> a 10.3 GB table), EBWT=1: 90 GB of arrays resident on the one GPU; its eight
+    # position-range shards run one after the other, their edge words are combined like the ranks' (lime_combine_edges)
     n, nr, ng, ebwt_on = {"C2": (100_000_000, 100_000, 500, True), "C3": (1_000_000_000, 1_000_000, 5000, False),
-                          "C4": (2_000_000_000, 20_249_373, 930, True)}[shape]
-    n_shards = 4 if shape == "C4" else 3
+                          "C4": (2_000_000_000, 20_249_373, 930, True), "C5": (10_000_000_000, 3_000_000, 3423, True)}[shape]
+    n_shards = {"C4": 4, "C5": 8}.get(shape, 3)
     alpha, dev = 16, torch.device("cuda:0")
     lcp = torch.empty(n, dtype=torch.int32, device=dev); da = torch.empty_like(lcp)
     eb = torch.empty(n, dtype=torch.uint8, device=dev) if ebwt_on else None
@@ -432,14 +435,23 @@ def test_full_size_paths_agree(ctx, shape):
     assert sA.n_clusters > n // 30 and sA.n_updates > 0
     # (1) three (C4: four) shards into one table
     B = torch.empty(tb, dtype=torch.uint8, device=dev)
-    tot_c, tot_m, tot_u = 0, 0, 0
+    tot_c, tot_m, tot_u, edges = 0, 0, 0, []
     for k, (lo, hi, hh) in enumerate(shard_ranges(n, n_shards)):
         ctx.fused_dev(lcp[lo:], da[lo:], None if eb is None else eb[lo:], hi - lo, hh - lo, hh == n, nr, ng, alpha, B, k == 0)
         s, rc = ctx.stats(); assert rc == 0
-        tot_c += s.n_clusters; tot_m = max(tot_m, s.max_len); tot_u += s.n_updates
+        tot_c += s.n_clusters; tot_m = max(tot_m, s.max_len); tot_u += s.n_updates; edges.append(s.edge)
+    from lime_amd.dist import combine_edges
+    combine_edges(edges)                                 # no cluster among runs that cross shard borders beyond the halo
     assert (tot_c, tot_m, tot_u) == (sA.n_clusters, sA.max_len, sA.n_updates)
     assert torch.equal(A, B)
     del B
+    if shape == "C5":                                    # (2), (3) would need 18 GB of records on top: the row scan only
+        mx = torch.empty(nr, dtype=torch.uint8, device=dev); nz = torch.empty(nr, dtype=torch.int32, device=dev)
+        ctx.choose_dev(A, nr, ng, mx, nz)
+        t2 = A[:nr * ng].view(nr, ng)
+        assert torch.equal(mx, t2.amax(dim=1))
+        assert int(nz.sum()) == int(torch.count_nonzero(t2))
+        return
     # (2),(3) detection, then scoring of the list
     ptr, nc, ml = ctx.detect_dev(lcp, da, n, n, True, 0, nr, alpha)
     assert (nc, ml) == (sA.n_clusters, sA.max_len)
