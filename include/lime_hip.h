@@ -154,6 +154,33 @@ int lime_fused_dev(lime_ctx *ctx, const uint32_t *d_lcp, const uint32_t *d_da,
                    uint32_t n_reads, uint32_t n_refs, uint32_t alpha,
                    uint8_t *d_sim, int zero_sim, void *stream);
 
+/* ---- owner-partitioned exchange of table updates (several GPUs, large tables) ----
+ * lime_fused_records_dev: the same pass as lime_fused_dev, but no table is built: the shard's table updates are left as
+ * 32-bit records grouped by table bin (bin b = table bytes [b << bin_shift, (b+1) << bin_shift); record = offset inside
+ * the bin | t << bin_shift), the updates of clusters longer than the in-window limit as 64-bit records (cell | t << 40).
+ * The layout is a pure function of the table's shape: every rank gets the same (lime_records_layout).  After
+ * lime_get_stats (which also repeats a pass whose record pool proved too small), lime_records_get returns the device
+ * arrays (valid until the next pass on the ctx) and, optionally, the bin bases on the host.  The owner of bins
+ * [b0, b0 + nb) gathers the slices d_recs[binbase[b0] .. binbase[b0 + nb]) of every rank into one buffer and calls
+ * lime_apply_records_dev, which builds bytes [b0 << bin_shift, ...) of the table in d_block (every byte written; add
+ * the long clusters' records of ALL ranks).  lime_comm_exchange_records does the transport with RCCL.
+ * Reference counterpart: the cluster-range split over threads adding into one table, ClusterBWT_DA.cpp:630-670. */
+typedef struct {
+    uint32_t n_bins, bin_shift;
+    const uint32_t *d_recs;            /* device: records grouped by bin */
+    const uint64_t *d_binbase;         /* device: n_bins + 1 positions in d_recs */
+    const uint64_t *d_bigrecs;         /* device: updates of the long clusters, cell | t << 40 */
+    uint64_t n_bigrecs;
+} lime_records_t;
+int lime_records_layout(lime_ctx *ctx, uint32_t n_reads, uint32_t n_refs, uint32_t *n_bins, uint32_t *bin_shift);
+int lime_fused_records_dev(lime_ctx *ctx, const uint32_t *d_lcp, const uint32_t *d_da, const uint8_t *d_ebwt,
+                           uint64_t n_own, uint64_t n_avail, int eof, uint32_t n_reads, uint32_t n_refs,
+                           uint32_t alpha, void *stream);
+int lime_records_get(lime_ctx *ctx, lime_records_t *out, uint64_t *h_binbase /* n_bins + 1, may be NULL */, void *stream);
+int lime_apply_records_dev(lime_ctx *ctx, uint32_t n_src, const uint32_t *d_rx, const uint64_t *h_srcoff /* [n_src][nb + 1] */,
+                           uint32_t nb, uint32_t bin_shift, const uint64_t *d_bigrecs, uint64_t n_bigrecs,
+                           uint64_t cell_lo, uint64_t block_bytes, uint8_t *d_block, void *stream);
+
 /* Runs longer than the halo that cross shard borders: the reference reads on without limit (ClusterLCP.cpp:246-264)
  * and only refuses CLUSTERS longer than LIME_MAX_CLUSTER (ClusterBWT_DA.cpp:558-562).  A shard that ends inside such a
  * run reports it in lime_stats_t.edge (and lime_get_stats returns LIME_ERR_HALO to callers that do not look);
@@ -227,6 +254,11 @@ int  lime_comm_reduce_scatter_tables(lime_comm *comm, const uint8_t *d_sim, uint
 int  lime_comm_allreduce_tables(lime_comm *comm, uint8_t *d_sim, size_t bytes, void *stream);   /* whole table everywhere, in place */
 /* d_sum_max: device array of two u64: [0] summed over the ranks (cluster count), [1] maximum (longest cluster) */
 int  lime_comm_combine_counters(lime_comm *comm, uint64_t *d_sum_max, void *stream);
+/* Owner-partitioned exchange of the update records lime_fused_records_dev left on `ctx` (call lime_get_stats first): rank r
+ * ends with bytes [*cell_lo, *cell_lo + *block_bytes) of the finished table in d_block -- the bins r * per .. (r+1) * per,
+ * per = ceil(n_bins / world), see lime_records_layout; block_cap >= per << bin_shift.  Collective: every rank calls it. */
+int  lime_comm_exchange_records(lime_comm *comm, lime_ctx *ctx, uint32_t n_reads, uint32_t n_refs, uint8_t *d_block,
+                                size_t block_cap, uint64_t *cell_lo, uint64_t *block_bytes, void *stream);
 
 /* One process, n_dev GPUs (devices == NULL: 0 .. n_dev-1): lime_fused of host arrays with the collection cut into
  * n_dev position ranges, one reduce-scatter of the tables by read-row blocks, the blocks copied back into `sim`.

@@ -26,6 +26,11 @@ class Stats(C.Structure):
                 ("n_cross", C.c_uint32), ("n_big", C.c_uint32), ("flags", C.c_uint32), ("wave_records_max", C.c_uint32), ("edge", C.c_uint32), ("reserved", C.c_uint32)]
 
 
+class Records(C.Structure):
+    _fields_ = [("n_bins", C.c_uint32), ("bin_shift", C.c_uint32), ("d_recs", C.c_void_p), ("d_binbase", C.c_void_p),
+                ("d_bigrecs", C.c_void_p), ("n_bigrecs", C.c_uint64)]
+
+
 class LimeError(RuntimeError):
     def __init__(self, code, msg):
         super().__init__(f"lime error {code}: {msg}")
@@ -78,6 +83,11 @@ SYMBOLS = {
     "lime_comm_reduce_scatter_tables": (_i, [_vp, _vp, _vp, _sz, _vp]),
     "lime_comm_allreduce_tables": (_i, [_vp, _vp, _sz, _vp]),
     "lime_comm_combine_counters": (_i, [_vp, _vp, _vp]),
+    "lime_records_layout": (_i, [_vp, _u32, _u32, C.POINTER(_u32), C.POINTER(_u32)]),
+    "lime_fused_records_dev": (_i, [_vp, _vp, _vp, _vp, _u64, _u64, _i, _u32, _u32, _u32, _vp]),
+    "lime_records_get": (_i, [_vp, _vp, _vp, _vp]),
+    "lime_apply_records_dev": (_i, [_vp, _u32, _vp, _vp, _u32, _u32, _vp, _u64, _u64, _u64, _vp, _vp]),
+    "lime_comm_exchange_records": (_i, [_vp, _vp, _u32, _u32, _vp, _sz, _pu64, _pu64, _vp]),
     "lime_fused_multi": (_i, [_i, _vp, _vp, _vp, _vp, _u64, _u32, _u32, _u32, _vp, _pu64, _pu64]),
     "lime_score_choose_multi": (_i, [_i, _vp, _vp, _vp, _u64, _vp, _u64, _u32, _u32, _u32, C.c_float, _vp, _vp, _pp, _pu64]),
     "lime_write_res_txt_pairs": (_i, [C.c_char_p, _vp, _vp, _vp, _u32, _u32, C.c_float]),

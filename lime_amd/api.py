@@ -146,6 +146,33 @@ class Context:
         check(self.lib.lime_fused_dev(self.h, _ptr(lcp_t), _ptr(da_t), _ptr(ebwt_t), n_own, n_avail, int(eof),
                                       n_reads, n_refs, alpha, _ptr(sim_t), int(zero_sim), stream))
 
+    # ---- owner-partitioned exchange of table updates (include/lime_hip.h) ----
+    def records_layout(self, n_reads, n_refs):
+        nb, sh = C.c_uint32(0), C.c_uint32(0)
+        check(self.lib.lime_records_layout(self.h, n_reads, n_refs, C.byref(nb), C.byref(sh)))
+        return int(nb.value), int(sh.value)
+
+    def fused_records_dev(self, lcp_t, da_t, ebwt_t, n_own, n_avail, eof, n_reads, n_refs, alpha, stream=None):
+        self._rec_shape = self.records_layout(n_reads, n_refs)
+        check(self.lib.lime_fused_records_dev(self.h, _ptr(lcp_t), _ptr(da_t), _ptr(ebwt_t), n_own, n_avail, int(eof),
+                                              n_reads, n_refs, alpha, stream))
+
+    def records_get(self, stream=None):
+        """-> (Records with device pointers valid until the next pass, numpy bin bases [n_bins + 1])"""
+        import numpy as np
+        from ._lib import Records
+        nb, _ = self._rec_shape
+        r = Records()
+        base = np.zeros(nb + 1, dtype=np.uint64)
+        check(self.lib.lime_records_get(self.h, C.byref(r), base.ctypes.data, stream))
+        return r, base
+
+    def apply_records_dev(self, n_src, rx_t, srcoff, nb, bin_shift, bigrecs_t, n_big, cell_lo, block_bytes, block_t, stream=None):
+        import numpy as np
+        so = np.ascontiguousarray(srcoff, dtype=np.uint64)
+        check(self.lib.lime_apply_records_dev(self.h, n_src, _ptr(rx_t), so.ctypes.data, nb, bin_shift, _ptr(bigrecs_t), n_big,
+                                              cell_lo, block_bytes, _ptr(block_t), stream))
+
     def detect_dev(self, lcp_t, da_t, n_own, n_avail, eof, pos_base, n_reads, alpha, stream=None):
         """-> (device pointer of the library-owned record list, n_clusters, max_len); the list stays valid
         until the next detect_dev on this context."""

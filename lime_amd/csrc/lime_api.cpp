@@ -67,6 +67,11 @@ struct lime_ctx {
     uint32_t *d_counts = nullptr; size_t counts_cap = 0;
     uint32_t *d_totals = nullptr; uint64_t *d_binbase = nullptr;
     uint64_t *d_regbase = nullptr; size_t regbase_cap = 0;
+    // owner-partitioned exchange: the long clusters' update records of this rank; the owner's regrouped records
+    uint64_t *d_bigrec = nullptr; uint32_t *d_bigrec_n = nullptr; uint32_t bigrec_cap = 0;
+    uint32_t *d_xrecs = nullptr, *d_xrecs2 = nullptr; size_t xrecs_cap = 0;
+    uint64_t *d_xoff = nullptr; size_t xoff_cap = 0; uint64_t *d_xreg = nullptr; size_t xreg_cap = 0;
+    uint32_t rec_n_bins = 0, rec_bin_shift = 0;                // layout of the records the last lime_fused_records_dev left
     int upd_pref = -1;                      // LIME_UPDATE_PATH: -1 auto, 0 compare-and-swap on the table, 1 binned
     bool density_known = false; double density = 0.0;          // table updates per owned symbol of the last pass read back
     bool bin_levels_forced = false;
@@ -76,7 +81,7 @@ struct lime_ctx {
         bool valid = false, binned = false;
         const uint32_t *lcp = nullptr, *da = nullptr; const uint8_t *ebwt = nullptr;
         uint64_t n_own = 0, n_avail = 0; int eof = 0; uint32_t n_reads = 0, n_refs = 0, alpha = 0;
-        uint8_t *sim = nullptr; int zero_sim = 0; hipStream_t st = nullptr; uint32_t n_waves = 0;
+        uint8_t *sim = nullptr; int zero_sim = 0; hipStream_t st = nullptr; uint32_t n_waves = 0; bool records_only = false;
         uint64_t own_total = 0;             // owned symbols the counters in d_stats stand for (chunks of a stream accumulate)
     } last;
     // timing with HIP events on the launch stream: per pass {pass start, scan start, scan end, pass end}
@@ -160,6 +165,7 @@ extern "C" void lime_shutdown(lime_ctx *c)
     (void)hipFree(c->d_big_scratch);
     (void)hipFree(c->d_pool); (void)hipFree(c->d_recs); (void)hipFree(c->d_wave_cnt); (void)hipFree(c->d_counts);
     (void)hipFree(c->d_totals); (void)hipFree(c->d_binbase); (void)hipFree(c->d_regbase);
+    (void)hipFree(c->d_bigrec); (void)hipFree(c->d_bigrec_n); (void)hipFree(c->d_xrecs); (void)hipFree(c->d_xrecs2); (void)hipFree(c->d_xoff); (void)hipFree(c->d_xreg);
     delete c;
 }
 
@@ -335,16 +341,36 @@ static int ensure_binned(lime_ctx *c, uint64_t n_own, uint32_t n_waves, uint32_t
     return LIME_OK;
 }
 
+// The table's bins for the binned update path: one bin per 64 KB region for small tables; else as few levels of fan-out
+// as fit: at most 2048 bins of 2^k regions (the bins' open output lines then merge in the L2), more bins only when k would
+// pass its limit.  A pure function of the table's size (and LIME_BIN_LEVELS): every rank of an exchange gets the same.
+static void bin_layout(const lime_ctx *c, size_t sim_bytes, uint32_t *n_bins, uint32_t *bin_shift_out)
+{
+    uint32_t bin_shift = REGION_SHIFT;
+    auto bins_at = [&](uint32_t sh) { return (sim_bytes + ((size_t)1 << sh) - 1) >> sh; };
+    const uint32_t bmax = BIN_MAX;                        // what the scan's LDS histogram holds
+    const uint32_t one = c->bin_one_level < bmax ? c->bin_one_level : bmax, two = c->bin_two_level < bmax ? c->bin_two_level : bmax;
+    if (bins_at(bin_shift) > one) {
+        while ((bins_at(bin_shift) > two && bin_shift < BIN_SHIFT_MAX) || bins_at(bin_shift) > bmax) ++bin_shift;
+        // fewer, wider bins while that leaves at least 256 of them and at most 64 regions per bin: measured on a 1 GB
+        // table (N = 10^10) 477 bins of 32 regions beat 1908 of 8 by 1 ms in 11; a 5 GB table keeps its 1193 bins of 64
+        if (!c->bin_levels_forced)
+            while (bin_shift < REGION_SHIFT + 6 && bin_shift < BIN_SHIFT_MAX && bins_at(bin_shift + 1) >= 256) ++bin_shift;
+    }
+    *n_bins = (uint32_t)bins_at(bin_shift);               // <= BIN_MAX: want_binned checked the table size
+    *bin_shift_out = bin_shift;
+}
+
 // keep_stats: this call continues a position-range sequence on the same table (lime_fused_stream):
 // cluster / update counters and flags accumulate, only the per-call list counters restart.
 static int fused_dev_impl(lime_ctx *c, const uint32_t *d_lcp, const uint32_t *d_da, const uint8_t *d_ebwt,
                           uint64_t n_own, uint64_t n_avail, int eof, uint32_t n_reads, uint32_t n_refs,
                           uint32_t alpha, uint8_t *d_sim, int zero_sim, bool keep_stats, hipStream_t st,
-                          uint32_t *d_edge = nullptr, bool no_bin = false)
+                          uint32_t *d_edge = nullptr, bool no_bin = false, bool records_only = false)
 {
     int rc;
     if (n_own > n_avail) return fail(LIME_ERR_ARG, "lime_fused_dev: n_own > n_avail");
-    if (n_avail && (!d_lcp || !d_da || !d_sim)) return fail(LIME_ERR_ARG, "lime_fused_dev: NULL array");
+    if (n_avail && (!d_lcp || !d_da || (!d_sim && !records_only))) return fail(LIME_ERR_ARG, "lime_fused_dev: NULL array");
     if (misaligned(d_lcp, 16) || misaligned(d_da, 16) || misaligned(d_ebwt, 8) || misaligned(d_sim, 16))
         return fail(LIME_ERR_ARG, "lime_fused_dev: device arrays must be 16-byte aligned (ebwt: 8)");
     if (!n_reads || !n_refs) return fail(LIME_ERR_ARG, "lime_fused_dev: n_reads and n_refs must be > 0");
@@ -358,24 +384,20 @@ static int fused_dev_impl(lime_ctx *c, const uint32_t *d_lcp, const uint32_t *d_
     // no_bin: a chunk of a multi-chunk stream -- its device buffers are reused by later chunks, so the pass could not be
     // repeated after a pool overflow, and the later chunks add to the table by compare-and-swap
     bool binned = n_avail && !no_bin && want_binned(c, n_own, sim_bytes, zero_sim, keep_stats, ebwt);
+    if (records_only) {                                   // the records ARE the result: the binned path or nothing
+        if (sim_bytes > ((size_t)BIN_MAX << BIN_SHIFT_MAX) || sim_bytes >= (1ull << CELL_BITS) || sim_bytes > ((uint64_t)MAX_SUB << 32))
+            return fail(LIME_ERR_ARG, "lime_fused_records_dev: table too large for update records");
+        binned = true;
+    }
     const uint32_t n_sub_want = (uint32_t)((sim_bytes + 0xFFFFFFFFull) >> 32);
-    if (binned && ((double)n_own * c->pool_density * 1.10 + 512.0 * 4096.0) * n_sub_want > 3.9e9) binned = false;   // more records than 32-bit positions hold: compare-and-swap path
+    if (binned && ((double)n_own * c->pool_density * 1.10 + 512.0 * 4096.0) * n_sub_want > 3.9e9) {   // more records than 32-bit positions hold: compare-and-swap path
+        if (records_only) return fail(LIME_ERR_ARG, "lime_fused_records_dev: shard too long for 32-bit record positions (cut it in two)");
+        binned = false;
+    }
     uint32_t grid = 0, cap_w = 0, n_bins = 0, bin_shift = REGION_SHIFT, n_sub = 1;
     if (binned) {
         grid = scan_grid(ebwt, 0, 1, n_tiles, c->max_blocks);
-        // one bin per 64 KB region for small tables; else as few levels of fan-out as fit: at most 2048 bins of 2^k
-        // regions (the bins' open output lines then merge in the L2), more bins only when k would pass its limit
-        auto bins_at = [&](uint32_t sh) { return (sim_bytes + ((size_t)1 << sh) - 1) >> sh; };
-        const uint32_t bmax = BIN_MAX;                        // what the scan's LDS histogram holds
-        const uint32_t one = c->bin_one_level < bmax ? c->bin_one_level : bmax, two = c->bin_two_level < bmax ? c->bin_two_level : bmax;
-        if (bins_at(bin_shift) > one) {
-            while ((bins_at(bin_shift) > two && bin_shift < BIN_SHIFT_MAX) || bins_at(bin_shift) > bmax) ++bin_shift;
-            // fewer, wider bins while that leaves at least 256 of them and at most 64 regions per bin: measured on a 1 GB
-            // table (N = 10^10) 477 bins of 32 regions beat 1908 of 8 by 1 ms in 11; a 5 GB table keeps its 1193 bins of 64
-            if (!c->bin_levels_forced)
-                while (bin_shift < REGION_SHIFT + 6 && bin_shift < BIN_SHIFT_MAX && bins_at(bin_shift + 1) >= 256) ++bin_shift;
-        }
-        n_bins = (uint32_t)bins_at(bin_shift);           // <= BIN_MAX: want_binned checked the table size
+        bin_layout(c, sim_bytes, &n_bins, &bin_shift);
         n_sub = (uint32_t)((sim_bytes + 0xFFFFFFFFull) >> 32);
         if ((rc = ensure_binned(c, n_own, grid * scan_waves_per_wg(ebwt, 0), grid, n_bins, bin_shift, n_sub, &cap_w, st))) return rc;
     }
@@ -387,13 +409,23 @@ static int fused_dev_impl(lime_ctx *c, const uint32_t *d_lcp, const uint32_t *d_
         HIP_TRY(hipMemsetAsync(c->d_stats, 0, sizeof(DevStats), st));
     }
     if (zero_sim && !binned) HIP_TRY(hipMemsetAsync(d_sim, 0, sim_bytes, st));           // the binned path writes every byte itself
-    if (!n_avail) { if ((rc = timing_mark(c, st)) || (rc = timing_mark(c, st)) || (rc = timing_mark(c, st))) return rc; return LIME_OK; }
+    if (records_only) {                                   // the long clusters' updates leave as records too
+        if (!c->d_bigrec) {
+            c->bigrec_cap = 16u << 20;
+            HIP_TRY(hipMalloc(&c->d_bigrec, (size_t)c->bigrec_cap * sizeof(uint64_t)));
+            HIP_TRY(hipMalloc(&c->d_bigrec_n, sizeof(uint32_t)));
+        }
+        HIP_TRY(hipMemsetAsync(c->d_bigrec_n, 0, sizeof(uint32_t), st));
+        c->rec_n_bins = n_bins; c->rec_bin_shift = bin_shift;
+    }
+    if (!n_avail && !records_only) { if ((rc = timing_mark(c, st)) || (rc = timing_mark(c, st)) || (rc = timing_mark(c, st))) return rc; return LIME_OK; }
     ScanArgs a = base_args(c, d_lcp, d_da, d_ebwt, n_own, n_avail, eof, n_reads, n_refs, alpha, d_sim);
     if (d_edge) a.edge = d_edge;                          // a chunk of a stream: its own (cleared) word
     if (binned) {
         a.upd_mode = 1; a.pool = c->d_pool; a.cap_w = cap_w; a.n_sub = n_sub; a.wave_cnt = c->d_wave_cnt; a.counts = c->d_counts;
         a.n_bins = n_bins; a.bin_shift = bin_shift; a.prod_waves = scan_waves_per_wg(ebwt, 0);
     }
+    if (records_only) { a.sim = nullptr; a.bigrec = c->d_bigrec; a.bigrec_n = c->d_bigrec_n; a.bigrec_cap = c->bigrec_cap; }
     if ((rc = timing_mark(c, st))) return rc;
     launch_tile(ebwt, 0, a, c->max_blocks, st);
     if ((rc = timing_mark(c, st))) return rc;
@@ -402,7 +434,9 @@ static int fused_dev_impl(lime_ctx *c, const uint32_t *d_lcp, const uint32_t *d_
         launch_bin_rowscan(c->d_counts, c->d_totals, n_bins, grid, st);
         launch_scan_tiles(c->d_totals, c->d_binbase, n_bins, reinterpret_cast<unsigned long long *>(c->d_binbase + n_bins), st);
         launch_part(a, grid, c->d_binbase, c->d_recs, st);
-        if (bin_shift > REGION_SHIFT) {                   // second level into the (by now free) pool, then regions from there
+        if (records_only) {
+            // the records grouped by bin are the result: the owners of the bins build the table (lime_apply_records_dev)
+        } else if (bin_shift > REGION_SHIFT) {            // second level into the (by now free) pool, then regions from there
             uint32_t *recs2 = c->d_pool;
             launch_part2(c->d_recs, c->d_binbase, n_bins, bin_shift, c->d_regbase, recs2, st);
             // the base after the last region = the total (regions past the table's end hold no records)
@@ -421,7 +455,7 @@ static int fused_dev_impl(lime_ctx *c, const uint32_t *d_lcp, const uint32_t *d_
         l.valid = true; l.binned = binned; l.lcp = d_lcp; l.da = d_da; l.ebwt = d_ebwt; l.n_own = n_own; l.n_avail = n_avail;
         l.eof = eof; l.n_reads = n_reads; l.n_refs = n_refs; l.alpha = alpha; l.sim = d_sim; l.zero_sim = zero_sim; l.st = st;
         l.n_waves = grid * scan_waves_per_wg(ebwt, 0);
-        l.own_total = n_own;
+        l.own_total = n_own; l.records_only = records_only;
     } else {
         c->last.own_total += n_own;         // a later chunk of a stream: the update counter keeps accumulating
         c->last.binned = false;             // and the pass stored in `last` can no longer be repeated on its own
@@ -436,6 +470,101 @@ extern "C" int lime_fused_dev(lime_ctx *c, const uint32_t *d_lcp, const uint32_t
     int rc = check_ctx(c, "lime_fused_dev"); if (rc) return rc;
     return fused_dev_impl(c, d_lcp, d_da, d_ebwt, n_own, n_avail, eof, n_reads, n_refs, alpha, d_sim, zero_sim, false,
                           (hipStream_t)stream);
+}
+
+
+// ---- owner-partitioned exchange of table updates (several GPUs, large tables) -------------------------------------
+// Instead of a private table per rank and a dense reduce-scatter of whole tables (every rank allocates and writes T bytes
+// and moves T (G-1)/G over xGMI), a rank leaves its updates as records grouped by table bin; the owner of a range of bins
+// receives the slices of its bins from every rank and builds its block of the table alone: T/G bytes per rank, about
+// 4 bytes per update over the links.  The reference's counterpart is the cluster-range split of ClusterBWT_DA.cpp:630-670
+// with all threads adding into one table.
+extern "C" int lime_records_layout(lime_ctx *c, uint32_t n_reads, uint32_t n_refs, uint32_t *n_bins, uint32_t *bin_shift)
+{
+    int rc = check_ctx(c, "lime_records_layout"); if (rc) return rc;
+    if (!n_reads || !n_refs || !n_bins || !bin_shift) return fail(LIME_ERR_ARG, "lime_records_layout: bad argument");
+    bin_layout(c, lime_sim_bytes(n_reads, n_refs), n_bins, bin_shift);
+    return LIME_OK;
+}
+
+extern "C" int lime_fused_records_dev(lime_ctx *c, const uint32_t *d_lcp, const uint32_t *d_da, const uint8_t *d_ebwt,
+                                      uint64_t n_own, uint64_t n_avail, int eof, uint32_t n_reads, uint32_t n_refs,
+                                      uint32_t alpha, void *stream)
+{
+    int rc = check_ctx(c, "lime_fused_records_dev"); if (rc) return rc;
+    return fused_dev_impl(c, d_lcp, d_da, d_ebwt, n_own, n_avail, eof, n_reads, n_refs, alpha, nullptr, 1, false,
+                          (hipStream_t)stream, nullptr, false, true);
+}
+
+extern "C" int lime_records_get(lime_ctx *c, lime_records_t *out, uint64_t *h_binbase, void *stream)
+{
+    int rc = check_ctx(c, "lime_records_get"); if (rc) return rc;
+    if (!out) return fail(LIME_ERR_ARG, "lime_records_get: out is NULL");
+    if (!c->last.valid || !c->last.records_only) return fail(LIME_ERR_ARG, "lime_records_get: the last pass on this ctx was not lime_fused_records_dev");
+    hipStream_t st = (hipStream_t)stream;
+    uint32_t nb = 0;
+    HIP_TRY(hipMemcpyAsync(&nb, c->d_bigrec_n, sizeof nb, hipMemcpyDeviceToHost, st));
+    if (h_binbase) HIP_TRY(hipMemcpyAsync(h_binbase, c->d_binbase, ((size_t)c->rec_n_bins + 1) * sizeof(uint64_t), hipMemcpyDeviceToHost, st));
+    HIP_TRY(hipStreamSynchronize(st));
+    if (nb > c->bigrec_cap) return fail(LIME_ERR_NOMEM, "more update records of long clusters (%u) than their list holds (%u)", nb, c->bigrec_cap);
+    out->n_bins = c->rec_n_bins; out->bin_shift = c->rec_bin_shift;
+    out->d_recs = c->d_recs; out->d_binbase = c->d_binbase; out->d_bigrecs = c->d_bigrec; out->n_bigrecs = nb;
+    return LIME_OK;
+}
+
+// d_rx: the record slices received for this rank's bins, source after source; h_srcoff[s * (nb + 1) + b]: where source s's
+// records of local bin b start in d_rx (h_srcoff[s * (nb + 1) + nb]: where they end).  Builds bytes [cell_lo, cell_lo +
+// block_bytes) of the table -- cell_lo = first own bin << bin_shift -- in d_block: every byte is written.
+extern "C" int lime_apply_records_dev(lime_ctx *c, uint32_t n_src, const uint32_t *d_rx, const uint64_t *h_srcoff, uint32_t nb,
+                                      uint32_t bin_shift, const uint64_t *d_bigrecs, uint64_t n_bigrecs, uint64_t cell_lo,
+                                      uint64_t block_bytes, uint8_t *d_block, void *stream)
+{
+    int rc = check_ctx(c, "lime_apply_records_dev"); if (rc) return rc;
+    hipStream_t st = (hipStream_t)stream;
+    if (!n_src || !h_srcoff || !d_block || (n_bigrecs && !d_bigrecs)) return fail(LIME_ERR_ARG, "lime_apply_records_dev: NULL argument");
+    if (bin_shift < REGION_SHIFT || bin_shift > BIN_SHIFT_MAX || (block_bytes & 15u) || misaligned(d_block, 16) ||
+        block_bytes > ((uint64_t)nb << bin_shift) || (cell_lo & (((uint64_t)1 << bin_shift) - 1u)))
+        return fail(LIME_ERR_ARG, "lime_apply_records_dev: bad block geometry");
+    if (!nb || !block_bytes) return LIME_OK;
+    // where every bin starts in the regrouped array: the sources' counts added up
+    std::vector<uint64_t> dstbase((size_t)nb + 1, 0);
+    for (uint32_t b = 0; b < nb; ++b) {
+        uint64_t cnt = 0;
+        for (uint32_t s = 0; s < n_src; ++s) {
+            const uint64_t lo = h_srcoff[(size_t)s * (nb + 1) + b], hi = h_srcoff[(size_t)s * (nb + 1) + b + 1];
+            if (hi < lo) return fail(LIME_ERR_ARG, "lime_apply_records_dev: source offsets not ascending");
+            cnt += hi - lo;
+        }
+        dstbase[b + 1] = dstbase[b] + cnt;
+    }
+    const uint64_t total = dstbase[nb];
+    if (total > 0xF0000000ull) return fail(LIME_ERR_ARG, "lime_apply_records_dev: too many records for one block");
+    if (total && !d_rx) return fail(LIME_ERR_ARG, "lime_apply_records_dev: d_rx is NULL");
+    const size_t f2 = (size_t)1 << (bin_shift - REGION_SHIFT), n_reg = (size_t)nb * f2;
+    if (total + 16 > c->xrecs_cap) {
+        HIP_TRY(hipStreamSynchronize(st));
+        if ((rc = regrow(c->d_xrecs, (size_t)total + 16 + total / 8))) return rc;
+        if ((rc = regrow(c->d_xrecs2, (size_t)total + 16 + total / 8))) return rc;
+        c->xrecs_cap = (size_t)total + 16 + total / 8;
+    }
+    const size_t off_words = (size_t)n_src * (nb + 1) + (nb + 1);
+    if (off_words > c->xoff_cap) { HIP_TRY(hipStreamSynchronize(st)); if ((rc = regrow(c->d_xoff, off_words))) return rc; c->xoff_cap = off_words; }
+    if (n_reg + 2 > c->xreg_cap) { HIP_TRY(hipStreamSynchronize(st)); if ((rc = regrow(c->d_xreg, n_reg + 2))) return rc; c->xreg_cap = n_reg + 2; }
+    uint64_t *d_srcoff = c->d_xoff, *d_dstbase = c->d_xoff + (size_t)n_src * (nb + 1);
+    HIP_TRY(hipMemcpyAsync(d_srcoff, h_srcoff, (size_t)n_src * (nb + 1) * sizeof(uint64_t), hipMemcpyHostToDevice, st));
+    HIP_TRY(hipMemcpyAsync(d_dstbase, dstbase.data(), ((size_t)nb + 1) * sizeof(uint64_t), hipMemcpyHostToDevice, st));
+    HIP_TRY(hipStreamSynchronize(st));                    // the host vectors go out of scope
+    launch_regroup(d_rx, d_srcoff, n_src, nb, d_dstbase, c->d_xrecs, st);
+    if (bin_shift > REGION_SHIFT) {
+        launch_part2(c->d_xrecs, d_dstbase, nb, bin_shift, c->d_xreg, c->d_xrecs2, st);
+        HIP_TRY(hipMemcpyAsync(c->d_xreg + n_reg, d_dstbase + nb, sizeof(uint64_t), hipMemcpyDeviceToDevice, st));
+        launch_apply(d_block, (size_t)block_bytes, c->d_xrecs2, c->d_xreg, bin_shift, st);
+    } else {
+        launch_apply(d_block, (size_t)block_bytes, c->d_xrecs, d_dstbase, bin_shift, st);
+    }
+    launch_apply_bigrecs(d_bigrecs, n_bigrecs, cell_lo, cell_lo + block_bytes, d_block, st);
+    HIP_TRY(hipGetLastError());
+    return LIME_OK;
 }
 
 static int read_stats(lime_ctx *c, lime_stats_t *s, hipStream_t st, uint32_t *sticky = nullptr)
@@ -470,12 +599,12 @@ extern "C" int lime_get_stats(lime_ctx *c, lime_stats_t *out, void *stream)
     lime_ctx::Last &l = c->last;
     for (int attempt = 0; (s.flags & LIME_FLAG_POOL_FULL) && l.valid && l.binned && attempt < 3; ++attempt) {
         const int pref = c->upd_pref;
-        if (attempt == 2) c->upd_pref = 0;
+        if (attempt == 2 && !l.records_only) c->upd_pref = 0;
         const double need = (double)s.wave_records_max * (double)l.n_waves / (double)(l.n_own ? l.n_own : 1);
         c->pool_density = need * 1.08 > c->pool_density * 1.5 ? need * 1.08 : c->pool_density * 1.5;
         const bool timing = c->timing; c->timing = false;
         rc = fused_dev_impl(c, l.lcp, l.da, l.ebwt, l.n_own, l.n_avail, l.eof, l.n_reads, l.n_refs, l.alpha, l.sim, l.zero_sim,
-                            false, l.st);
+                            false, l.st, nullptr, false, l.records_only);
         c->timing = timing; c->upd_pref = pref;
         if (rc) return rc;
         if ((rc = read_stats(c, &s, l.st, &unsettled))) return rc;

@@ -23,7 +23,7 @@ extern "C" {
 typedef struct ncclComm *ncclComm_t;
 typedef struct { char internal[128]; } ncclUniqueId;
 typedef int ncclResult_t;
-enum { nccl_Sum = 0, nccl_Max = 2, nccl_Uint8 = 1, nccl_Uint64 = 5 };
+enum { nccl_Sum = 0, nccl_Max = 2, nccl_Uint8 = 1, nccl_Uint32 = 3, nccl_Uint64 = 5 };   // rccl.h: ncclRedOp_t / ncclDataType_t
 }
 
 namespace {
@@ -35,6 +35,9 @@ struct Rccl {
     ncclResult_t (*CommDestroy)(ncclComm_t) = nullptr;
     ncclResult_t (*ReduceScatter)(const void *, void *, size_t, int, int, ncclComm_t, hipStream_t) = nullptr;
     ncclResult_t (*AllReduce)(const void *, void *, size_t, int, int, ncclComm_t, hipStream_t) = nullptr;
+    ncclResult_t (*AllGather)(const void *, void *, size_t, int, ncclComm_t, hipStream_t) = nullptr;
+    ncclResult_t (*Send)(const void *, size_t, int, int, ncclComm_t, hipStream_t) = nullptr;
+    ncclResult_t (*Recv)(void *, size_t, int, int, ncclComm_t, hipStream_t) = nullptr;
     ncclResult_t (*GroupStart)() = nullptr;
     ncclResult_t (*GroupEnd)() = nullptr;
     const char *(*GetErrorString)(ncclResult_t) = nullptr;
@@ -60,6 +63,7 @@ int load_rccl()
 #define SYM(field, name) if (!(*(void **)(&g_rccl.field) = dlsym(h, name))) return cfail(LIME_ERR_HIP, "librccl lacks %s", name)
     SYM(GetUniqueId, "ncclGetUniqueId"); SYM(CommInitRank, "ncclCommInitRank"); SYM(CommInitAll, "ncclCommInitAll");
     SYM(CommDestroy, "ncclCommDestroy"); SYM(ReduceScatter, "ncclReduceScatter"); SYM(AllReduce, "ncclAllReduce");
+    SYM(AllGather, "ncclAllGather"); SYM(Send, "ncclSend"); SYM(Recv, "ncclRecv");
     SYM(GroupStart, "ncclGroupStart"); SYM(GroupEnd, "ncclGroupEnd"); SYM(GetErrorString, "ncclGetErrorString");
 #undef SYM
     g_rccl.h = h;
@@ -145,6 +149,83 @@ extern "C" int lime_comm_combine_counters(lime_comm *c, uint64_t *d_sum_max, voi
     NCCL_TRY(g_rccl.AllReduce(d_sum_max, d_sum_max, 1, nccl_Uint64, nccl_Sum, c->comm, (hipStream_t)stream));
     NCCL_TRY(g_rccl.AllReduce(d_sum_max + 1, d_sum_max + 1, 1, nccl_Uint64, nccl_Max, c->comm, (hipStream_t)stream));
     NCCL_TRY(g_rccl.GroupEnd());
+    return LIME_OK;
+}
+
+
+// ---- owner-partitioned exchange of table updates (large tables: include/lime_hip.h, lime_fused_records_dev) ------------
+// Rank r owns the bins [r * per, (r+1) * per) of the table (per = ceil(n_bins / world)): it receives, from every rank, the
+// slice of records of those bins (ncclSend / ncclRecv inside one group, after an all-gather of the ranks' bin bases) and
+// all ranks' long-cluster records (all-gather), and builds bytes [cell_lo, cell_lo + block_bytes) of the table in d_block
+// (capacity: per << bin_shift bytes).  About 4 bytes per update cross xGMI instead of T (G-1)/G, and a rank writes T/G
+// bytes of table instead of T.  Synchronises `stream` (the slice sizes size the receive buffer).
+namespace { struct ExBuf { void *p = nullptr; ~ExBuf() { if (p) (void)hipFree(p); } }; }
+
+extern "C" int lime_comm_exchange_records(lime_comm *c, lime_ctx *ctx, uint32_t n_reads, uint32_t n_refs, uint8_t *d_block,
+                                          size_t block_cap, uint64_t *cell_lo, uint64_t *block_bytes, void *stream)
+{
+    if (!c || !ctx || !d_block || !cell_lo || !block_bytes) return cfail(LIME_ERR_ARG, "lime_comm_exchange_records: NULL argument");
+    hipStream_t st = (hipStream_t)stream;
+    const int W = c->world, me = c->rank;
+    uint32_t n_bins = 0, bin_shift = 0;
+    int rc = lime_records_layout(ctx, n_reads, n_refs, &n_bins, &bin_shift);
+    if (rc) return cfail(rc, "%s", lime_last_error());
+    const size_t sim_bytes = lime_sim_bytes(n_reads, n_refs);
+    const uint32_t per = (n_bins + (uint32_t)W - 1u) / (uint32_t)W;
+    const uint32_t b0 = per * (uint32_t)me < n_bins ? per * (uint32_t)me : n_bins, b1 = b0 + per < n_bins ? b0 + per : n_bins, nb = b1 - b0;
+    *cell_lo = (uint64_t)b0 << bin_shift;
+    const uint64_t hi = ((uint64_t)b1 << bin_shift) < sim_bytes ? ((uint64_t)b1 << bin_shift) : sim_bytes;
+    *block_bytes = hi > *cell_lo ? hi - *cell_lo : 0;
+    if (*block_bytes > block_cap) return cfail(LIME_ERR_ARG, "lime_comm_exchange_records: block of %llu bytes, room for %zu", (unsigned long long)*block_bytes, block_cap);
+    // my records and their bin bases; everybody's bin bases (+ the long clusters' record counts as one more word)
+    std::vector<uint64_t> base((size_t)n_bins + 2);
+    lime_records_t R;
+    if ((rc = lime_records_get(ctx, &R, base.data(), st))) return cfail(rc, "%s", lime_last_error());
+    if (R.n_bins != n_bins || R.bin_shift != bin_shift) return cfail(LIME_ERR_ARG, "lime_comm_exchange_records: the ctx holds records of another table shape");
+    base[(size_t)n_bins + 1] = R.n_bigrecs;
+    const size_t row = (size_t)n_bins + 2;
+    ExBuf d_all; HIP_TRYC(hipMalloc(&d_all.p, row * sizeof(uint64_t) * ((size_t)W + 1)));
+    uint64_t *d_mine = (uint64_t *)d_all.p + row * (size_t)W;
+    HIP_TRYC(hipMemcpyAsync(d_mine, base.data(), row * sizeof(uint64_t), hipMemcpyHostToDevice, st));
+    NCCL_TRY(g_rccl.AllGather(d_mine, d_all.p, row, nccl_Uint64, c->comm, st));
+    std::vector<uint64_t> all(row * (size_t)W);
+    HIP_TRYC(hipMemcpyAsync(all.data(), d_all.p, all.size() * sizeof(uint64_t), hipMemcpyDeviceToHost, st));
+    HIP_TRYC(hipStreamSynchronize(st));
+    // what I receive: source s's records of my bins, one source after the other
+    std::vector<uint64_t> srcoff((size_t)W * (nb + 1));
+    uint64_t rx_total = 0, big_total = 0, big_max = 0;
+    for (int s = 0; s < W; ++s) {
+        const uint64_t *bs = all.data() + row * (size_t)s;
+        for (uint32_t b = 0; b <= nb; ++b) srcoff[(size_t)s * (nb + 1) + b] = rx_total + (bs[b0 + b] - bs[b0]);
+        rx_total += bs[b1] - bs[b0];
+        big_total += bs[n_bins + 1]; if (bs[n_bins + 1] > big_max) big_max = bs[n_bins + 1];
+    }
+    ExBuf d_rx, d_big; HIP_TRYC(hipMalloc(&d_rx.p, (rx_total + 16) * sizeof(uint32_t)));
+    HIP_TRYC(hipMalloc(&d_big.p, ((size_t)W * big_max + 2) * sizeof(uint64_t)));
+    NCCL_TRY(g_rccl.GroupStart());
+    for (int p = 0; p < W; ++p) {
+        const uint32_t pb0 = per * (uint32_t)p < n_bins ? per * (uint32_t)p : n_bins, pb1 = pb0 + per < n_bins ? pb0 + per : n_bins;
+        const uint64_t n_send = base[pb1] - base[pb0];                         // my records of p's bins
+        const uint64_t *bs = all.data() + row * (size_t)p;
+        const uint64_t n_recv = bs[b1] - bs[b0];                               // p's records of my bins
+        if (n_send) NCCL_TRY(g_rccl.Send(R.d_recs + base[pb0], n_send, nccl_Uint32, p, c->comm, st));
+        if (n_recv) NCCL_TRY(g_rccl.Recv((uint32_t *)d_rx.p + srcoff[(size_t)p * (nb + 1)], n_recv, nccl_Uint32, p, c->comm, st));
+    }
+    NCCL_TRY(g_rccl.GroupEnd());
+    // the long clusters' records of every rank, padded to the longest list (few: clusters beyond the in-window limit)
+    uint64_t n_big_all = 0;
+    if (big_max) {
+        ExBuf d_pad; HIP_TRYC(hipMalloc(&d_pad.p, (big_max + 1) * sizeof(uint64_t)));
+        HIP_TRYC(hipMemsetAsync(d_pad.p, 0, big_max * sizeof(uint64_t), st));   // t == 0: no update
+        if (R.n_bigrecs) HIP_TRYC(hipMemcpyAsync(d_pad.p, R.d_bigrecs, R.n_bigrecs * sizeof(uint64_t), hipMemcpyDeviceToDevice, st));
+        NCCL_TRY(g_rccl.AllGather(d_pad.p, d_big.p, big_max, nccl_Uint64, c->comm, st));
+        HIP_TRYC(hipStreamSynchronize(st));
+        n_big_all = (uint64_t)W * big_max;
+    }
+    rc = lime_apply_records_dev(ctx, (uint32_t)W, (const uint32_t *)d_rx.p, srcoff.data(), nb, bin_shift, (const uint64_t *)d_big.p, n_big_all,
+                                *cell_lo, *block_bytes, d_block, st);
+    if (rc) return cfail(rc, "%s", lime_last_error());
+    HIP_TRYC(hipStreamSynchronize(st));                   // the receive buffers are freed on return
     return LIME_OK;
 }
 

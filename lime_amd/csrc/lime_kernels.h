@@ -87,6 +87,7 @@ struct ScanArgs {
     uint32_t prod_waves;                         // waves per workgroup of the scan that made them
     uint32_t *counts;                            // [n_bins][gridDim.x]: records of bin b counted by workgroup p
     uint32_t n_bins, bin_shift;                  // bin of a cell = cell >> bin_shift
+    uint64_t *bigrec; uint32_t *bigrec_n; uint32_t bigrec_cap;   // sim == NULL (records for an owner-partitioned exchange): the long clusters' updates, cell | t << CELL_BITS
 };
 
 void launch_tile(int ebwt, int mode, const ScanArgs &a, uint32_t max_blocks, hipStream_t st);
@@ -99,6 +100,8 @@ void launch_part2(const uint32_t *recs, const uint64_t *binbase, uint32_t n_bins
                   uint32_t *out, hipStream_t st);
 void launch_apply(uint8_t *sim, size_t sim_bytes, const uint32_t *recs, const uint64_t *regbase, uint32_t bin_shift, hipStream_t st);
 void launch_resolve(int mode, const ScanArgs &a, hipStream_t st);
+void launch_regroup(const uint32_t *rx, const uint64_t *srcoff, uint32_t n_src, uint32_t nb, const uint64_t *dstbase, uint32_t *dst, hipStream_t st);
+void launch_apply_bigrecs(const uint64_t *recs, uint64_t n, uint64_t cell_lo, uint64_t cell_hi, uint8_t *block, hipStream_t st);
 void launch_emit(const ScanArgs &a, hipStream_t st);
 void launch_scan_tiles(const uint32_t *cnt, uint64_t *off, uint32_t n, unsigned long long *total, hipStream_t st);
 void launch_score_list(int ebwt, const ScanArgs &a, const lime_cluster_t *list, uint64_t count, uint32_t blocks, hipStream_t st);

@@ -2004,8 +2004,14 @@ __global__ __launch_bounds__(WGSZ) void k_score_big(ScanArgs a, uint32_t *scratc
                 }
                 if (t) {
                     const uint32_t g = gdoc - a.n_reads;
-                    if (g < a.n_refs) { sim_add(a.sim, row + g, t); ++nupd; }
-                    else atomicOr(&a.stats->flags, LIME_FLAG_DOCID);
+                    if (g >= a.n_refs) atomicOr(&a.stats->flags, LIME_FLAG_DOCID);
+                    else if (a.sim) { sim_add(a.sim, row + g, t); ++nupd; }
+                    else {                                     // records for the owner of the cell (owner-partitioned exchange)
+                        const uint32_t k = atomicAdd(a.bigrec_n, 1u);
+                        if (k < a.bigrec_cap) a.bigrec[k] = (row + g) | ((uint64_t)t << CELL_BITS);
+                        else atomicOr(&a.stats->flags, LIME_FLAG_OVERFLOW);
+                        ++nupd;
+                    }
                 }
             }
         }
@@ -2128,6 +2134,36 @@ __global__ void k_fill_u32(uint32_t *p, size_t n, uint32_t v)
     for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) p[i] = v;
 }
 
+// =========================================================================================
+// Owner-partitioned exchange of table updates (several GPUs, large tables): every rank leaves its updates as records
+// grouped by table bin (k_part); the owner of a range of bins receives, from every rank, the slice of records of its
+// bins and builds ITS block of the table alone.  k_regroup: the received slices (source-major, each grouped by bin) into
+// one array grouped by bin -- a workgroup per bin copies the sources' runs one after the other.
+// srcoff[s * (nb + 1) + b]: where source s's records of local bin b start in rx; dstbase[b]: where bin b starts in dst.
+// =========================================================================================
+__global__ __launch_bounds__(256) void k_regroup(const uint32_t *rx, const uint64_t *srcoff, uint32_t n_src, uint32_t nb,
+                                                 const uint64_t *dstbase, uint32_t *dst)
+{
+    const uint32_t b = blockIdx.x;
+    uint64_t at = dstbase[b];
+    for (uint32_t s = 0; s < n_src; ++s) {
+        const uint64_t lo = srcoff[(size_t)s * (nb + 1u) + b], hi = srcoff[(size_t)s * (nb + 1u) + b + 1u];
+        for (uint64_t i = lo + threadIdx.x; i < hi; i += 256u) dst[at + (i - lo)] = rx[i];
+        at += hi - lo;
+    }
+}
+
+// the long clusters' updates of ALL ranks (cell | t << CELL_BITS): the ones that fall into this rank's block are added
+// to it (exact modulo 256 per byte cell, like k_score_big on a whole table)
+__global__ __launch_bounds__(256) void k_apply_bigrecs(const uint64_t *recs, uint64_t n, uint64_t cell_lo, uint64_t cell_hi, uint8_t *block)
+{
+    const uint64_t stride = (uint64_t)gridDim.x * 256u;
+    for (uint64_t i = (uint64_t)blockIdx.x * 256u + threadIdx.x; i < n; i += stride) {
+        const uint64_t r = recs[i], cell = r & ((1ull << CELL_BITS) - 1ull);
+        if (cell >= cell_lo && cell < cell_hi) sim_add(block, cell - cell_lo, (uint32_t)(r >> CELL_BITS));
+    }
+}
+
 // ---- launch wrappers (host) ------------------------------------------------------------
 template <typename K> static uint32_t resident_blocks(K kernel, int block)
 {
@@ -2194,6 +2230,18 @@ void launch_apply(uint8_t *sim, size_t sim_bytes, const uint32_t *recs, const ui
 {
     const uint32_t grid = (uint32_t)((sim_bytes + ((size_t)1 << REGION_SHIFT) - 1) >> REGION_SHIFT);
     hipLaunchKernelGGL(k_apply, dim3(grid), dim3(APPLY_WG), 0, st, sim, sim_bytes, recs, regbase, bin_shift);
+}
+
+void launch_regroup(const uint32_t *rx, const uint64_t *srcoff, uint32_t n_src, uint32_t nb, const uint64_t *dstbase, uint32_t *dst, hipStream_t st)
+{
+    if (nb) hipLaunchKernelGGL(k_regroup, dim3(nb), dim3(256), 0, st, rx, srcoff, n_src, nb, dstbase, dst);
+}
+
+void launch_apply_bigrecs(const uint64_t *recs, uint64_t n, uint64_t cell_lo, uint64_t cell_hi, uint8_t *block, hipStream_t st)
+{
+    if (!n) return;
+    const uint64_t want = (n + 255u) / 256u;
+    hipLaunchKernelGGL(k_apply_bigrecs, dim3((uint32_t)(want < 4096u ? want : 4096u)), dim3(256), 0, st, recs, n, cell_lo, cell_hi, block);
 }
 
 void launch_tile(int ebwt, int mode, const ScanArgs &a, uint32_t max_blocks, hipStream_t st)

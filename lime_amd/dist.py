@@ -99,6 +99,15 @@ class Comm:
     def allreduce_tables(self, sim_t, stream=None):
         self._check(self.lib.lime_comm_allreduce_tables(self.h, sim_t.data_ptr(), sim_t.numel(), stream))
 
+    def exchange_records(self, ctx, n_reads, n_refs, block_t, stream=None):
+        """owner-partitioned exchange of the update records ctx.fused_records_dev left (after ctx.stats()): this rank ends
+        with bytes [cell_lo, cell_lo + block_bytes) of the finished table in block_t; returns (cell_lo, block_bytes)"""
+        import ctypes as C
+        lo, nb = C.c_uint64(0), C.c_uint64(0)
+        self._check(self.lib.lime_comm_exchange_records(self.h, ctx.h, n_reads, n_refs, block_t.data_ptr(), block_t.numel(),
+                                                        C.byref(lo), C.byref(nb), stream))
+        return int(lo.value), int(nb.value)
+
     def combine_counters(self, n_clusters, max_len):
         import torch
         t = torch.tensor([n_clusters, max_len], dtype=torch.int64, device=self.device)
@@ -162,6 +171,42 @@ class HostComm:
 
     def combine_counters(self, n_clusters, max_len):
         return combine_counters(n_clusters, max_len, "cpu", self.group)
+
+    def exchange_records(self, ctx, n_reads, n_refs, block_t, stream=None):
+        """the same exchange staged through host memory (gloo all_gather_object of the ranks' records)"""
+        import ctypes as C
+        import numpy as np
+        import torch
+        import torch.distributed as dist
+        from . import _lib
+        R, base = ctx.records_get(stream)
+        total = int(base[-1])
+        rec = torch.empty(max(total, 1), dtype=torch.int32, device=self.device)
+        if total:
+            assert _lib.hip_memcpy_d2d(rec.data_ptr(), R.d_recs, total * 4) == 0
+        big = torch.empty(max(int(R.n_bigrecs), 1), dtype=torch.int64, device=self.device)
+        if R.n_bigrecs:
+            assert _lib.hip_memcpy_d2d(big.data_ptr(), R.d_bigrecs, int(R.n_bigrecs) * 8) == 0
+        mine = (base, rec[:total].cpu().numpy(), big[:int(R.n_bigrecs)].cpu().numpy())
+        everyone = [None] * self.world
+        dist.all_gather_object(everyone, mine, group=self.group)
+        n_bins, bin_shift = int(R.n_bins), int(R.bin_shift)
+        per = (n_bins + self.world - 1) // self.world
+        b0 = min(per * self.rank, n_bins); b1 = min(b0 + per, n_bins); nb = b1 - b0
+        from .api import sim_bytes as _sb
+        cell_lo = b0 << bin_shift
+        block_bytes = max(min(b1 << bin_shift, _sb(n_reads, n_refs)) - cell_lo, 0)
+        srcoff = np.zeros((self.world, nb + 1), dtype=np.uint64)
+        parts, at = [], 0
+        for s, (bs, rs, _) in enumerate(everyone):
+            sl = bs[b0:b1 + 1].astype(np.int64)
+            srcoff[s] = at + (sl - sl[0]); parts.append(rs[int(sl[0]):int(sl[-1])]); at += int(sl[-1] - sl[0])
+        rx = torch.from_numpy(np.concatenate(parts) if at else np.zeros(1, np.int32)).to(self.device)
+        bigs = np.concatenate([b for _, _, b in everyone]) if sum(len(b) for _, _, b in everyone) else np.zeros(0, np.int64)
+        bt = torch.from_numpy(bigs if len(bigs) else np.zeros(1, np.int64)).to(self.device)
+        ctx.apply_records_dev(self.world, rx, srcoff, nb, bin_shift, bt, len(bigs), cell_lo, block_bytes, block_t, stream)
+        torch.cuda.synchronize()
+        return cell_lo, block_bytes
 
     def check_uint8_sum_wraps(self):
         import torch

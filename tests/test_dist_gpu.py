@@ -53,6 +53,45 @@ if rank == 0: print("DIST_OK")
 '''
 
 
+WORKER_RECORDS = r'''
+import os, sys
+import numpy as np, torch, torch.distributed as dist
+sys.path.insert(0, os.environ["LIME_ROOT"])
+import lime_amd
+from lime_amd import dist as ldist
+from oracle import oracle_py as O
+rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
+torch.cuda.set_device(0); dev = torch.device("cuda", 0)
+dist.init_process_group("gloo")
+comm = ldist.HostComm(rank, world, dev)
+n, nr, ng = 900001, 7000, 90
+lcp, da, eb = O.synth(22, 0, n, nr, ng, 16, 1)
+lcp[449000:451000] = 30                                        # a run across the cut between the two ranges: a long cluster
+lo, hi, hh = ldist.shard_ranges(n, world)[rank]
+ctx = lime_amd.Context(0)
+n_bins, bin_shift = ctx.records_layout(nr, ng)
+per = (n_bins + world - 1) // world
+for e in (eb, None):
+    tl = torch.from_numpy(lcp[lo:hh].view(np.int32)).to(dev); td = torch.from_numpy(da[lo:hh].view(np.int32)).to(dev)
+    te = None if e is None else torch.from_numpy(e[lo:hh]).to(dev)
+    ctx.fused_records_dev(tl, td, te, hi - lo, hh - lo, hh == n, nr, ng, 16)
+    s, rc = ctx.stats(); assert rc == 0, rc
+    blk = torch.full((per << bin_shift,), 0xCD, dtype=torch.uint8, device=dev)
+    cell_lo, nbytes = comm.exchange_records(ctx, nr, ng, blk)
+    nc, ml = comm.combine_counters(int(s.n_clusters), int(s.max_len))
+    parts = [None] * world
+    dist.all_gather_object(parts, (cell_lo, blk[:nbytes].cpu().numpy()))
+    if rank == 0:
+        cl, enc, eml = O.detect(lcp, da, nr, 16)
+        exp = O.score(da, e, cl, nr, ng, threads=4)
+        got = np.concatenate([p for _, p in sorted(parts, key=lambda x: x[0])])[:nr * ng].reshape(nr, ng)
+        assert (nc, ml) == (enc, eml), ((nc, ml), (enc, eml))
+        assert np.array_equal(got, exp), "the owners' blocks differ from the oracle"
+ctx.close(); dist.destroy_process_group()
+if rank == 0: print("DIST_OK")
+'''
+
+
 def _free_port():
     s = socket.socket(); s.bind(("127.0.0.1", 0)); p = s.getsockname()[1]; s.close(); return p
 
@@ -67,6 +106,15 @@ def _torchrun(args, env_extra, timeout=600):
 def test_two_ranks_run_the_hip_path_and_sum_to_the_oracle(tmp_path):
     w = tmp_path / "worker.py"
     w.write_text(WORKER)
+    r = _torchrun([str(w)], {})
+    assert r.returncode == 0 and b"DIST_OK" in r.stdout, r.stderr.decode()[-3000:]
+
+
+def test_two_ranks_exchange_update_records_and_build_their_blocks(tmp_path):
+    """owner-partitioned exchange (lime_fused_records_dev -> exchange -> lime_apply_records_dev) with two ranks; the
+    transport is the host-staged stand-in, everything else the product path"""
+    w = tmp_path / "worker_records.py"
+    w.write_text(WORKER_RECORDS)
     r = _torchrun([str(w)], {})
     assert r.returncode == 0 and b"DIST_OK" in r.stdout, r.stderr.decode()[-3000:]
 
@@ -101,6 +149,24 @@ def test_rccl_calls_through_the_c_abi_on_one_rank():
         comm.reduce_scatter_tables(src, out, 4096, torch.cuda.current_stream().cuda_stream)
         torch.cuda.synchronize()
         assert torch.equal(src, out)
+        # the owner-partitioned exchange through RCCL (all-gather, send / receive to itself, all-gather of the long clusters' records)
+        from oracle import oracle_py as O
+        n, nr, ng = 600001, 4000, 70
+        lcp, da, eb = O.synth(23, 0, n, nr, ng, 16, 1)
+        lcp[300000:300900] = 25
+        cl, nc, ml = O.detect(lcp, da, nr, 16)
+        exp = O.score(da, eb, cl, nr, ng, threads=4)
+        ctx = lime_amd.Context(0)
+        tl = torch.from_numpy(lcp.view(np.int32)).to(dev); td = torch.from_numpy(da.view(np.int32)).to(dev); te = torch.from_numpy(eb).to(dev)
+        ctx.fused_records_dev(tl, td, te, n, n, True, nr, ng, 16)
+        s, rc = ctx.stats(); assert rc == 0
+        n_bins, bin_shift = ctx.records_layout(nr, ng)
+        blk = torch.full((n_bins << bin_shift,), 0xEE, dtype=torch.uint8, device=dev)
+        cell_lo, nbytes = comm.exchange_records(ctx, nr, ng, blk, torch.cuda.current_stream().cuda_stream)
+        torch.cuda.synchronize()
+        assert (cell_lo, nbytes) == (0, lime_amd.sim_bytes(nr, ng))
+        assert np.array_equal(blk[:nr * ng].cpu().numpy().reshape(nr, ng), exp) and (s.n_clusters, s.max_len) == (nc, ml)
+        ctx.close()
         comm.close()
     finally:
         dist.destroy_process_group()

@@ -33,7 +33,8 @@ def test_example_paired_end_chain_matches_reference(tmp_path):
     tax = {}
     for row in bytes(z["lineage"]).decode().splitlines()[1:]:
         f = row.split(";")
-        tax[f[0]] = f[1]
+        if len(f) > 1:
+            tax[f[0]] = f[1]
     species = [tax[a] for a in G.DB]
     right = wrong = ctrl_hit = 0
     for ln in files["classification.txt"].decode().splitlines()[1:]:
