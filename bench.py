@@ -111,7 +111,7 @@ def cpu_baseline(wl, lcp_t, da_t, eb_t, n, sample_n):
             "nproc": os.cpu_count(), "affinity_cpus": len(aff), "runs": runs}
 
 
-def run_pass_series(torch, lime_amd, ldist, wl, n_total, steps, warmup, world, rank, dev, comm, overlap):
+def run_pass_series(torch, lime_amd, ldist, wl, n_total, steps, warmup, world, rank, dev, comm, overlap, exchange="dense"):
     """K timed steps of the workload on this rank's position range; returns (seconds, per-step parts, stats, n_own)."""
     lo, hi, hi_halo = ldist.shard_ranges(n_total, world)[rank]
     n_own, n_avail = hi - lo, hi_halo - lo
@@ -122,8 +122,15 @@ def run_pass_series(torch, lime_amd, ldist, wl, n_total, steps, warmup, world, r
     sim_bytes = lime_amd.sim_bytes(wl["nr"], wl["ng"])
     blk_bytes = ldist.table_block_bytes(sim_bytes, world)
     nbuf = 2 if (world > 1 and overlap) else 1
-    sims = [torch.zeros(blk_bytes * world, dtype=torch.uint8, device=dev) for _ in range(nbuf)]
-    blks = [torch.empty(blk_bytes, dtype=torch.uint8, device=dev) for _ in range(nbuf)] if world > 1 else []
+    sparse = world > 1 and exchange == "sparse"
+    if sparse:
+        # owner-partitioned exchange: no table per rank, only this rank's block of it (T / world bytes)
+        n_bins, bin_shift = ctx.records_layout(wl["nr"], wl["ng"])
+        own_block = torch.empty(((n_bins + world - 1) // world) << bin_shift, dtype=torch.uint8, device=dev)
+        sims, blks = [None], []
+    else:
+        sims = [torch.zeros(blk_bytes * world, dtype=torch.uint8, device=dev) for _ in range(nbuf)]
+        blks = [torch.empty(blk_bytes, dtype=torch.uint8, device=dev) for _ in range(nbuf)] if world > 1 else []
     stream = torch.cuda.current_stream().cuda_stream
     ex_stream = torch.cuda.Stream(device=dev) if (world > 1 and overlap) else None
     done = [None] * nbuf                       # event: the exchange that read sims[b] has completed
@@ -152,6 +159,14 @@ def run_pass_series(torch, lime_amd, ldist, wl, n_total, steps, warmup, world, r
         if done[b] is not None:                # the table buffer is free again (stream-side wait)
             torch.cuda.current_stream().wait_event(done[b])
             done[b] = None
+        if sparse:
+            # the updates leave the scan as records grouped by table bin; their owners build the table (lime_comm_exchange_records)
+            ctx.fused_records_dev(lcp, da, eb, n_own, n_avail, hi_halo == n_total, wl["nr"], wl["ng"], ALPHA, stream)
+            _s, _rc = ctx.stats(stream)
+            if _rc:
+                sys.exit(f"scan failed: rc={_rc}")
+            comm.exchange_records(ctx, wl["nr"], wl["ng"], own_block, stream)
+            return
         ctx.fused_dev(lcp, da, eb, n_own, n_avail, hi_halo == n_total, wl["nr"], wl["ng"], ALPHA, sims[b], True, stream)
         if world > 1:
             # the pass is final only once lime_get_stats has returned (a record pool that proved too small is repaired there):
@@ -207,6 +222,7 @@ def summarize(wl, r, n_total, steps):
             "kernel_ms_avg": scan_ms, "kernel_GBps": bps * r["n_own"] / scan_ms / 1e6 if scan_ms else None,
             "frac_of_hbm_peak": bps * r["n_own"] / scan_ms / 1e6 / HBM_PEAK_GBS if scan_ms else None,
             "pass_ms_avg": pass_ms, "pass_GBps": bps * r["n_own"] / pass_ms / 1e6 if pass_ms else None,
+            "pass_frac_of_hbm_peak": bps * r["n_own"] / pass_ms / 1e6 / HBM_PEAK_GBS if pass_ms else None,
             "parts_ms": r["parts"], "n_clusters": r["n_clusters"], "table_updates": r["updates"]}
 
 
@@ -219,6 +235,8 @@ def main():
     ap.add_argument("--scaling", default=None, choices=["strong", "weak"], help="N>1: strong (fixed --n-total, default) or weak (workload per GPU)")
     ap.add_argument("--n-total", type=float, default=None, help="symbols of the whole collection (strong scaling)")
     ap.add_argument("--n", type=float, default=None, help="symbols per GPU (overrides the workload's size)")
+    ap.add_argument("--exchange", default=os.environ.get("LIME_BENCH_EXCHANGE", "dense"), choices=["dense", "sparse"],
+                    help="N>1: dense = a uint8 reduce-scatter of whole tables (default); sparse = owner-partitioned exchange of update records")
     ap.add_argument("--no-cpu", action="store_true", help="skip the cpu_baseline leg")
     ap.add_argument("--no-also", action="store_true", help="skip the secondary workloads")
     ap.add_argument("--cpu-sample", type=int, default=200_000_000)
@@ -264,7 +282,7 @@ def main():
         n_total = int(args.n_total or wl["n"])
     else:
         n_total = int(args.n or wl["n"]) * world
-    r = run_pass_series(torch, lime_amd, ldist, wl, n_total, args.steps, args.warmup, world, rank, dev, comm, overlap=False)
+    r = run_pass_series(torch, lime_amd, ldist, wl, n_total, args.steps, args.warmup, world, rank, dev, comm, overlap=False, exchange=args.exchange)
     dt, n_clusters, max_len = r["dt"], r["n_clusters"], r["max_len"]
     if world > 1:
         dt = comm.max_float(dt)
@@ -275,13 +293,14 @@ def main():
         bps = 8 + wl["ebwt"]
         scan_ms, pass_ms = r["parts"]["scan"], r["parts"]["pass"]
         achieved = bps * r["n_own"] / (scan_ms * 1e-3) / 1e9 if scan_ms > 0 else 0.0
-        traffic, tsrc = None, None
+        traffic, tsrc, pass_traffic = None, None, None
         tfile = os.path.join(ROOT, "profiles", "traffic.json")        # rocprofv3 --pmc results, see DESIGN.md
         if os.path.exists(tfile) and world == 1:
             try:
                 t = json.load(open(tfile)).get(wname)
                 if t and t.get("symbols") == n_total:
                     traffic, tsrc = t["hbm_bytes_per_launch"], f"profiles/traffic.json[{wname}] ({t.get('from', '')}); file, not measured in this run"
+                    pass_traffic = t.get("pass_hbm_bytes")
             except Exception:
                 traffic = None
         kname = f"lime::k_scan<{wl['ebwt']}, 0, {1 if r['binned'] else 0}>"
@@ -290,14 +309,18 @@ def main():
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3,
             "higher_is_better": True, "scaling": scaling, "vs_baseline": None, "dtype": "u8", "data": "synthetic",
             "config": {"workload": describe(wl, n_total, world), "symbols_total": n_total,
-                       "sharding": (f"position ranges x{world}; tables combined by one uint8 reduce-scatter per step through the C ABI "
-                                    f"(RCCL), exposed (the step waits for it)") if world > 1 else "one GPU",
+                       "sharding": ((f"position ranges x{world}; tables combined by one uint8 reduce-scatter per step through the C ABI "
+                                     f"(RCCL), exposed (the step waits for it)") if args.exchange == "dense" else
+                                    (f"position ranges x{world}; update records exchanged owner-partitioned through the C ABI (RCCL all-gather + "
+                                     f"send/receive), every rank builds its block of the table")) if world > 1 else "one GPU",
                        "update_path": "binned (records -> bins -> table regions built in LDS)" if r["binned"] else "compare-and-swap on the table",
                        "n_clusters": int(n_clusters), "max_cluster_len": int(max_len), "table_updates_rank0": r["updates"]},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
                          "traffic": traffic, "traffic_source": tsrc, "kernel": kname, "kernel_ms_avg": scan_ms,
                          "launches_timed": r["launches"], "algorithmic_bytes_per_launch": bps * r["n_own"],
                          "pass_ms_avg": pass_ms, "pass_achieved": bps * r["n_own"] / (pass_ms * 1e-3) / 1e9 if pass_ms else None,
+                         "pass_frac": bps * r["n_own"] / (pass_ms * 1e-3) / 1e9 / HBM_PEAK_GBS if pass_ms else None,
+                         "pass_traffic": pass_traffic,          # HBM bytes of ALL kernels of a pass (same source as `traffic`, which covers the scan kernel alone)
                          "pass_parts_ms": r["parts"]},
         }
     if world == 1 and rank == 0 and not args.no_cpu:
@@ -329,6 +352,12 @@ def main():
             also["overlapped"] = {"what": "the same series with the exchange of step k under the scan of step k+1 (two table buffers)",
                                   "value": n_total * args.steps / dt2, "ms_per_step": dt2 / args.steps * 1e3}
             del r2
+            if os.environ.get("LIME_BENCH_SPARSE") == "1" and args.exchange == "dense":
+                r3 = run_pass_series(torch, lime_amd, ldist, wl, n_total, args.steps, args.warmup, world, rank, dev, comm, overlap=False, exchange="sparse")
+                dt3 = comm.max_float(r3["dt"])
+                also["sparse_exchange"] = {"what": "the same series with the owner-partitioned exchange of update records instead of the dense reduce-scatter",
+                                           "value": n_total * args.steps / dt3, "ms_per_step": dt3 / args.steps * 1e3}
+                del r3
         if rank == 0:
             out["also"] = also
     if rank == 0:

@@ -907,6 +907,33 @@ struct Feeder {
 };
 }
 
+// Host arrays -> device buffers through the pinned staging ring, asynchronous pieces on `st`, complete on return
+// (lime_fused_multi: one host thread per device calls this, so k devices upload at k times the rate of one).
+int lime_internal_upload(int n_arr, const void *const *src, void *const *dst, const size_t *bytes, hipStream_t st)
+{
+    const size_t CH = (size_t)32 << 20;                   // bytes per array and chunk
+    size_t total = 0, longest = 0;
+    bool pinned = true;
+    for (int i = 0; i < n_arr; ++i) { total += bytes[i]; if (bytes[i] > longest) longest = bytes[i]; pinned = pinned && Feeder::pinned(src[i]); }
+    if (!total) return LIME_OK;
+    if (n_arr > Feeder::MAXP) return fail(LIME_ERR_ARG, "lime_internal_upload: too many arrays");
+    const uint64_t n_chunks = (longest + CH - 1) / CH;
+    Feeder feeder;
+    int rc = feeder.init((size_t)n_arr * (CH + 16), n_chunks, pinned, [&](uint64_t k, Piece *pc) {
+        int np = 0;
+        for (int i = 0; i < n_arr; ++i) {
+            const size_t off = (size_t)k * CH;
+            if (off >= bytes[i]) continue;
+            pc[np++] = Piece{(const char *)src[i] + off, bytes[i] - off < CH ? bytes[i] - off : CH, (char *)dst[i] + off};
+        }
+        return np;
+    });
+    if (rc) return rc;
+    for (uint64_t k = 0; k < n_chunks; ++k) if ((rc = feeder.feed(k, st))) { (void)hipStreamSynchronize(st); return rc; }
+    HIP_TRY(hipStreamSynchronize(st));
+    return LIME_OK;
+}
+
 extern "C" int lime_fused_stream(lime_ctx *c, const uint32_t *lcp, const uint32_t *da, const uint8_t *ebwt, uint64_t n,
                                  uint32_t n_reads, uint32_t n_refs, uint32_t alpha, uint64_t chunk, uint8_t *sim,
                                  uint64_t *n_clusters, uint64_t *max_len)

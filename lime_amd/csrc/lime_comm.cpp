@@ -12,7 +12,10 @@
 #include <stdarg.h>
 #include <stdio.h>
 #include <string.h>
+#include <map>
+#include <mutex>
 #include <string>
+#include <thread>
 #include <vector>
 
 #include "lime_hip.h"
@@ -25,6 +28,10 @@ typedef struct { char internal[128]; } ncclUniqueId;
 typedef int ncclResult_t;
 enum { nccl_Sum = 0, nccl_Max = 2, nccl_Uint8 = 1, nccl_Uint32 = 3, nccl_Uint64 = 5 };   // rccl.h: ncclRedOp_t / ncclDataType_t
 }
+
+#if __has_include(<rccl/rccl.h>)
+// the values declared above, checked against the installed header (its own translation unit: lime_rccl_check.cpp)
+#endif
 
 namespace {
 struct Rccl {
@@ -229,12 +236,33 @@ extern "C" int lime_comm_exchange_records(lime_comm *c, lime_ctx *ctx, uint32_t 
     return LIME_OK;
 }
 
+// the communicators of one process driving several GPUs: created once per device list (ncclCommInitAll costs hundreds of
+// milliseconds), kept for the life of the process
+static std::mutex g_multi_mu;
+static std::map<std::vector<int>, std::vector<ncclComm_t>> g_multi_comms;
+static int multi_comms(int n_dev, const int *devs, std::vector<ncclComm_t> **out)
+{
+    std::lock_guard<std::mutex> g(g_multi_mu);
+    std::vector<int> key(devs, devs + n_dev);
+    auto it = g_multi_comms.find(key);
+    if (it == g_multi_comms.end()) {
+        std::vector<ncclComm_t> comms(n_dev, nullptr);
+        NCCL_TRY(g_rccl.CommInitAll(comms.data(), n_dev, devs));
+        it = g_multi_comms.emplace(key, std::move(comms)).first;
+    }
+    *out = &it->second;
+    return LIME_OK;
+}
+
+int lime_internal_upload(int n_arr, const void *const *src, void *const *dst, const size_t *bytes, hipStream_t st);   // lime_api.cpp: through the pinned staging ring
+
 // all devices of one process: device k ends with block k of the summed tables (internal; lime_api.cpp uses it too)
 int lime_internal_reduce_scatter(int n_dev, const int *devs, uint8_t *const *d_sim, uint8_t *const *d_blk, size_t blk)
 {
     int rc = load_rccl(); if (rc) return rc;
-    std::vector<ncclComm_t> comms(n_dev, nullptr);
-    NCCL_TRY(g_rccl.CommInitAll(comms.data(), n_dev, devs));
+    std::vector<ncclComm_t> *pc = nullptr;
+    if ((rc = multi_comms(n_dev, devs, &pc))) return rc;
+    std::vector<ncclComm_t> &comms = *pc;
     rc = LIME_OK;
     if (g_rccl.GroupStart() != 0) rc = cfail(LIME_ERR_HIP, "ncclGroupStart failed");
     for (int k = 0; k < n_dev && !rc; ++k) {
@@ -244,7 +272,6 @@ int lime_internal_reduce_scatter(int n_dev, const int *devs, uint8_t *const *d_s
     }
     if (!rc && g_rccl.GroupEnd() != 0) rc = cfail(LIME_ERR_HIP, "ncclGroupEnd failed");
     for (int k = 0; k < n_dev; ++k) { (void)hipSetDevice(devs[k]); (void)hipDeviceSynchronize(); }
-    for (int k = 0; k < n_dev; ++k) if (comms[k]) (void)g_rccl.CommDestroy(comms[k]);
     return rc;
 }
 
@@ -291,30 +318,45 @@ extern "C" int lime_fused_multi(int n_dev, const int *devices, const uint32_t *l
         const uint64_t hi = (k == n_dev - 1) ? n : (t1 * LIME_TILE < n ? t1 * LIME_TILE : n);
         own[k] = hi - lo[k];
         avail[k] = hi < n ? ((hi + halo < n ? hi + halo : n) - lo[k]) : n - lo[k];
-        DevSet &d = ds[k];
-        HIP_TRYC(hipSetDevice(devs[k]));
-        d.dev = devs[k];
-        if ((rc = lime_init(devs[k], &d.ctx))) return cfail(rc, "lime_init(device %d): %s", devs[k], lime_last_error());
-        HIP_TRYC(hipStreamCreateWithFlags(&d.st, hipStreamNonBlocking));
-        HIP_TRYC(hipMalloc(&d.lcp, avail[k] * 4 + 16)); HIP_TRYC(hipMalloc(&d.da, avail[k] * 4 + 16));
-        if (ebwt) HIP_TRYC(hipMalloc(&d.ebwt, avail[k] + 16));
-        HIP_TRYC(hipMalloc(&d.sim, blk * n_dev)); HIP_TRYC(hipMalloc(&d.blk, blk));
-        if (blk * n_dev > sim_bytes) HIP_TRYC(hipMemsetAsync(d.sim + sim_bytes, 0, blk * n_dev - sim_bytes, d.st));
-        HIP_TRYC(hipMemcpyAsync(d.lcp, lcp + lo[k], avail[k] * 4, hipMemcpyHostToDevice, d.st));
-        HIP_TRYC(hipMemcpyAsync(d.da, da + lo[k], avail[k] * 4, hipMemcpyHostToDevice, d.st));
-        if (ebwt) HIP_TRYC(hipMemcpyAsync(d.ebwt, ebwt + lo[k], avail[k], hipMemcpyHostToDevice, d.st));
-        rc = lime_fused_dev(d.ctx, d.lcp, d.da, d.ebwt, own[k], avail[k], lo[k] + avail[k] == n, n_reads, n_refs, alpha, d.sim, 1, d.st);
-        if (rc) return cfail(rc, "device %d: %s", devs[k], lime_last_error());
+    }
+    // a host thread per device: context, buffers, its range through the pinned staging ring (per-thread FILE* readers in the
+    // reference, ClusterLCP.cpp:100-123; k devices upload at k times the PCIe rate of one), the pass, its counters
+    std::vector<int> rcs(n_dev, LIME_OK);
+    std::vector<std::string> errs(n_dev);
+    std::vector<lime_stats_t> stats(n_dev);
+    {
+        std::vector<std::thread> th;
+        for (int k = 0; k < n_dev; ++k)
+            th.emplace_back([&, k]() {
+                DevSet &d = ds[k];
+                auto bad = [&](int code, const std::string &what) { rcs[k] = code; errs[k] = what; };
+                auto hipok = [&](hipError_t e, const char *what) { if (e == hipSuccess) return true; bad(e == hipErrorOutOfMemory ? LIME_ERR_NOMEM : LIME_ERR_HIP, std::string(what) + ": " + hipGetErrorString(e)); return false; };
+                if (!hipok(hipSetDevice(devs[k]), "hipSetDevice")) return;
+                d.dev = devs[k];
+                int r = lime_init(devs[k], &d.ctx);
+                if (r) { bad(r, std::string("lime_init: ") + lime_last_error()); return; }
+                if (!hipok(hipStreamCreateWithFlags(&d.st, hipStreamNonBlocking), "hipStreamCreate")) return;
+                if (!hipok(hipMalloc(&d.lcp, avail[k] * 4 + 16), "hipMalloc") || !hipok(hipMalloc(&d.da, avail[k] * 4 + 16), "hipMalloc")) return;
+                if (ebwt && !hipok(hipMalloc(&d.ebwt, avail[k] + 16), "hipMalloc")) return;
+                if (!hipok(hipMalloc(&d.sim, blk * n_dev), "hipMalloc") || !hipok(hipMalloc(&d.blk, blk), "hipMalloc")) return;
+                if (blk * n_dev > sim_bytes && !hipok(hipMemsetAsync(d.sim + sim_bytes, 0, blk * n_dev - sim_bytes, d.st), "hipMemsetAsync")) return;
+                const void *src[3] = {lcp + lo[k], da + lo[k], ebwt ? ebwt + lo[k] : nullptr};
+                void *dst[3] = {d.lcp, d.da, d.ebwt};
+                const size_t bytes[3] = {(size_t)avail[k] * 4, (size_t)avail[k] * 4, ebwt ? (size_t)avail[k] : 0};
+                if ((r = lime_internal_upload(ebwt ? 3 : 2, src, dst, bytes, d.st))) { bad(r, std::string("upload: ") + lime_last_error()); return; }
+                r = lime_fused_dev(d.ctx, d.lcp, d.da, d.ebwt, own[k], avail[k], lo[k] + avail[k] == n, n_reads, n_refs, alpha, d.sim, 1, d.st);
+                if (r) { bad(r, lime_last_error()); return; }
+                r = lime_get_stats(d.ctx, &stats[k], d.st);
+                if (r && !(r == LIME_ERR_HALO && (stats[k].edge & LIME_EDGE_OPEN))) bad(r, lime_last_error());
+            });
+        for (auto &t : th) t.join();
     }
     uint64_t tot = 0, mx = 0;
     std::vector<uint32_t> edges(n_dev);
     for (int k = 0; k < n_dev; ++k) {
-        HIP_TRYC(hipSetDevice(devs[k]));
-        lime_stats_t s;
-        rc = lime_get_stats(ds[k].ctx, &s, ds[k].st);
-        if (rc && !(rc == LIME_ERR_HALO && (s.edge & LIME_EDGE_OPEN))) return cfail(rc, "device %d: %s", devs[k], lime_last_error());
-        tot += s.n_clusters; if (s.max_len > mx) mx = s.max_len;
-        edges[k] = s.edge;
+        if (rcs[k]) return cfail(rcs[k], "device %d: %s", devs[k], errs[k].c_str());
+        tot += stats[k].n_clusters; if (stats[k].max_len > mx) mx = stats[k].max_len;
+        edges[k] = stats[k].edge;
     }
     // runs longer than the halo across range borders: clusters among them are refused, the others are nothing
     if ((rc = lime_combine_edges(edges.data(), (uint32_t)n_dev))) return cfail(rc, "%s", lime_last_error());
@@ -326,8 +368,9 @@ extern "C" int lime_fused_multi(int n_dev, const int *devices, const uint32_t *l
         HIP_TRYC(hipStreamSynchronize(ds[0].st));
         return LIME_OK;
     }
-    std::vector<ncclComm_t> comms(n_dev, nullptr);
-    NCCL_TRY(g_rccl.CommInitAll(comms.data(), n_dev, devs.data()));
+    std::vector<ncclComm_t> *pc = nullptr;
+    if ((rc = multi_comms(n_dev, devs.data(), &pc))) return rc;
+    std::vector<ncclComm_t> &comms = *pc;
     rc = LIME_OK;
     if (g_rccl.GroupStart() != 0) rc = cfail(LIME_ERR_HIP, "ncclGroupStart failed");
     for (int k = 0; k < n_dev && !rc; ++k) {
@@ -346,6 +389,5 @@ extern "C" int lime_fused_multi(int n_dev, const int *devices, const uint32_t *l
         if (e != hipSuccess) rc = cfail(LIME_ERR_HIP, "hipMemcpyAsync: %s", hipGetErrorString(e));
     }
     for (int k = 0; k < n_dev; ++k) { (void)hipSetDevice(devs[k]); (void)hipStreamSynchronize(ds[k].st); }
-    for (int k = 0; k < n_dev; ++k) if (comms[k]) (void)g_rccl.CommDestroy(comms[k]);
     return rc;
 }

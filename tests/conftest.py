@@ -11,7 +11,7 @@ if ROOT not in sys.path:
 
 GOLDEN_DIR = os.path.join(ROOT, "tests", "golden")
 GOLDEN_CASES = sorted(os.path.splitext(os.path.basename(p))[0] for p in glob.glob(os.path.join(GOLDEN_DIR, "*.npz"))
-                      if not os.path.basename(p).startswith("classify_"))   # those: tests/test_classify_cpu.py
+                      if not os.path.basename(p).startswith(("classify_", "example_")))   # those: tests/test_classify_cpu.py, tests/test_example_gpu.py
 
 
 def pytest_configure(config):

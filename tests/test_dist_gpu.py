@@ -128,6 +128,13 @@ def test_bench_control_flow_with_two_ranks():
     d = json.loads(line)
     assert d["n_gpus"] == 2 and d["scaling"] == "strong" and d["value"] > 0 and d["also"]["overlapped"]["value"] > 0
     assert d["config"]["symbols_total"] == 30000000
+    # the same series with the owner-partitioned exchange of update records
+    r = _torchrun(["bench.py", "--gpus", "2", "--steps", "2", "--warmup", "1", "--workload", "c2", "--scaling", "strong",
+                   "--n-total", "30000000", "--exchange", "sparse", "--no-also"], {"LIME_BENCH_BACKEND": "gloo"})
+    assert r.returncode == 0, r.stderr.decode()[-3000:]
+    d2 = json.loads([ln for ln in r.stdout.decode().splitlines() if ln.startswith("{")][-1])
+    assert d2["n_gpus"] == 2 and d2["value"] > 0 and "owner-partitioned" in d2["config"]["sharding"]
+    assert d2["config"]["n_clusters"] == d["config"]["n_clusters"]
 
 
 def test_rccl_calls_through_the_c_abi_on_one_rank():
