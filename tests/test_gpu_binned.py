@@ -173,3 +173,59 @@ def test_binned_random_shapes(monkeypatch, seed):
             assert np.array_equal(sim, exp), (nr, ng, levels, int((sim != exp).sum()))
     finally:
         c.close()
+
+
+def test_overflowed_pass_followed_by_another_without_stats_is_an_error(monkeypatch):
+    """Two different shards through one ctx with no lime_get_stats between them, the FIRST denser than the pool: its table is
+    short and can no longer be repaired (the arrays were replaced).  The next lime_get_stats must say so (LIME_ERR_NOMEM)
+    instead of returning a quietly incomplete table; the ctx is usable again afterwards."""
+    import torch
+    import lime_amd
+    from lime_amd._lib import ERR_NOMEM
+    monkeypatch.setenv("LIME_UPDATE_PATH", "bin")
+    monkeypatch.setenv("LIME_POOL_DENSITY", "0.001")
+    c = lime_amd.Context()
+    try:
+        n, nr, ng = 1500000, 3000, 300
+        dense = O.synth(5, 0, n, nr, ng, 16, 1)                       # ~0.1 updates per symbol: overflows a pool for 0.001
+        lcp2 = np.zeros(n, np.uint32); da2 = np.zeros(n, np.uint32)   # no clusters at all: fits any pool
+        dev = "cuda"
+        t1 = [torch.from_numpy(x.view(np.int32) if x.dtype == np.uint32 else x).to(dev) for x in dense]
+        t2 = [torch.from_numpy(lcp2.view(np.int32)).to(dev), torch.from_numpy(da2.view(np.int32)).to(dev)]
+        sim1 = torch.empty(lime_amd.sim_bytes(nr, ng), dtype=torch.uint8, device=dev)
+        sim2 = torch.empty_like(sim1)
+        c.fused_dev(t1[0], t1[1], t1[2], n, n, True, nr, ng, 16, sim1)      # overflows; not settled
+        c.fused_dev(t2[0], t2[1], None, n, n, True, nr, ng, 16, sim2)       # another pass on the ctx
+        s, rc = c.stats()
+        assert rc == ERR_NOMEM
+        # settled one by one, both are right
+        cl, nc, ml = O.detect(dense[0], dense[1], nr, 16)
+        exp = O.score(dense[1], dense[2], cl, nr, ng, threads=4)
+        c.fused_dev(t1[0], t1[1], t1[2], n, n, True, nr, ng, 16, sim1)
+        s, rc = c.stats(); assert rc == 0 and s.n_clusters == nc
+        assert np.array_equal(sim1[:nr * ng].cpu().numpy().reshape(nr, ng), exp)
+        c.fused_dev(t2[0], t2[1], None, n, n, True, nr, ng, 16, sim2)
+        s, rc = c.stats(); assert rc == 0 and s.n_clusters == 0 and int(sim2.count_nonzero()) == 0
+    finally:
+        c.close()
+
+
+def test_stream_chunks_stay_off_the_binned_path(monkeypatch):
+    """lime_fused_stream with the binned path forced, a pool far too small and several chunks: chunk 0 must not leave
+    records behind that a later repeat would apply to buffers holding another chunk (round 2 advisor finding)"""
+    import lime_amd
+    monkeypatch.setenv("LIME_UPDATE_PATH", "bin")
+    monkeypatch.setenv("LIME_POOL_DENSITY", "0.001")
+    c = lime_amd.Context()
+    try:
+        n, nr, ng = 1300001, 2000, 200
+        lcp, da, eb = O.synth(41, 0, n, nr, ng, 16, 1)
+        cl, nc, ml = O.detect(lcp, da, nr, 16)
+        for e in (eb, None):
+            exp = O.score(da, e, cl, nr, ng, threads=4)
+            sim, gnc, gml = c.fused_stream(lcp, da, e, nr, ng, 16, chunk=400000)      # 4 chunks
+            assert (gnc, gml) == (nc, ml) and np.array_equal(sim, exp)
+            sim, gnc, gml = c.fused_stream(lcp, da, e, nr, ng, 16, chunk=2 * n)       # one chunk: binned, overflow, repeated
+            assert (gnc, gml) == (nc, ml) and np.array_equal(sim, exp)
+    finally:
+        c.close()

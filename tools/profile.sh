@@ -3,7 +3,7 @@
 # --workload WORKLOAD` (default c3 = the headline) on the GPU box; writes under gpurun_out/prof_TAG, then
 # tools/summarize_profile.py TAG WORKLOAD copies the summaries into profiles/ (run it on the box or afterwards).
 # The program itself follows `--` (python3 bench.py ...): no env / bash -c hop under the profiler.
-TAG=${1:-r02}
+TAG=${1:-r03}
 WL=${2:-c3}
 OUT=$PWD/gpurun_out/prof_$TAG
 rm -rf $OUT; mkdir -p $OUT
@@ -11,7 +11,7 @@ export TMPDIR=/tmp
 ARGS="bench.py --steps 5 --warmup 2 --no-cpu --no-also --workload $WL"
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -- python3 $ARGS > $OUT/trace.log 2>&1
 echo "trace rc=$?"
-rocprofv3 --pmc SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS --output-format csv -d $OUT/pmc1 -- python3 $ARGS > $OUT/pmc1.log 2>&1
+rocprofv3 --pmc SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_ACTIVE_INST_VALU SQ_INSTS --output-format csv -d $OUT/pmc1 -- python3 $ARGS > $OUT/pmc1.log 2>&1
 echo "pmc1 rc=$?"
 rocprofv3 --pmc SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_INSTS_VMEM SQ_INSTS_SMEM SQ_WAIT_INST_LDS --output-format csv -d $OUT/pmc2 -- python3 $ARGS > $OUT/pmc2.log 2>&1
 echo "pmc2 rc=$?"

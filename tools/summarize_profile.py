@@ -70,6 +70,11 @@ def main():
             "hbm_bytes_per_launch": int(2 * s["FETCH_SIZE"] * 1024 + s["WRITE_SIZE"] * 1024),
             "FETCH_SIZE_KiB": s["FETCH_SIZE"], "WRITE_SIZE_KiB": s["WRITE_SIZE"], "TCC_EA0_ATOMIC_sum": s.get("TCC_EA0_ATOMIC_sum"),
             "algorithmic_bytes_per_launch": bench["roofline"]["algorithmic_bytes_per_launch"] if bench else None,
+            # all kernels of one pass (scan, resolve, bin prefix sums, partition levels, table build, long clusters): each kernel's
+            # per-launch average; the kernels of a pass are launched once per pass
+            "pass_hbm_bytes": int(sum(2 * v.get("FETCH_SIZE", 0.0) * 1024 + v.get("WRITE_SIZE", 0.0) * 1024 for k, v in summary.items()
+                                      if not any(x in k for x in ("k_synth", "k_fill", "k_choose", "k_gather")))),
+            "pass_kernels": sorted(k for k in summary if not any(x in k for x in ("k_synth", "k_fill", "k_choose", "k_gather"))),
             "from": f"profiles/{tag}_pmc_summary.json: HBM bytes = 2 x FETCH_SIZE x 1024 (gfx950 counts 128-B requests at 64 B) + WRITE_SIZE x 1024, "
                     f"separate --pmc passes of tools/profile.sh {tag} {wl}, averages over {s['launches']} launches",
         }
