@@ -242,7 +242,7 @@ def main():
     ap.add_argument("--cpu-sample", type=int, default=200_000_000)
     args = ap.parse_args()
 
-    for var in ("LIME_ABLATE", "LIME_MAX_BLOCKS", "LIME_POOL_DENSITY", "LIME_BIN_LEVELS"):
+    for var in ("LIME_ABLATE", "LIME_MAX_BLOCKS", "LIME_POOL_DENSITY", "LIME_POOL_SLACK", "LIME_BIN_LEVELS"):
         if os.environ.get(var):
             sys.exit(f"bench.py refuses to run with {var} set: it changes what is measured")
 

@@ -330,7 +330,6 @@ __device__ __forceinline__ void drain_bin(UpdQueue &q, const ScanArgs &a)
         const uint64_t cell = (uint64_t)rd * a.n_refs + (gt & (MAX_REFS - 1u));
         const uint32_t hi = (uint32_t)(cell >> 32);
         uint32_t left = (on && !bad) ? gt >> T_SHIFT : 0u;
-        if (left && !ABL(7)) atomicAdd(&q.hist[(uint32_t)(cell >> a.bin_shift)], left);
         while (__ballot(left != 0u)) {                            // once, unless a pair scored more than 1
             for (uint32_t sub = 0; sub < a.n_sub; ++sub) {        // wave-uniform; one sub-region for tables below 4 GB
                 const bool mine = left != 0u && hi == sub;
@@ -338,8 +337,10 @@ __device__ __forceinline__ void drain_bin(UpdQueue &q, const ScanArgs &a)
                 if (!m) continue;
                 const uint32_t base = q.sub_n[sub];               // LDS, one address: a broadcast read
                 const uint32_t slot = base + rank_in(m);
-                if (mine && slot < a.cap_w && !ABL(6) && !ABL(7))
-                    __builtin_nontemporal_store((uint32_t)cell, q.out + (size_t)sub * a.cap_w + slot);
+                if (mine && slot < a.cap_w && !ABL(7)) {          // a full sub-region only counts (sub_n): the pass is repeated with a larger pool
+                    atomicAdd(&q.hist[(uint32_t)(cell >> a.bin_shift)], 1u);     // the histogram counts exactly the records that are stored
+                    if (!ABL(6)) __builtin_nontemporal_store((uint32_t)cell, q.out + (size_t)sub * a.cap_w + slot);
+                }
                 if (lane == 0) q.sub_n[sub] = base + (uint32_t)__popcll(m);
             }
             left -= (uint32_t)(left != 0u);

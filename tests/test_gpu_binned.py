@@ -105,6 +105,7 @@ def test_binned_pool_too_small_is_repeated(monkeypatch):
     import lime_amd
     monkeypatch.setenv("LIME_UPDATE_PATH", "bin")
     monkeypatch.setenv("LIME_POOL_DENSITY", "0.001")
+    monkeypatch.setenv("LIME_POOL_SLACK", "0")
     c = lime_amd.Context()
     try:
         n, nr, ng = 2500000, 3000, 300
@@ -175,6 +176,30 @@ def test_binned_random_shapes(monkeypatch, seed):
         c.close()
 
 
+@pytest.mark.parametrize("nr,ng,levels", [(3000, 300, None), (200000, 3000, None), (150000, 3000, "4,7")])
+def test_binned_pool_overflows_badly_and_is_repeated(monkeypatch, nr, ng, levels):
+    """a pool with room for a few records per wave on an input with hundreds per window (LIME_POOL_SLACK=0): nearly every
+    record of the first attempt is dropped -- its counters and lists must stay consistent with what WAS stored (nothing may be
+    written past the record buffers) -- and lime_get_stats repeats the pass until the table is the oracle's"""
+    import lime_amd
+    monkeypatch.setenv("LIME_UPDATE_PATH", "bin")
+    monkeypatch.setenv("LIME_POOL_DENSITY", "0.0001")
+    monkeypatch.setenv("LIME_POOL_SLACK", "0")
+    if levels:
+        monkeypatch.setenv("LIME_BIN_LEVELS", levels)
+    c = lime_amd.Context()
+    try:
+        n = 6000000
+        lcp, da, eb = O.synth(91, 0, n, nr, ng, 16, 1)
+        cl, nc, ml = O.detect(lcp, da, nr, 16)
+        for e in (eb, None):
+            exp = O.score(da, e, cl, nr, ng, threads=4)
+            sim, gnc, gml = c.fused(lcp, da, e, nr, ng, 16)
+            assert (gnc, gml) == (nc, ml) and np.array_equal(sim, exp)
+    finally:
+        c.close()
+
+
 def test_overflowed_pass_followed_by_another_without_stats_is_an_error(monkeypatch):
     """Two different shards through one ctx with no lime_get_stats between them, the FIRST denser than the pool: its table is
     short and can no longer be repaired (the arrays were replaced).  The next lime_get_stats must say so (LIME_ERR_NOMEM)
@@ -184,6 +209,7 @@ def test_overflowed_pass_followed_by_another_without_stats_is_an_error(monkeypat
     from lime_amd._lib import ERR_NOMEM
     monkeypatch.setenv("LIME_UPDATE_PATH", "bin")
     monkeypatch.setenv("LIME_POOL_DENSITY", "0.001")
+    monkeypatch.setenv("LIME_POOL_SLACK", "0")
     c = lime_amd.Context()
     try:
         n, nr, ng = 1500000, 3000, 300
@@ -216,6 +242,7 @@ def test_stream_chunks_stay_off_the_binned_path(monkeypatch):
     import lime_amd
     monkeypatch.setenv("LIME_UPDATE_PATH", "bin")
     monkeypatch.setenv("LIME_POOL_DENSITY", "0.001")
+    monkeypatch.setenv("LIME_POOL_SLACK", "0")
     c = lime_amd.Context()
     try:
         n, nr, ng = 1300001, 2000, 200

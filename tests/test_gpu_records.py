@@ -91,6 +91,7 @@ def test_records_of_a_pool_that_is_too_small_are_repaired(monkeypatch):
     import torch
     import lime_amd
     monkeypatch.setenv("LIME_POOL_DENSITY", "0.0005")
+    monkeypatch.setenv("LIME_POOL_SLACK", "0")
     n, nr, ng = 2000000, 2000, 64
     lcp, da, eb = O.synth(77, 0, n, nr, ng, 16, 1)
     cl, nc, ml = O.detect(lcp, da, nr, 16)

@@ -165,6 +165,34 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))) voi
                 if (SMODE == 9) __builtin_nontemporal_store(((uint64_t)part << 8) | lane, reg + at); else reg[at] = ((uint64_t)part << 8) | lane;
             }
             out_n += recs;
+        } else if (SMODE == 12 || SMODE == 13) {
+            // window-indexed slots: window w writes at pool + w * slot -- the band of windows in flight is contiguous, so the
+            // stores sweep the pool sequentially like the loads sweep the arrays (12: 8-byte records, 13: 4-byte records)
+            if (SMODE == 12) {
+                uint64_t *dst = pool + (size_t)win * cap_w;
+                for (uint32_t k0 = 0; k0 < recs; k0 += 64u) if (k0 + lane < recs) __builtin_nontemporal_store(((uint64_t)part << 8) | lane, dst + k0 + lane);
+            } else {
+                uint32_t *dst = reinterpret_cast<uint32_t *>(pool) + (size_t)win * cap_w;
+                for (uint32_t k0 = 0; k0 < recs; k0 += 64u) if (k0 + lane < recs) __builtin_nontemporal_store(part + lane, dst + k0 + lane);
+            }
+        } else if (SMODE == 14) {
+            if ((iter & 7u) == 7u) for (int rep = 0; rep < 8; ++rep) stores(part);
+        } else if (SMODE == 16) {
+            for (uint32_t k0 = 0; k0 < recs; k0 += 64u)
+                if (k0 + lane < recs && out_n + k0 + lane < cap_w) __hip_atomic_exchange(reg + out_n + k0 + lane, ((uint64_t)part << 8) | lane, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            out_n += recs;
+        } else if (SMODE == 17) {
+            // the same stores written in inline assembly: the compiler's s_waitcnt pass does not know they are outstanding and
+            // keeps its tight counted waits on the loads (safe: vmcnt(N) can only wait LONGER with more operations in flight)
+            for (uint32_t k0 = 0; k0 < recs; k0 += 64u) {
+                const uint32_t k = k0 + lane;
+                if (k < recs && out_n + k < cap_w) {
+                    const uint64_t r = ((uint64_t)part << 8) | k;
+                    uint64_t *addr = reg + out_n + k;
+                    asm volatile("global_store_dwordx2 %0, %1, off nt" :: "v"(addr), "v"(r) : "memory");
+                }
+            }
+            out_n += recs;
         } else if (SMODE == 8) {
             uint32_t *r4 = reinterpret_cast<uint32_t *>(reg);
             for (uint32_t k0 = 0; k0 < recs; k0 += 64u) if (out_n + k0 + lane < 2u * cap_w) __builtin_nontemporal_store(part + lane, r4 + out_n + k0 + lane);
@@ -295,8 +323,25 @@ int main(int argc, char **argv)
         timeit("split: 3 loading waves + 1 storing wave per workgroup, no stores", bytes, [&] { hipLaunchKernelGGL((k_split<1>), g3, blk, 0, 0, lcp, da, n_win, 16u, pool, cap_w, 0u, out); });
         timeit("split: 3 loading waves + 1 storing wave (nt, 1 GB)", b2, [&] { hipLaunchKernelGGL((k_split<1>), g3, blk, 0, 0, lcp, da, n_win, 16u, pool, cap_w, recs, out); });
         timeit("split: 3 loading waves + 1 storing wave (plain, 1 GB)", b2, [&] { hipLaunchKernelGGL((k_split<0>), g3, blk, 0, 0, lcp, da, n_win, 16u, pool, cap_w, recs, out); });
+        {
+            uint64_t *wpool; CK(hipMalloc(&wpool, (size_t)n_win * 256 * 8 + 64));
+            timeit("A + window-indexed slots of 128 x 8 B (dense)", b2, [&] { hipLaunchKernelGGL((k_mix<12>), g3, blk, 0, 0, lcp, da, n_win, 16u, wpool, 128u, recs, out); });
+            timeit("A + window-indexed slots of 256 x 8 B (half used)", b2, [&] { hipLaunchKernelGGL((k_mix<12>), g3, blk, 0, 0, lcp, da, n_win, 16u, wpool, 256u, recs, out); });
+            timeit("A + window-indexed slots of 128 x 4 B (dense, 0.5 GB)", bytes + (uint64_t)n_win * recs * 4, [&] { hipLaunchKernelGGL((k_mix<13>), g3, blk, 0, 0, lcp, da, n_win, 16u, wpool, 128u, recs, out); });
+            timeit("A + window-indexed slots of 256 x 4 B (half used, 0.5 GB)", bytes + (uint64_t)n_win * recs * 4, [&] { hipLaunchKernelGGL((k_mix<13>), g3, blk, 0, 0, lcp, da, n_win, 16u, wpool, 256u, recs, out); });
+            CK(hipFree(wpool));
+        }
         timeit("A + 4-byte records (0.5 GB)", bytes + (uint64_t)n_win * recs * 4, [&] { hipLaunchKernelGGL((k_mix<8>), g3, blk, 0, 0, lcp, da, n_win, 16u, pool, cap_w, recs, out); });
         timeit("A + 64 records per window (0.5 GB)", bytes + (uint64_t)n_win * 64 * 8, [&] { hipLaunchKernelGGL((k_mix<1>), g3, blk, 0, 0, lcp, da, n_win, 16u, pool, cap_w, 64u, out); });
+        timeit("A + 8 records per window (62 MB)", bytes + (uint64_t)n_win * 8 * 8, [&] { hipLaunchKernelGGL((k_mix<1>), g3, blk, 0, 0, lcp, da, n_win, 16u, pool, cap_w, 8u, out); });
+        timeit("A + 1 record per window (8 MB)", bytes + (uint64_t)n_win * 8, [&] { hipLaunchKernelGGL((k_mix<1>), g3, blk, 0, 0, lcp, da, n_win, 16u, pool, cap_w, 1u, out); });
+        timeit("A + 8 records per window, plain stores", bytes + (uint64_t)n_win * 8 * 8, [&] { hipLaunchKernelGGL((k_mix<2>), g3, blk, 0, 0, lcp, da, n_win, 16u, pool, cap_w, 8u, out); });
+        timeit("A + 64 records every 8th window (same 62 MB)", bytes + (uint64_t)n_win * 8 * 8, [&] { hipLaunchKernelGGL((k_mix<14>), g3, blk, 0, 0, lcp, da, n_win, 16u, pool, cap_w, 8u, out); });
+        timeit("A + 8 records per window as atomic exchanges", bytes + (uint64_t)n_win * 8 * 8, [&] { hipLaunchKernelGGL((k_mix<16>), g3, blk, 0, 0, lcp, da, n_win, 16u, pool, cap_w, 8u, out); });
+        timeit("A + 128 records per window, stores every 8th window (1 GB)", b2, [&] { hipLaunchKernelGGL((k_mix<14>), g3, blk, 0, 0, lcp, da, n_win, 16u, pool, cap_w, recs, out); });
+        timeit("A + 8 records per window, asm stores", bytes + (uint64_t)n_win * 8 * 8, [&] { hipLaunchKernelGGL((k_mix<17>), g3, blk, 0, 0, lcp, da, n_win, 16u, pool, cap_w, 8u, out); });
+        timeit("A + 64 records per window, asm stores (0.5 GB)", bytes + (uint64_t)n_win * 64 * 8, [&] { hipLaunchKernelGGL((k_mix<17>), g3, blk, 0, 0, lcp, da, n_win, 16u, pool, cap_w, 64u, out); });
+        timeit("A + 128 records per window, asm stores (1 GB)", b2, [&] { hipLaunchKernelGGL((k_mix<17>), g3, blk, 0, 0, lcp, da, n_win, 16u, pool, cap_w, recs, out); });
         timeit("A + 32 records per window (0.25 GB)", bytes + (uint64_t)n_win * 32 * 8, [&] { hipLaunchKernelGGL((k_mix<1>), g3, blk, 0, 0, lcp, da, n_win, 16u, pool, cap_w, 32u, out); });
         CK(hipFree(pool));
     }
