@@ -85,7 +85,7 @@ struct alignas(16) WaveLds {
 // threads per workgroup of k_scan (its waves work independently) and waves per SIMD it is compiled for: ScanCfg in
 // lime_kernels.h (EBWT = 0: 8 waves, two workgroups per CU = 4 waves per SIMD; EBWT = 1: 4 waves, three workgroups)
 constexpr uint32_t DUP_SLOTS = 8;     // clusters with a repeated document a wave of k_scan holds before scoring them
-constexpr uint32_t QCAP_SCAN = 256;   // >= the 256 hits one batch of 64 clusters of <= 4 symbols can add
+constexpr uint32_t QCAP_SCAN = 286;   // >= the 256 hits one batch of 64 clusters of <= 4 symbols can add + the 2 x 15 entries a binned drain leaves behind
 
 __device__ __forceinline__ uint32_t lane_id() { return threadIdx.x & 63u; }
 // The kernel's ScanArgs (always its first argument) re-read from the kernarg segment at the point of use: fields that only
@@ -312,16 +312,37 @@ __device__ __forceinline__ void drain_async(UpdQueue &q, const ScanArgs &a)
 // Binned mode: the queue's entries become pool records cell | t << CELL_BITS, written 64 at a time to the wave's
 // own region (coalesced 512-byte stores); records beyond the region's capacity are only counted (the host
 // repeats the pass with a larger pool: LIME_FLAG_POOL_FULL).
+// LINES: the once-per-window drain of the scan's main loop; the drains an overfull queue forces elsewhere (rare) write everything
+template <bool LINES>
 __device__ __forceinline__ void drain_bin(UpdQueue &q, const ScanArgs &a)
 {
     const uint32_t lane = lane_id();
     // A record is the LOW 32 bits of the cell; the high part picks one of the wave's n_sub sub-regions (one for tables
     // below 4 GB) and the score is implicit: a pair that scores t > 1 (repeated documents only) leaves t records.  Every
     // byte the scan stores costs its read stream dearly -- a gigabyte of appended records slows 8 GB of loads from 1.15 to
-    // 1.76 ms whatever the layout of the stores (tools/load_bench.hip) -- so the records are as short as they can be.
-    for (uint32_t k0 = 0; k0 < q.n; k0 += 64u) {
+    // 1.76 ms whatever the layout of the stores (tools/load_bench.hip) -- so the records are as short as they can be, and
+    // (one or two sub-regions) only whole 64-byte lines leave: per sub-region a multiple of 16 entries, the regions start
+    // line-aligned; the up to 15 entries per sub-region left over move to the queue's front (partial-line writes cost the
+    // N = 10^10 scan 5 %).  The kernel's last drain (flush_all) takes everything.
+    const uint32_t n = q.n;
+    const bool lines = LINES && a.n_sub <= 2u;
+    uint32_t lim0 = ~0u, lim1 = ~0u;                              // entries of sub-region 0 / 1 that leave now
+    if (lines) {
+        uint32_t c1 = 0;
+        if (a.n_sub == 2u)
+            for (uint32_t k0 = 0; k0 < n; k0 += 64u) {
+                const uint32_t k = k0 + lane;
+                const bool on = k < n;
+                const uint64_t cell = (uint64_t)q.qr[on ? k : 0u] * a.n_refs + (q.qg[on ? k : 0u] & (MAX_REFS - 1u));
+                c1 += (uint32_t)__popcll(__ballot(on && (uint32_t)(cell >> 32) == 1u));
+            }
+        lim0 = (n - c1) & ~15u; lim1 = c1 & ~15u;
+        if (!(lim0 | lim1)) return;
+    }
+    uint32_t seen0 = 0, seen1 = 0, kept = 0;                      // entries of each sub-region met so far; entries kept
+    for (uint32_t k0 = 0; k0 < n; k0 += 64u) {
         const uint32_t k = k0 + lane;
-        const bool on = k < q.n;
+        const bool on = k < n;
         const uint32_t gt = q.qg[on ? k : 0u], rd = q.qr[on ? k : 0u];
         // the scan's fast emitters do not look at the document ids: a genome id beyond the table is caught here, on
         // full waves (the entry is dropped; the pass fails with LIME_ERR_DOCID)
@@ -329,7 +350,19 @@ __device__ __forceinline__ void drain_bin(UpdQueue &q, const ScanArgs &a)
         if (__ballot(bad)) { if (bad) atomicOr(&cold(a).stats->flags, LIME_FLAG_DOCID); }
         const uint64_t cell = (uint64_t)rd * a.n_refs + (gt & (MAX_REFS - 1u));
         const uint32_t hi = (uint32_t)(cell >> 32);
-        uint32_t left = (on && !bad) ? gt >> T_SHIFT : 0u;
+        bool go = on;                                             // leaves now (else stays queued)
+        if (lines) {
+            const uint64_t m1 = __ballot(on && hi == 1u), m0 = __ballot(on && hi != 1u);
+            const uint32_t r = hi == 1u ? seen1 + rank_in(m1) : seen0 + rank_in(m0);
+            go = on && r < (hi == 1u ? lim1 : lim0);
+            seen0 += (uint32_t)__popcll(m0); seen1 += (uint32_t)__popcll(m1);
+            const uint64_t mk = __ballot(on && !go);
+            if (mk) {                                             // kept entries close up at the queue's front (index <= their own)
+                if (on && !go) { const uint32_t d = kept + rank_in(mk); q.qg[d] = gt; q.qr[d] = rd; }
+                kept += (uint32_t)__popcll(mk);
+            }
+        }
+        uint32_t left = (go && !bad) ? gt >> T_SHIFT : 0u;
         while (__ballot(left != 0u)) {                            // once, unless a pair scored more than 1
             for (uint32_t sub = 0; sub < a.n_sub; ++sub) {        // wave-uniform; one sub-region for tables below 4 GB
                 const bool mine = left != 0u && hi == sub;
@@ -346,12 +379,12 @@ __device__ __forceinline__ void drain_bin(UpdQueue &q, const ScanArgs &a)
             left -= (uint32_t)(left != 0u);
         }
     }
-    q.n = 0;
+    q.n = kept;
 }
 
 __device__ __forceinline__ void drain(UpdQueue &q, const ScanArgs &a)
 {
-    if (q.async) { if (q.binned) drain_bin(q, a); else drain_async(q, a); return; }     // both flags are compile-time constants of the kernel
+    if (q.async) { if (q.binned) drain_bin<false>(q, a); else drain_async(q, a); return; }     // both flags are compile-time constants of the kernel
 #ifdef LIME_PHASE_TIMING
     const uint64_t t0 = __builtin_readcyclecounter();
 #endif
@@ -1229,7 +1262,7 @@ __global__ __launch_bounds__(ScanCfg<EBWT>::wg) __attribute__((amdgpu_waves_per_
         // its acknowledgement when it wants to stage the loaded window (measured on configs[2]: 0.34 of 2.06 ms with the
         // stores issued from the scoring rounds).  Issued here they are older than the loads and long done by then.
         if (MODE == 0 && !ABL(8)) {
-            drain(qu, a);
+            if (binned) drain_bin<true>(qu, a); else drain(qu, a);
             asm volatile("" ::: "memory");                    // the loads below stay below
         }
         // ---- the next window's loads go out now and land while this one is processed ----------
