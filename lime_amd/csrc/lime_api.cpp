@@ -77,6 +77,7 @@ struct lime_ctx {
     bool bin_levels_forced = false;
     uint32_t bin_one_level = BIN_ONE_LEVEL, bin_two_level = BIN_TWO_LEVEL;   // LIME_BIN_LEVELS="a,b" (tests: force the second level on small tables)
     double pool_density = 0.20;             // records per owned symbol the pool is sized for (grows on LIME_FLAG_POOL_FULL)
+    uint32_t scan_static_pct = 75;          // share of the scan's rounds of window chunks that go round-robin; the rest is handed out as workgroups get there (LIME_SCAN_STATIC_PCT: tests)
     uint32_t pool_slack = 512;              // + this many records per wave and sub-region (LIME_POOL_SLACK: tests make pools overflow)
     struct Last {                           // the last lime_fused_dev call, so that lime_get_stats can repeat it with a larger pool
         bool valid = false, binned = false;
@@ -149,6 +150,7 @@ extern "C" int lime_init(int device, lime_ctx **out)
         if (sscanf(s, "%u,%u", &a1, &a2) == 2 && a1 >= 1 && a2 >= 1 && a1 <= BIN_MAX && a2 <= BIN_MAX) { c->bin_one_level = a1; c->bin_two_level = a2; c->bin_levels_forced = true; }
     }
     if (const char *s = getenv("LIME_POOL_DENSITY")) { const double v = atof(s); if (v > 0) c->pool_density = v; }   // tests: force a small pool
+    if (const char *s = getenv("LIME_SCAN_STATIC_PCT")) { const long v = atol(s); if (v >= 0 && v <= 100) c->scan_static_pct = (uint32_t)v; }
     if (const char *s = getenv("LIME_POOL_SLACK")) { const long v = atol(s); if (v >= 0) c->pool_slack = (uint32_t)v; }
     if (const char *s = getenv("LIME_MAX_BLOCKS")) { long v = atol(s); if (v > 0) c->max_blocks = (uint32_t)v; }
     *out = c;
@@ -239,7 +241,7 @@ static ScanArgs base_args(lime_ctx *c, const uint32_t *lcp, const uint32_t *da, 
     a.tile_cnt = c->d_tile_cnt; a.tile_off = c->d_tile_off; a.cross = c->d_cross; a.out = c->d_out;
     a.wmask = c->d_wmask;
     a.edge = &c->d_stats->edge;
-    a.sticky = c->d_sticky;
+    a.sticky = c->d_sticky; a.dyn = c->d_sticky + 1; a.static_pct = c->scan_static_pct;
     a.ablate = c->ablate;
     return a;
 }
@@ -317,7 +319,7 @@ static int ensure_binned(lime_ctx *c, uint64_t n_own, uint32_t n_waves, uint32_t
 {
     int rc;
     const double per_wave = (double)n_own * c->pool_density / (double)n_waves;
-    uint64_t cw = (((uint64_t)(per_wave * 1.10) + c->pool_slack) & ~15ull) + 16u;   // a multiple of 16 records: sub-regions start on a 64-byte line
+    uint64_t cw = (((uint64_t)(per_wave * 1.35) + c->pool_slack) & ~15ull) + 16u;   // a multiple of 16 records: sub-regions start on a 64-byte line
     const size_t segs = (size_t)n_waves * n_sub;                          // every sub-region can take a wave's whole share (no assumption on how the cells spread)
     if (c->pool_cap / segs > cw) cw = (c->pool_cap / segs) & ~15ull;      // grow-only: use all of what is there
     if (cw * segs > 0xF0000000ull) return fail(LIME_ERR_ARG, "update record pool too large for one shard");   // record positions are 32-bit

@@ -13,16 +13,16 @@ constexpr uint32_t NW = WIN / 64;            // 64-bit mask words per window
 constexpr uint32_t HALO = 16;                // read-ahead positions behind a window (>= SMALL_MAX)
 constexpr uint32_t WPOS = WIN + HALO;
 constexpr int SCAN_WG = 256;                 // 4 independent waves per workgroup of k_score_list
-// k_scan: threads per workgroup (its waves work independently: the workgroup only shares lookup tables and the binned
-// path's histogram) and waves per SIMD it is compiled for.  The scan is bound by the latency of each wave's chain of
-// dependent steps, so waves per SIMD count (measured, configs[2]: 2 -> 2.94 ms, 3 -> 1.90 ms): without ebwt the window
-// state fits 8 waves x 2 workgroups per CU (<= 128 VGPRs, <= 80 KB of LDS per workgroup); with ebwt it stays at 3 x 4.
+// k_scan: threads per workgroup and waves per SIMD it is compiled for.  ONE workgroup fills a CU (16 waves without ebwt:
+// <= 128 VGPRs and <= 160 KB of LDS together; 12 with ebwt: 168 VGPRs): its waves work independently but draw their
+// windows from one LDS counter, which is what keeps a CU's waves -- which the SIMDs do not serve equally -- ending
+// together (k_scan).  Waves per SIMD count (measured, configs[2]: 2 -> 2.94 ms, 3 -> 1.90 ms, 4 about the same as 3).
 #ifndef LIME_SCAN_WG0
-#define LIME_SCAN_WG0 512
+#define LIME_SCAN_WG0 1024
 #define LIME_SCAN_WAVES0 4
 #endif
 #ifndef LIME_SCAN_WG1
-#define LIME_SCAN_WG1 256
+#define LIME_SCAN_WG1 768
 #define LIME_SCAN_WAVES1 3
 #endif
 template <int EBWT> struct ScanCfg { static constexpr int wg = EBWT ? LIME_SCAN_WG1 : LIME_SCAN_WG0, waves = EBWT ? LIME_SCAN_WAVES1 : LIME_SCAN_WAVES0; };
@@ -78,6 +78,7 @@ struct ScanArgs {
     uint32_t *tile_cnt; uint64_t *tile_off; CrossRec *cross; lime_cluster_t *out;   // detect only
     WinMasks *wmask;                             // detect only: count pass -> emit pass
     uint32_t *edge;                              // LIME_EDGE_* word of this shard (default: &stats->edge)
+    uint32_t *dyn; uint32_t n_static, static_pct;           // k_scan: rounds of round-robin window chunks before the chunks come from the counter dyn[0] (dyn[1]: workgroups done; both are left at 0); set by the launch wrapper from static_pct
     uint32_t *sticky;                            // passes whose record pool overflowed and that lime_get_stats has not settled yet (never cleared by a pass)
     int ablate;                                  // timing experiments only (LIME_ABLATE_BUILD): 0 = full kernel
     // binned table updates (upd_mode 1; 0 = compare-and-swap on the table)

@@ -67,6 +67,17 @@ struct alignas(16) WaveLds {
 #define ABL(k) false
 #endif
 
+#ifdef LIME_WALL_TIMING      // debug build: start and end wall clock (100 MHz) of every wave of the last scan
+__device__ uint64_t g_wall[2 * 8192];
+extern "C" int lime_debug_wall(uint64_t *out) { return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_wall), sizeof(g_wall)); }
+__device__ uint32_t g_winmark[1u << 20];       // which wave (+ 1) took window w of the last scan
+extern "C" int lime_debug_winmark(uint32_t *out)
+{
+    int rc = (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_winmark), sizeof(g_winmark));
+    void *p = nullptr; (void)hipGetSymbolAddress(&p, HIP_SYMBOL(g_winmark)); (void)hipMemset(p, 0, sizeof(g_winmark));
+    return rc;
+}
+#endif
 #ifdef LIME_PHASE_TIMING     // debug build: per-wave cycle counts of the scan's phases, printed by a few waves
 #define PT_DECL uint64_t pt_t = __builtin_readcyclecounter(), pt_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0}, pt_m[4] = {0, 0, 0, 0}; uint32_t pt_nwin = 0;
 #define PT(i) { const uint64_t n_ = __builtin_readcyclecounter(); pt_acc[i] += n_ - pt_t; pt_t = n_; }
@@ -1049,7 +1060,7 @@ __device__ __forceinline__ void window_load(WinRegs &t, const ScanArgs &a, uint6
 }
 
 // =========================================================================================
-// k_scan: the streaming scan.  Every wave is an independent worker over windows of WIN positions
+// (a workgroup takes chunks of consecutive windows round-robin, its waves draw from the chunk); no workgroup barrier in the loop.
 // (stride = number of waves in the grid); no workgroup barrier in the loop.
 // MODE 0: detect + score; 1: count clusters per window and keep the window's masks for k_emit.
 // Front end: lane-strided loads; mask words from wave ballots; lane l owns the CHUNK of positions
@@ -1161,7 +1172,9 @@ __global__ __launch_bounds__(ScanCfg<EBWT>::wg) __attribute__((amdgpu_waves_per_
     constexpr uint32_t NJ = SCANK_WG > 256 ? 2u : 4u;
     constexpr uint32_t FS = BIN ? BIN_MAX : (SCANK_WG / 64) * 192u * NJ;
     __shared__ uint32_t fslots[FS];
-    __shared__ uint32_t wg_done;
+    __shared__ uint32_t wg_done, wg_next, wg_exit, wg_max_len, wg_rec_max;
+    __shared__ unsigned long long wg_n_clusters, wg_n_updates;
+    __shared__ uint64_t wg_slot[16];
     const uint32_t lane = lane_id(), wave = (uint32_t)__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));   // wave-uniform: LDS bases stay scalar
     ScanLds &L = lds[wave];
     constexpr bool binned = BIN != 0;
@@ -1169,9 +1182,11 @@ __global__ __launch_bounds__(ScanCfg<EBWT>::wg) __attribute__((amdgpu_waves_per_
         for (uint32_t i = threadIdx.x; i < FS; i += SCANK_WG) fslots[i] = 0u;
         if (threadIdx.x == 0) wg_done = 0u;
     }
+    if (threadIdx.x == 0) { wg_next = 0u; wg_exit = 0u; wg_max_len = 0u; wg_rec_max = 0u; wg_n_clusters = 0ull; wg_n_updates = 0ull; }
+    if (threadIdx.x < 16) wg_slot[threadIdx.x] = 0ull;
     tables_init(T);                                        // the only workgroup barrier of the kernel
-    const uint32_t n_win = a.n_tiles, stride = gridDim.x * (SCANK_WG / 64);
-    uint32_t win = blockIdx.x * (SCANK_WG / 64) + wave;
+    const uint32_t n_win = a.n_tiles;
+    constexpr uint32_t WPW = SCANK_WG / 64;
     UpdQueue qu; qu.qr = L.q_read; qu.qg = L.q_gen; qu.n = 0; qu.cap = QCAP_SCAN;
     qu.async = true;
     if (!binned) { qu.nj = NJ; qu.fr = fslots + 192u * NJ * wave; qu.fg = qu.fr + 64u * NJ; qu.fe = qu.fr + 128u * NJ; }
@@ -1186,7 +1201,7 @@ __global__ __launch_bounds__(ScanCfg<EBWT>::wg) __attribute__((amdgpu_waves_per_
         if (lane < a.n_sub) {
             const uint32_t n = qu.sub_n[lane];
             cold(a).wave_cnt[(size_t)wave_gid * a.n_sub + lane] = n < a.cap_w ? n : a.cap_w;
-            atomicMax(&cold(a).stats->wave_records_max, n);
+            atomicMax(&wg_rec_max, n);
             if (n > a.cap_w) {                                 // the pass's first overflow also counts the pass as unsettled
                 const uint32_t old = atomicOr(&cold(a).stats->flags, LIME_FLAG_POOL_FULL);
                 if (!(old & LIME_FLAG_POOL_FULL)) atomicAdd(cold(a).sticky, 1u);
@@ -1201,14 +1216,75 @@ __global__ __launch_bounds__(ScanCfg<EBWT>::wg) __attribute__((amdgpu_waves_per_
             for (uint32_t b = lane; b < cold(a).n_bins; b += 64u) cold(a).counts[(size_t)b * gridDim.x + blockIdx.x] = qu.hist[b];
         }
     };
-    if (win >= n_win) { if (binned) finish_binned(); return; }
+    // The workgroup takes chunks of its wave count of consecutive windows and its waves draw the windows of those chunks
+    // one by one from an LDS counter: the waves of a CU do not run equally fast (with every wave on a fixed share,
+    // configs[2], the older wave of each SIMD's pairs ended at 0.70 .. 0.78 of the kernel's time and the tail ran at a
+    // fraction of the occupancy); drawn this way they end within a window of each other.  The chunks of the first
+    // n_static rounds go round-robin over the workgroups; the XCDs do not run equally fast either (the odd ones ended 5 ..
+    // 9 % later), so the chunks of the last rounds come from a device-wide counter, one atomic per chunk: the wave that
+    // draws the first window of chunk k fetches chunk k + 1 and leaves it, tagged k + 2, in the LDS slot the others poll.
+    auto take = [&]() -> uint32_t {
+        uint32_t i = 0;
+        if (lane == 0) i = atomicAdd(&wg_next, 1u);
+        i = (uint32_t)__builtin_amdgcn_readfirstlane((int)i);
+        const uint32_t k = i / WPW, j = i % WPW, ks = (EBWT ? cold(a) : a).n_static;
+        uint32_t chunk = k * gridDim.x + blockIdx.x;
+        if (k >= ks) {
+            uint64_t v;
+            while ((uint32_t)((v = __hip_atomic_load(&wg_slot[k & 15u], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP)) >> 32) != k + 1u) __builtin_amdgcn_s_sleep(2);
+            chunk = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)v);
+        }
+        // (after chunk k is known: the workgroup's fetches follow each other, so its chunks ascend and a wave that draws a
+        // window past the end can stop -- no chunk fetched later is still inside)
+        if (j == 0u && k + 1u >= ks) {
+            if (lane == 0) {
+                const uint32_t g = atomicAdd(cold(a).dyn, 1u);
+                __hip_atomic_store(&wg_slot[(k + 1u) & 15u], ((uint64_t)(k + 2u) << 32) | (uint64_t)(ks * gridDim.x + g), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            }
+        }
+        return chunk * WPW + j;
+    };
+    // end of a wave.  The counters of the pass are summed per workgroup in LDS and its last wave adds them to the device's:
+    // the waves end together, and a few atomics per wave on the same few words took the last 0.1 .. 0.2 ms of the kernel
+    // (configs[2]: 16 k atomics on one cache line).  The last wave of the last workgroup leaves the chunk counters at 0
+    // for the next launch.
+    auto wave_exit = [&](uint32_t tn, uint32_t tm, uint32_t tu) {
+        if (lane == 0) {
+            if (tn) atomicAdd(&wg_n_clusters, (unsigned long long)tn);
+            if (tm) atomicMax(&wg_max_len, tm);
+            if (tu) atomicAdd(&wg_n_updates, (unsigned long long)tu);
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+            if (atomicAdd(&wg_exit, 1u) == WPW - 1u) {
+                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+                DevStats *st = cold(a).stats;
+                const unsigned long long nc = __hip_atomic_load(&wg_n_clusters, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP), nu = __hip_atomic_load(&wg_n_updates, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                const uint32_t ml = __hip_atomic_load(&wg_max_len, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP), rm = __hip_atomic_load(&wg_rec_max, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                if (nc) atomicAdd(&st->n_clusters, nc);
+                if (ml) atomicMax(&st->max_len, (unsigned long long)ml);
+                if (MODE == 0 && nu) atomicAdd(&st->n_updates, nu);
+                if (rm) atomicMax(&st->wave_records_max, rm);
+                uint32_t *dyn = cold(a).dyn;
+                if (atomicAdd(dyn + 1, 1u) == gridDim.x - 1u) {
+                    __hip_atomic_store(dyn, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); __hip_atomic_store(dyn + 1, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                }
+            }
+        }
+    };
+    uint32_t win = take();
+    if (win >= n_win) { if (binned) finish_binned(); wave_exit(0u, 0u, 0u); return; }
     WinRegs regs;
     window_load<EBWT>(regs, a, (uint64_t)win * WIN);
     uint32_t acc_n = 0, acc_max = 0, acc_upd = 0;          // per-lane partial counters, reduced once at the end
     uint32_t n_dup = 0;                                    // clusters waiting in the wave's dup store
     PT_DECL
+#ifdef LIME_WALL_TIMING
+    const uint64_t pt_wall0 = wall_clock64();
+#endif
     for (;;) {
         PT_WAITVM PT(0)
+#ifdef LIME_WALL_TIMING
+        if (lane == 0 && win < (1u << 20)) atomicAdd(&g_winmark[win], ((wave_gid + 1u) & 0xFFFFu) | 0x10000u);
+#endif
         const uint64_t lo = (uint64_t)win * WIN;
         const uint64_t n_own_ = (EBWT ? cold(a) : a).n_own;
         const uint32_t own_lim = (uint32_t)(n_own_ > lo ? (n_own_ - lo < WIN ? n_own_ - lo : (uint64_t)WIN) : 0ull);
@@ -1266,8 +1342,8 @@ __global__ __launch_bounds__(ScanCfg<EBWT>::wg) __attribute__((amdgpu_waves_per_
             asm volatile("" ::: "memory");                    // the loads below stay below
         }
         // ---- the next window's loads go out now and land while this one is processed ----------
-        const uint32_t next = win + stride;
         const uint32_t n_win_ = (EBWT ? cold(a) : a).n_tiles;
+        const uint32_t next = take();
         if (next < n_win_) window_load<EBWT>(regs, a, (uint64_t)next * WIN);
 
         PT(1)
@@ -1457,14 +1533,10 @@ __global__ __launch_bounds__(ScanCfg<EBWT>::wg) __attribute__((amdgpu_waves_per_
                (unsigned long long)pt_acc[0], (unsigned long long)pt_acc[1], (unsigned long long)pt_acc[2], (unsigned long long)pt_acc[3],
                (unsigned long long)pt_acc[4], (unsigned long long)pt_acc[5], (unsigned long long)pt_acc[6], (unsigned long long)pt_acc[7]);
 #endif
-    {
-        const uint32_t tn = wave_sum(acc_n), tm = wave_max(acc_max), tu = wave_sum(acc_upd);
-        if (lane == 0) {
-            if (tn) atomicAdd(&cold(a).stats->n_clusters, (unsigned long long)tn);
-            if (tm) atomicMax(&cold(a).stats->max_len, (unsigned long long)tm);
-            if (MODE == 0 && tu) atomicAdd(&cold(a).stats->n_updates, (unsigned long long)tu);
-        }
-    }
+    wave_exit(wave_sum(acc_n), wave_max(acc_max), wave_sum(acc_upd));
+#ifdef LIME_WALL_TIMING      // debug build: when each wave started and ended (tools/pt_wall.sh)
+    if (MODE == 0 && lane == 0 && wave_gid < 8192u) { g_wall[2u * wave_gid] = pt_wall0; g_wall[2u * wave_gid + 1u] = wall_clock64(); }
+#endif
 }
 
 // =========================================================================================
@@ -2228,7 +2300,13 @@ template <int ID, int WG, typename K> static uint32_t scan_grid_of(K kernel, uin
 template <int ID, int WG, typename K> static void launch_scan_kernel(K kernel, const ScanArgs &a, uint32_t max_blocks, hipStream_t st)
 {
     // persistent grid: as many workgroups as fit the device at once (per instantiation), or fewer for short inputs
-    hipLaunchKernelGGL(kernel, dim3(scan_grid_of<ID, WG>(kernel, a.n_tiles, max_blocks)), dim3(WG), 0, st, a);
+    const uint32_t grid = scan_grid_of<ID, WG>(kernel, a.n_tiles, max_blocks);
+    const uint32_t pct = a.static_pct > 100u ? 100u : a.static_pct;
+    ScanArgs b = a;
+    const uint64_t rounds = ((uint64_t)a.n_tiles + WG / 64 - 1) / (WG / 64) / grid;      // whole rounds of chunks
+    b.n_static = (uint32_t)(rounds * (uint64_t)pct / 100u);
+    if (!b.n_static) b.n_static = 1u;                  // round 0 is always the workgroups' own chunks (grid <= number of chunks)
+    hipLaunchKernelGGL(kernel, dim3(grid), dim3(WG), 0, st, b);
 }
 
 uint32_t scan_grid(int ebwt, int mode, int binned, uint32_t n_tiles, uint32_t max_blocks)

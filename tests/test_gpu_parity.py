@@ -669,3 +669,40 @@ def test_dense_small_clusters(ctx, period, n):
         sim, gnc, gml = ctx.fused(lcp, da, e, nr, ng, 16)
         assert (gnc, gml) == (nc, ml)
         assert np.array_equal(sim, exp)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("pct", [0, 50, 100])
+@pytest.mark.parametrize("path,ebwt_on", [("cas", False), ("bin", False), ("cas", True)])
+def test_window_handout_repeats(monkeypatch, pct, path, ebwt_on):
+    """The scan's waves draw their windows from counters (LDS inside a workgroup, a device word for the last
+    rounds): whatever the split between fixed and handed-out rounds, and however the waves race, every window is
+    taken exactly once -- the same pass repeated gives the same counters and table, equal to the all-fixed split's.
+    (A workgroup whose two chunk fetches were answered out of order once dropped a chunk near the end of the data.)"""
+    import torch
+    import lime_amd
+    n, nr, ng, alpha = 40_000_000 + 12_345, 200_000, 700, 16
+    dev = torch.device("cuda:0")
+    lcp = torch.empty(n, dtype=torch.int32, device=dev); da = torch.empty_like(lcp)
+    eb = torch.empty(n, dtype=torch.uint8, device=dev) if ebwt_on else None
+    monkeypatch.setenv("LIME_UPDATE_PATH", path)
+    tb = lime_amd.sim_bytes(nr, ng)
+    want = None
+    for p in (100, pct):
+        monkeypatch.setenv("LIME_SCAN_STATIC_PCT", str(p))
+        c = lime_amd.Context()
+        try:
+            if want is None:
+                c.synth_dev(7, 0, n, nr, ng, alpha, 0, lcp, da, eb)
+            for _ in range(1 if want is None else 6):
+                A = torch.empty(tb, dtype=torch.uint8, device=dev)
+                c.fused_dev(lcp, da, eb, n, n, True, nr, ng, alpha, A, True)
+                s, rc = c.stats(); assert rc == 0
+                got = (s.n_clusters, s.max_len, s.n_updates)
+                if want is None:
+                    want, ref = got, A
+                else:
+                    assert got == want
+                    assert torch.equal(A, ref)
+        finally:
+            c.close()

@@ -23,7 +23,7 @@ if "--gate" in sys.argv:
         want_waves = 3 if ebwt else 4
         if r["vgpr_spill"] or r["scratch"]: bad.append(f"{name}: VGPR spills / scratch")
         if r["waves_by_vgpr"] < want_waves: bad.append(f"{name}: {r['vgpr']} VGPRs allow {r['waves_by_vgpr']} waves per SIMD, planned {want_waves}")
-        if r["lds"] * (2 if not ebwt else 3) > 160 * 1024: bad.append(f"{name}: {r['lds']} B of LDS do not fit the planned workgroups per CU")
+        if r["lds"] > 160 * 1024: bad.append(f"{name}: {r['lds']} B of LDS do not fit a CU (one workgroup per CU)")
         if r["sgpr_spill"] > (12 if ebwt else 0): bad.append(f"{name}: {r['sgpr_spill']} SGPR spills")
     if bad:
         print("RESOURCE GATE FAILED:\n  " + "\n  ".join(bad)); sys.exit(1)
