@@ -67,6 +67,9 @@ struct lime_ctx {
     uint32_t *d_counts = nullptr; size_t counts_cap = 0;
     uint32_t *d_totals = nullptr; uint64_t *d_binbase = nullptr;
     uint64_t *d_regbase = nullptr; size_t regbase_cap = 0;
+    uint32_t *d_tbase = nullptr;            // second level by tiles: tiles before each bin, and the tiles' region index
+    uint16_t *d_tidx = nullptr; size_t tidx_cap = 0;
+    bool by_tiles = true;                   // LIME_SECOND_LEVEL=sweeps: k_part2 + k_apply instead (comparison runs)
     // owner-partitioned exchange: the long clusters' update records of this rank; the owner's regrouped records
     uint64_t *d_bigrec = nullptr; uint32_t *d_bigrec_n = nullptr; uint32_t bigrec_cap = 0;
     uint32_t *d_xrecs = nullptr, *d_xrecs2 = nullptr; size_t xrecs_cap = 0;
@@ -151,6 +154,7 @@ extern "C" int lime_init(int device, lime_ctx **out)
     }
     if (const char *s = getenv("LIME_POOL_DENSITY")) { const double v = atof(s); if (v > 0) c->pool_density = v; }   // tests: force a small pool
     if (const char *s = getenv("LIME_SCAN_STATIC_PCT")) { const long v = atol(s); if (v >= 0 && v <= 100) c->scan_static_pct = (uint32_t)v; }
+    if (const char *s = getenv("LIME_SECOND_LEVEL")) c->by_tiles = strcmp(s, "sweeps") != 0;
     if (const char *s = getenv("LIME_POOL_SLACK")) { const long v = atol(s); if (v >= 0) c->pool_slack = (uint32_t)v; }
     if (const char *s = getenv("LIME_MAX_BLOCKS")) { long v = atol(s); if (v > 0) c->max_blocks = (uint32_t)v; }
     *out = c;
@@ -168,7 +172,7 @@ extern "C" void lime_shutdown(lime_ctx *c)
     (void)hipFree(c->d_small); (void)hipFree(c->d_big); (void)hipFree(c->d_out);
     (void)hipFree(c->d_big_scratch);
     (void)hipFree(c->d_pool); (void)hipFree(c->d_recs); (void)hipFree(c->d_wave_cnt); (void)hipFree(c->d_counts);
-    (void)hipFree(c->d_totals); (void)hipFree(c->d_binbase); (void)hipFree(c->d_regbase);
+    (void)hipFree(c->d_totals); (void)hipFree(c->d_binbase); (void)hipFree(c->d_regbase); (void)hipFree(c->d_tbase); (void)hipFree(c->d_tidx);
     (void)hipFree(c->d_bigrec); (void)hipFree(c->d_bigrec_n); (void)hipFree(c->d_xrecs); (void)hipFree(c->d_xrecs2); (void)hipFree(c->d_xoff); (void)hipFree(c->d_xreg);
     delete c;
 }
@@ -323,7 +327,8 @@ static int ensure_binned(lime_ctx *c, uint64_t n_own, uint32_t n_waves, uint32_t
     const size_t segs = (size_t)n_waves * n_sub;                          // every sub-region can take a wave's whole share (no assumption on how the cells spread)
     if (c->pool_cap / segs > cw) cw = (c->pool_cap / segs) & ~15ull;      // grow-only: use all of what is there
     if (cw * segs > 0xF0000000ull) return fail(LIME_ERR_ARG, "update record pool too large for one shard");   // record positions are 32-bit
-    const size_t want = (size_t)cw * segs;
+    size_t want = (size_t)cw * segs;
+    if (want < (size_t)n_bins * part_tile()) want = (size_t)n_bins * part_tile();      // the second level's 16-bit rows (one per tile, a bin's last one partly used) fit the pool
     if (want > c->pool_cap) {
         HIP_TRY(hipStreamSynchronize(st));
         if ((rc = regrow(c->d_pool, want + 16))) return rc;      // slack: k_part2 / k_apply read aligned groups of four 4-byte records
@@ -336,6 +341,11 @@ static int ensure_binned(lime_ctx *c, uint64_t n_own, uint32_t n_waves, uint32_t
     if (!c->d_totals) {
         HIP_TRY(hipMalloc(&c->d_totals, (BIN_MAX + 1) * sizeof(uint32_t)));
         HIP_TRY(hipMalloc(&c->d_binbase, (BIN_MAX + 2) * sizeof(uint64_t)));
+    }
+    if (bin_shift > REGION_SHIFT) {
+        if (!c->d_tbase) HIP_TRY(hipMalloc(&c->d_tbase, (BIN_MAX + 2) * sizeof(uint32_t)));
+        const size_t want_idx = (size_t)tiles_bound(c->pool_cap, n_bins) * (((size_t)1 << (bin_shift - REGION_SHIFT)) + 1);
+        if (want_idx > c->tidx_cap) { HIP_TRY(hipStreamSynchronize(st)); if ((rc = regrow(c->d_tidx, want_idx))) return rc; c->tidx_cap = want_idx; }
     }
     const size_t want_reg = ((size_t)n_bins << (bin_shift - REGION_SHIFT)) + 2;
     if (bin_shift > REGION_SHIFT && want_reg > c->regbase_cap) {
@@ -440,6 +450,9 @@ static int fused_dev_impl(lime_ctx *c, const uint32_t *d_lcp, const uint32_t *d_
         launch_part(a, grid, c->d_binbase, c->d_recs, st);
         if (records_only) {
             // the records grouped by bin are the result: the owners of the bins build the table (lime_apply_records_dev)
+        } else if (bin_shift > REGION_SHIFT && c->by_tiles) {      // second level tile by tile into the (by now free) pool, regions from the tiles' runs
+            launch_apply_by_tiles(d_sim, sim_bytes, c->d_recs, c->d_binbase, n_bins, bin_shift, c->d_tbase, c->d_tidx,
+                                  reinterpret_cast<uint16_t *>(c->d_pool), st);
         } else if (bin_shift > REGION_SHIFT) {            // second level into the (by now free) pool, then regions from there
             uint32_t *recs2 = c->d_pool;
             launch_part2(c->d_recs, c->d_binbase, n_bins, bin_shift, c->d_regbase, recs2, st);
@@ -545,11 +558,18 @@ extern "C" int lime_apply_records_dev(lime_ctx *c, uint32_t n_src, const uint32_
     if (total > 0xF0000000ull) return fail(LIME_ERR_ARG, "lime_apply_records_dev: too many records for one block");
     if (total && !d_rx) return fail(LIME_ERR_ARG, "lime_apply_records_dev: d_rx is NULL");
     const size_t f2 = (size_t)1 << (bin_shift - REGION_SHIFT), n_reg = (size_t)nb * f2;
-    if (total + 16 > c->xrecs_cap) {
+    size_t xwant = (size_t)total + 16;
+    if (xwant < (size_t)nb * part_tile() + 16) xwant = (size_t)nb * part_tile() + 16;      // (the second level's 16-bit tile rows)
+    if (xwant > c->xrecs_cap) {
         HIP_TRY(hipStreamSynchronize(st));
-        if ((rc = regrow(c->d_xrecs, (size_t)total + 16 + total / 8))) return rc;
-        if ((rc = regrow(c->d_xrecs2, (size_t)total + 16 + total / 8))) return rc;
-        c->xrecs_cap = (size_t)total + 16 + total / 8;
+        if ((rc = regrow(c->d_xrecs, xwant + total / 8))) return rc;
+        if ((rc = regrow(c->d_xrecs2, xwant + total / 8))) return rc;
+        c->xrecs_cap = xwant + total / 8;
+    }
+    if (bin_shift > REGION_SHIFT) {
+        if (!c->d_tbase) HIP_TRY(hipMalloc(&c->d_tbase, (BIN_MAX + 2) * sizeof(uint32_t)));
+        const size_t want_idx = (size_t)tiles_bound(total, nb) * (f2 + 1);
+        if (want_idx > c->tidx_cap) { HIP_TRY(hipStreamSynchronize(st)); if ((rc = regrow(c->d_tidx, want_idx))) return rc; c->tidx_cap = want_idx; }
     }
     const size_t off_words = (size_t)n_src * (nb + 1) + (nb + 1);
     if (off_words > c->xoff_cap) { HIP_TRY(hipStreamSynchronize(st)); if ((rc = regrow(c->d_xoff, off_words))) return rc; c->xoff_cap = off_words; }
@@ -559,7 +579,10 @@ extern "C" int lime_apply_records_dev(lime_ctx *c, uint32_t n_src, const uint32_
     HIP_TRY(hipMemcpyAsync(d_dstbase, dstbase.data(), ((size_t)nb + 1) * sizeof(uint64_t), hipMemcpyHostToDevice, st));
     HIP_TRY(hipStreamSynchronize(st));                    // the host vectors go out of scope
     launch_regroup(d_rx, d_srcoff, n_src, nb, d_dstbase, c->d_xrecs, st);
-    if (bin_shift > REGION_SHIFT) {
+    if (bin_shift > REGION_SHIFT && c->by_tiles) {
+        launch_apply_by_tiles(d_block, (size_t)block_bytes, c->d_xrecs, d_dstbase, nb, bin_shift, c->d_tbase, c->d_tidx,
+                              reinterpret_cast<uint16_t *>(c->d_xrecs2), st);
+    } else if (bin_shift > REGION_SHIFT) {
         launch_part2(c->d_xrecs, d_dstbase, nb, bin_shift, c->d_xreg, c->d_xrecs2, st);
         HIP_TRY(hipMemcpyAsync(c->d_xreg + n_reg, d_dstbase + nb, sizeof(uint64_t), hipMemcpyDeviceToDevice, st));
         launch_apply(d_block, (size_t)block_bytes, c->d_xrecs2, c->d_xreg, bin_shift, st);

@@ -1928,6 +1928,159 @@ __global__ __launch_bounds__(PART_WG) void k_part2(const uint32_t *recs, const u
     }
 }
 
+// ---- second level without a second sweep -------------------------------------------------------------------------
+// k_part2 reads a bin's records twice (count per region, then move) because every region's range of the output must be
+// known before the first record moves.  k_sort_tiles does not move records between tiles at all: a bin's records are
+// taken TILE by TILE (8192), each tile is sorted by region in LDS and leaves as 16-bit offsets inside the region (the
+// region is what the position says), 16 KB per tile at out16[row * PART_TILE ..], row = the tile's number over all bins
+// (tbase[bin] + tile of the bin); where the regions' runs start inside the tile goes to the bin's index,
+// idx[tbase[bin] * (f2 + 1) + sub * T + t] (T = tiles of the bin, entry f2: the tile's record count).  k_apply_tiles
+// then builds a region from its run of every tile of the bin.  One read of 4 bytes and one write of 2 per record here,
+// one read of 2 there (k_part2 + k_apply: 8 + 4 and 4).
+__global__ __launch_bounds__(PART_WG) void k_tile_bases(const uint64_t *binbase, uint32_t n_bins, uint32_t *tbase)
+{
+    __shared__ uint32_t cnt[BIN_MAX], toff[BIN_MAX];
+    __shared__ uint32_t wsum[PART_WG / 64];
+    for (uint32_t b = threadIdx.x; b < n_bins; b += PART_WG) cnt[b] = (uint32_t)((binbase[b + 1] - binbase[b] + PART_TILE - 1u) / PART_TILE);
+    __syncthreads();
+    part_scan(cnt, toff, n_bins, wsum);
+    for (uint32_t b = threadIdx.x; b < n_bins; b += PART_WG) { tbase[b] = toff[b]; if (b == n_bins - 1u) tbase[n_bins] = toff[b] + cnt[b]; }
+}
+
+__global__ __launch_bounds__(PART_WG) void k_sort_tiles(const uint32_t *recs, const uint64_t *binbase, uint32_t bin_shift,
+                                                        const uint32_t *tbase, uint16_t *idx, uint16_t *out16)
+{
+    constexpr uint32_t F2MAX = 1u << (BIN_SHIFT_MAX - REGION_SHIFT);
+    __shared__ uint4 stage4[PART_TILE / 8];                              // the tile's 16-bit offsets, sorted by region
+    __shared__ uint32_t cnt[F2MAX], toff[F2MAX];
+    __shared__ uint32_t wsum[PART_WG / 64];
+    uint16_t *stage = reinterpret_cast<uint16_t *>(stage4);
+    const uint32_t tid = threadIdx.x;
+    const uint32_t f2 = 1u << (bin_shift - REGION_SHIFT), omask = (1u << bin_shift) - 1u;
+    const uint32_t bin = blockIdx.x;
+    const uint64_t lo = binbase[bin], hi = binbase[bin + 1];
+    const uint32_t row0 = tbase[bin], n_rows = tbase[bin + 1] - row0;
+    uint16_t *bidx = idx + (size_t)row0 * (f2 + 1u);
+    for (uint32_t i = tid; i < f2; i += PART_WG) cnt[i] = 0u;
+    __syncthreads();
+    auto load_tile = [&](uint64_t t0, uint32_t (&v)[PART_PER]) {
+        const uint32_t tn = hi - t0 < PART_TILE ? (uint32_t)(hi - t0) : PART_TILE;
+#pragma unroll
+        for (uint32_t j = 0; j < PART_PER; ++j) {
+            const uint32_t i = j * PART_WG + tid;
+            v[j] = i < tn ? __builtin_nontemporal_load(recs + t0 + i) : 0u;
+        }
+    };
+    uint32_t nxt[PART_PER];
+    if (lo < hi) load_tile(lo, nxt);
+    uint32_t row = 0;
+    for (uint64_t t0 = lo; t0 < hi; t0 += PART_TILE, ++row) {
+        uint32_t val[PART_PER], dr[PART_PER];
+#pragma unroll
+        for (uint32_t j = 0; j < PART_PER; ++j) {
+            val[j] = nxt[j]; dr[j] = ~0u;
+            if (val[j] >> bin_shift) {                                   // (0: no record)
+                const uint32_t d = (val[j] & omask) >> REGION_SHIFT;
+                dr[j] = d | (atomicAdd(&cnt[d], 1u) << 12);
+            }
+        }
+        if (t0 + PART_TILE < hi) load_tile(t0 + PART_TILE, nxt);
+        __syncthreads();
+        part_scan(cnt, toff, f2, wsum);
+#pragma unroll
+        for (uint32_t j = 0; j < PART_PER; ++j)
+            if (dr[j] != ~0u) stage[toff[dr[j] & 0xFFFu] + (dr[j] >> 12)] = (uint16_t)(val[j] & 0xFFFFu);
+        for (uint32_t i = tid; i <= f2; i += PART_WG)
+            bidx[(size_t)i * n_rows + row] = (uint16_t)(i < f2 ? toff[i] : toff[f2 - 1u] + cnt[f2 - 1u]);
+        __syncthreads();
+        const uint32_t nv = toff[f2 - 1u] + cnt[f2 - 1u];               // records of the tile
+        uint4 *dst = reinterpret_cast<uint4 *>(out16 + (size_t)(row0 + row) * PART_TILE);
+        for (uint32_t i = tid; i < (nv + 7u) / 8u; i += PART_WG) dst[i] = stage4[i];       // whole 16-byte groups: the row is the tile's alone
+        __syncthreads();
+        for (uint32_t i = tid; i < f2; i += PART_WG) cnt[i] = 0u;
+        __syncthreads();
+    }
+}
+
+// k_apply_tiles: k_apply on the output of k_sort_tiles: the region's records are its run in every tile of its bin.
+// Wave w takes the tiles w, w + 8, ... of the bin (a lane reads one tile's two index entries), then their runs one after
+// the other, four 16-bit records per lane and step from 8-byte-aligned loads; the loads of the next four runs are in
+// flight while four are added.
+__global__ __launch_bounds__(APPLY_WG) void k_apply_tiles(uint8_t *sim, size_t sim_bytes, const uint16_t *recs16, const uint32_t *tbase,
+                                                          const uint16_t *idx, uint32_t bin_shift)
+{
+    constexpr uint32_t RW = (1u << REGION_SHIFT) / 4u;           // words per region
+    constexpr uint32_t NWV = APPLY_WG / 64, UR = 4;
+    __shared__ uint4 reg4[RW / 4];
+    uint32_t *reg = reinterpret_cast<uint32_t *>(reg4);
+    const uint32_t region = blockIdx.x, lane = lane_id(), wave = threadIdx.x >> 6;
+    const size_t reg_base = (size_t)region << REGION_SHIFT;      // grid = regions that start inside the table
+    const uint32_t f2 = 1u << (bin_shift - REGION_SHIFT), bin = region >> (bin_shift - REGION_SHIFT), sub = region & (f2 - 1u);
+    const uint32_t row0 = tbase[bin], n_rows = tbase[bin + 1] - row0;
+    const uint16_t *ia = idx + (size_t)row0 * (f2 + 1u) + (size_t)sub * n_rows, *ie = ia + n_rows;
+    // lane l reads the index entries of the l-th of the wave's tiles (the first 64 before the region is cleared: the
+    // loads fly meanwhile)
+    uint32_t a = 0, e = 0;
+    { const uint32_t t = wave + NWV * lane; if (t < n_rows) { a = ia[t]; e = ie[t]; } }
+    for (uint32_t i = threadIdx.x; i < RW / 4; i += APPLY_WG) reg4[i] = make_uint4(0u, 0u, 0u, 0u);
+    __syncthreads();
+    auto add = [&](uint32_t o) {                                  // one record: + 1 modulo 256 on byte o of the region
+        const uint32_t sh = (o & 3u) * 8u;
+        uint32_t *w = &reg[o >> 2];
+        uint32_t seen = *w;
+        for (;;) {
+            const uint32_t b = ((seen >> sh) + 1u) & 255u;
+            const uint32_t old = atomicCAS(w, seen, (seen & ~(255u << sh)) | (b << sh));
+            if (old == seen) break;
+            seen = old;
+        }
+    };
+    struct Step { uint2 v[UR]; uint32_t fa[UR], fe[UR], q[UR]; const uint16_t *src[UR]; };
+    for (uint32_t outer = 0; outer < n_rows; outer += NWV * 64u) {
+        if (outer) { a = 0u; e = 0u; const uint32_t t = outer + wave + NWV * lane; if (t < n_rows) { a = ia[t]; e = ie[t]; } }
+        const uint32_t left = n_rows - outer;                      // tiles of this round: the wave's are wave, wave + NWV, ... < left
+        const uint32_t nl = left > wave ? ((left - wave + NWV - 1u) / NWV < 64u ? (left - wave + NWV - 1u) / NWV : 64u) : 0u;
+        auto load_step = [&](uint32_t l0, Step &s) {              // the first 256 records of the runs l0 .. l0 + UR of this wave
+#pragma unroll
+            for (uint32_t u = 0; u < UR; ++u) {
+                const uint32_t l = l0 + u;
+                s.fa[u] = l < nl ? rl32(a, l) : 0u; s.fe[u] = l < nl ? rl32(e, l) : 0u;
+                s.q[u] = (s.fa[u] >> 2) + lane;                   // this lane's group of four records
+                s.src[u] = recs16 + (size_t)(row0 + outer + wave + NWV * l) * PART_TILE;
+                s.v[u] = make_uint2(0u, 0u);
+                if (s.q[u] * 4u < s.fe[u]) s.v[u] = *reinterpret_cast<const uint2 *>(s.src[u] + (size_t)s.q[u] * 4u);
+            }
+        };
+        Step nxt;
+        if (nl) load_step(0u, nxt);
+        for (uint32_t l0 = 0; l0 < nl; l0 += UR) {
+            Step cur = nxt;
+            if (l0 + UR < nl) load_step(l0 + UR, nxt);            // the next runs' loads go out before these are added
+#pragma unroll
+            for (uint32_t u = 0; u < UR; ++u) {
+                uint32_t q = cur.q[u];
+                uint2 w = cur.v[u];
+                const uint32_t fa = cur.fa[u], fe = cur.fe[u];
+                while (__ballot(q * 4u < fe)) {
+                    if (q * 4u < fe) {
+                        const uint32_t p = q * 4u;
+                        if (p >= fa) add(w.x & 0xFFFFu);
+                        if (p + 1u >= fa && p + 1u < fe) add(w.x >> 16);
+                        if (p + 2u >= fa && p + 2u < fe) add(w.y & 0xFFFFu);
+                        if (p + 3u >= fa && p + 3u < fe) add(w.y >> 16);
+                    }
+                    q += 64u;                                     // (runs beyond 256 records: further steps, loaded here)
+                    if (q * 4u < fe) w = *reinterpret_cast<const uint2 *>(cur.src[u] + (size_t)q * 4u);
+                }
+            }
+        }
+    }
+    __syncthreads();
+    uint4 *dst = reinterpret_cast<uint4 *>(sim + reg_base);
+    const size_t left = (sim_bytes - reg_base) / 16u;            // sim_bytes is a multiple of 16
+    for (uint32_t i = threadIdx.x; i < RW / 4 && i < left; i += APPLY_WG) dst[i] = reg4[i];
+}
+
 // k_apply: one workgroup builds one 64 KB region of the table in LDS -- zero, add the region's records (exact
 // modulo 256 per byte cell: an LDS compare-and-swap on the containing word), write it out once with 16-byte
 // stores.  Two workgroups fit a CU, so one region's write-out overlaps the next one's accumulation.  The table
@@ -2343,6 +2496,19 @@ void launch_apply(uint8_t *sim, size_t sim_bytes, const uint32_t *recs, const ui
     const uint32_t grid = (uint32_t)((sim_bytes + ((size_t)1 << REGION_SHIFT) - 1) >> REGION_SHIFT);
     hipLaunchKernelGGL(k_apply, dim3(grid), dim3(APPLY_WG), 0, st, sim, sim_bytes, recs, regbase, bin_shift);
 }
+
+// second level by tiles (k_sort_tiles + k_apply_tiles).  tbase: n_bins + 1 words; idx: (tiles + n_bins) * (f2 + 1) 16-bit entries;
+// out16: PART_TILE 16-bit records per tile row (tiles_bound() rows at most)
+void launch_apply_by_tiles(uint8_t *sim, size_t sim_bytes, const uint32_t *recs, const uint64_t *binbase, uint32_t n_bins, uint32_t bin_shift,
+                           uint32_t *tbase, uint16_t *idx, uint16_t *out16, hipStream_t st)
+{
+    hipLaunchKernelGGL(k_tile_bases, dim3(1), dim3(PART_WG), 0, st, binbase, n_bins, tbase);
+    hipLaunchKernelGGL(k_sort_tiles, dim3(n_bins), dim3(PART_WG), 0, st, recs, binbase, bin_shift, tbase, idx, out16);
+    const uint32_t grid = (uint32_t)((sim_bytes + ((size_t)1 << REGION_SHIFT) - 1) >> REGION_SHIFT);
+    hipLaunchKernelGGL(k_apply_tiles, dim3(grid), dim3(APPLY_WG), 0, st, sim, sim_bytes, out16, tbase, idx, bin_shift);
+}
+uint64_t tiles_bound(uint64_t n_records, uint32_t n_bins) { return n_records / PART_TILE + n_bins; }
+uint32_t part_tile() { return PART_TILE; }
 
 void launch_regroup(const uint32_t *rx, const uint64_t *srcoff, uint32_t n_src, uint32_t nb, const uint64_t *dstbase, uint32_t *dst, hipStream_t st)
 {
