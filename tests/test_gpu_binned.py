@@ -51,13 +51,16 @@ def test_binned_fused_vs_oracle(bctx, n, nr, ng, mode):
         assert np.array_equal(sim, exp)
 
 
+@pytest.mark.parametrize("second", ["tiles", "sweeps"])
 @pytest.mark.parametrize("levels,nr,ng", [("1,1", 3000, 300), ("2,3", 5000, 1200), ("4,7", 40000, 700), ("1,2", 1, 1)])
-def test_binned_two_levels_on_small_tables(monkeypatch, levels, nr, ng):
-    """LIME_BIN_LEVELS forces bins of several regions (second partition level, k_part2) on tables of a few regions:
-    1 bin for the whole table, 3 bins of 32 regions, ... ; one cell only"""
+def test_binned_two_levels_on_small_tables(monkeypatch, levels, nr, ng, second):
+    """LIME_BIN_LEVELS forces bins of several regions (second partition level) on tables of a few regions: 1 bin for
+    the whole table, 3 bins of 32 regions, ... ; one cell only.  Second level: tile by tile (k_sort_tiles +
+    k_apply_tiles, the default) and the two-sweep kernels kept for comparison runs (k_part2 + k_apply)."""
     import lime_amd
     monkeypatch.setenv("LIME_UPDATE_PATH", "bin")
     monkeypatch.setenv("LIME_BIN_LEVELS", levels)
+    monkeypatch.setenv("LIME_SECOND_LEVEL", second)
     c = lime_amd.Context()
     try:
         n = 1200000
