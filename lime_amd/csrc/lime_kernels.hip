@@ -2,19 +2,19 @@
 // alpha-cluster detection over lcp/da (reference: src/ClusterLCP.cpp:140-283) and per-cluster
 // read x genome similarity accumulation over ebwt/da (reference: src/ClusterBWT_DA.cpp:256-358).
 //
-// Design (see DESIGN.md): the unit of work is a POSITION; clusters are segments delimited by
-// head(i) := lcp[i] < alpha.  Every WAVE is an independent worker: it streams 512-position
-// windows (+16 positions of read-ahead) with 16-byte loads, 8 consecutive positions per lane,
-// keeps the next window's loads in flight while it works on the current one, and never meets
-// a workgroup barrier.  Per window: head / read / genome bits of a lane's 8 positions become
-// bytes of 64-bit masks (lane = mask word); which heads open an accepted cluster is decided by
-// carry-ripple arithmetic on those masks; the clusters (<= 16 symbols) are scored by groups of
-// 4 or 16 lanes that rotate the cluster's elements past each other with DPP moves; table
-// updates are queued in LDS and applied together.  Clusters that do not close inside the
-// read-ahead are closed from per-window summaries by k_resolve; clusters longer than 16 go to
-// a one-workgroup-per-cluster hash kernel.  Integer/byte work only: no MFMA, HBM-bound; the
-// score table is updated with 32-bit CAS on the packed byte cells so that every cell is exact
-// modulo 256 like the reference's unsigned char.
+// Design (see DESIGN.md 4): the unit of work is a POSITION; clusters are segments delimited by
+// head(i) := lcp[i] < alpha.  Every WAVE is an independent worker over 1024-position windows (+16
+// positions of read-ahead): lane-strided dword loads (register j of lane l = position 64 j + l),
+// the next window's loads in flight while the current one is worked on, no workgroup barrier in
+// the loop; the waves of a workgroup (one per CU) draw their windows from one LDS counter.  Per
+// window: head / read bits as wave ballots (= mask words), acceptance of the segments by carry-ripple
+// arithmetic on 16-bit chunks, a list of the accepted clusters' positions in LDS, clusters of 2..4
+// symbols one per lane, 5..16 by fixed lane groups, 17..64 one at a time by the whole wave; table
+// updates are queued in LDS and leave either as compare-and-swaps on the packed byte cells (exact
+// modulo 256 like the reference's unsigned char) or as 4-byte records that later kernels bin and
+// apply through LDS.  Segments still open after the read-ahead are closed by k_resolve_open /
+// k_resolve; clusters longer than 64 go to a one-workgroup-per-cluster hash kernel.  Integer / byte
+// work only: no MFMA, HBM-bound.
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include <atomic>
@@ -92,9 +92,8 @@ extern "C" int lime_debug_winmark(uint32_t *out)
 #define PT_WAITVM
 #endif
 
-// LDS of one wave of k_scan (kept small: it bounds the waves a CU holds)
-// threads per workgroup of k_scan (its waves work independently) and waves per SIMD it is compiled for: ScanCfg in
-// lime_kernels.h (EBWT = 0: 8 waves, two workgroups per CU = 4 waves per SIMD; EBWT = 1: 4 waves, three workgroups)
+// threads per workgroup of k_scan and waves per SIMD it is compiled for: ScanCfg in lime_kernels.h (one workgroup per CU:
+// EBWT = 0: 16 waves = 4 per SIMD; EBWT = 1: 12 waves = 3 per SIMD); the LDS of one wave is kept small: it bounds them
 constexpr uint32_t DUP_SLOTS = 8;     // clusters with a repeated document a wave of k_scan holds before scoring them
 constexpr uint32_t QCAP_SCAN = 286;   // >= the 256 hits one batch of 64 clusters of <= 4 symbols can add + the 2 x 15 entries a binned drain leaves behind
 
@@ -1060,8 +1059,9 @@ __device__ __forceinline__ void window_load(WinRegs &t, const ScanArgs &a, uint6
 }
 
 // =========================================================================================
-// (a workgroup takes chunks of consecutive windows round-robin, its waves draw from the chunk); no workgroup barrier in the loop.
-// (stride = number of waves in the grid); no workgroup barrier in the loop.
+// k_scan: the streaming scan.  Every wave is an independent worker over windows of WIN positions; a workgroup (one per
+// CU) takes chunks of as many consecutive windows as it has waves, which draw them from an LDS counter; no workgroup
+// barrier in the loop.
 // MODE 0: detect + score; 1: count clusters per window and keep the window's masks for k_emit.
 // Front end: lane-strided loads; mask words from wave ballots; lane l owns the CHUNK of positions
 // [16 l, 16 l + 16): its head / read bits are 16-bit masks cut out of the mask words, cluster
@@ -1071,7 +1071,7 @@ __device__ __forceinline__ void window_load(WinRegs &t, const ScanArgs &a, uint6
 // (position, length) of its accepted clusters into an LDS list at the slots a wave prefix sum gives
 // it; the scoring rounds read that list 64 clusters at a time.
 // =========================================================================================
-template <int EBWT>                          // EBWT == 0: no symbols are staged (a kilobyte less per wave: a fourth workgroup per CU)
+template <int EBWT>                          // EBWT == 0: no symbols are staged (a kilobyte less per wave)
 struct alignas(16) ScanLdsT {
     uint32_t da[WPOS + SMALL_MAX];
     uint8_t fl[EBWT ? WPOS + SMALL_MAX : 16];
