@@ -438,6 +438,8 @@ static int fused_dev_impl(lime_ctx *c, const uint32_t *d_lcp, const uint32_t *d_
     if (binned) {
         a.upd_mode = 1; a.pool = c->d_pool; a.cap_w = cap_w; a.n_sub = n_sub; a.wave_cnt = c->d_wave_cnt; a.counts = c->d_counts;
         a.n_bins = n_bins; a.bin_shift = bin_shift; a.prod_waves = scan_waves_per_wg(ebwt, 0);
+        a.sub_rb = 0xFFFFFFFFu; a.sub_gb = 0u;
+        if (n_sub == 2) { a.sub_rb = (uint32_t)((1ull << 32) / n_refs); a.sub_gb = (uint32_t)((1ull << 32) - (uint64_t)a.sub_rb * n_refs); }
     }
     if (records_only) { a.sim = nullptr; a.bigrec = c->d_bigrec; a.bigrec_n = c->d_bigrec_n; a.bigrec_cap = c->bigrec_cap; }
     if ((rc = timing_mark(c, st))) return rc;

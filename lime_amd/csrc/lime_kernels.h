@@ -79,6 +79,7 @@ struct ScanArgs {
     WinMasks *wmask;                             // detect only: count pass -> emit pass
     uint32_t *edge;                              // LIME_EDGE_* word of this shard (default: &stats->edge)
     uint32_t *dyn; uint32_t n_static, static_pct;           // k_scan: rounds of round-robin window chunks before the chunks come from the counter dyn[0] (dyn[1]: workgroups done; both are left at 0); set by the launch wrapper from static_pct
+    uint32_t sub_rb, sub_gb;                     // binned, two sub-regions: cell >= 2^32 <=> read > sub_rb or (read == sub_rb and genome >= sub_gb); one sub-region: sub_rb = ~0
     uint32_t *sticky;                            // passes whose record pool overflowed and that lime_get_stats has not settled yet (never cleared by a pass)
     int ablate;                                  // timing experiments only (LIME_ABLATE_BUILD): 0 = full kernel
     // binned table updates (upd_mode 1; 0 = compare-and-swap on the table)

@@ -254,6 +254,7 @@ struct UpdQueue { uint32_t *qr, *qg; uint32_t n, cap;
     // binned mode (ScanArgs::upd_mode): drains append (cell, t) records to the wave's region of the pool and count
     // them per table bin in the workgroup's LDS histogram; no table access from the scan at all
     bool binned = false; uint32_t *out = nullptr; lds_vu32 *sub_n = nullptr; uint32_t *hist = nullptr;   // out: the wave's n_sub sub-regions; sub_n: records in each (LDS)
+    uint32_t *lbuf = nullptr; lds_vu32 *lfill = nullptr;   // one or two sub-regions: finished records wait here (LBUF per sub-region, lfill[s] of them) until they fill 64-byte lines
 #ifdef LIME_PHASE_TIMING
     uint64_t t_drain = 0; uint32_t n_drain = 0;
 #endif
@@ -319,82 +320,109 @@ __device__ __forceinline__ void drain_async(UpdQueue &q, const ScanArgs &a)
         }
 }
 
-// Binned mode: the queue's entries become pool records cell | t << CELL_BITS, written 64 at a time to the wave's
-// own region (coalesced 512-byte stores); records beyond the region's capacity are only counted (the host
-// repeats the pass with a larger pool: LIME_FLAG_POOL_FULL).
-// LINES: the once-per-window drain of the scan's main loop; the drains an overfull queue forces elsewhere (rare) write everything
-template <bool LINES>
-__device__ __forceinline__ void drain_bin(UpdQueue &q, const ScanArgs &a)
+// Tables of one or two sub-regions (up to 8 GB): the queue's entries become finished 4-byte records in a small LDS
+// buffer per sub-region, and only WHOLE 64-byte lines leave it (partial-line writes cost the N = 10^10 scan 5 %); up to 15
+// records per sub-region wait there for the next drain, as records -- nothing is looked at twice (the first version
+// kept them as queue entries: a counting loop, a compaction of the kept entries and their 64-bit cell arithmetic again in
+// every drain, ~200 vector instructions per window).  `final`: the kernel's last drain writes the partial lines too.
+constexpr uint32_t LBUF = 80;                                     // <= 15 waiting + 64 new records per sub-region
+__device__ __forceinline__ void drain_lines(UpdQueue &q, const ScanArgs &a, bool final)
 {
     const uint32_t lane = lane_id();
-    // A record is the LOW 32 bits of the cell; the high part picks one of the wave's n_sub sub-regions (one for tables
-    // below 4 GB) and the score is implicit: a pair that scores t > 1 (repeated documents only) leaves t records.  Every
-    // byte the scan stores costs its read stream dearly -- a gigabyte of appended records slows 8 GB of loads from 1.15 to
-    // 1.76 ms whatever the layout of the stores (tools/load_bench.hip) -- so the records are as short as they can be, and
-    // (one or two sub-regions) only whole 64-byte lines leave: per sub-region a multiple of 16 entries, the regions start
-    // line-aligned; the up to 15 entries per sub-region left over move to the queue's front (partial-line writes cost the
-    // N = 10^10 scan 5 %).  The kernel's last drain (flush_all) takes everything.
     const uint32_t n = q.n;
-    const bool lines = LINES && a.n_sub <= 2u;
-    uint32_t lim0 = ~0u, lim1 = ~0u;                              // entries of sub-region 0 / 1 that leave now
-    if (lines) {
-        uint32_t c1 = 0;
-        if (a.n_sub == 2u)
-            for (uint32_t k0 = 0; k0 < n; k0 += 64u) {
-                const uint32_t k = k0 + lane;
-                const bool on = k < n;
-                const uint64_t cell = (uint64_t)q.qr[on ? k : 0u] * a.n_refs + (q.qg[on ? k : 0u] & (MAX_REFS - 1u));
-                c1 += (uint32_t)__popcll(__ballot(on && (uint32_t)(cell >> 32) == 1u));
-            }
-        lim0 = (n - c1) & ~15u; lim1 = c1 & ~15u;
-        if (!(lim0 | lim1)) return;
+    const ScanArgs &ca = cold(a);                                 // the fields a drain needs are loaded here, not held through the window loop
+    const uint32_t cap_w = ca.cap_w, bin_shift = ca.bin_shift, n_sub = ca.n_sub, sub_rb = ca.sub_rb, sub_gb = ca.sub_gb, n_refs = ca.n_refs;
+    uint32_t f0 = (uint32_t)__builtin_amdgcn_readfirstlane((int)q.lfill[0]), f1 = (uint32_t)__builtin_amdgcn_readfirstlane((int)q.lfill[1]);
+    auto flush = [&](uint32_t sub, uint32_t &f, uint32_t keep_mask) {      // keep_mask = 15: whole lines only; 0: everything
+        const uint32_t nl = f & ~keep_mask;
+        if (!nl) return;
+        const uint32_t base = (uint32_t)__builtin_amdgcn_readfirstlane((int)q.sub_n[sub]);
+        uint32_t *lb = q.lbuf + sub * LBUF;
+        const uint32_t rec = lb[lane < nl ? lane : 0u];
+        const uint32_t slot = base + lane;
+        if (lane < nl && slot < cap_w && !ABL(7)) {               // a full sub-region only counts (sub_n): the pass is repeated with a larger pool
+            const uint32_t bin = n_sub == 1u ? rec >> bin_shift : (rec >> bin_shift) | (sub << (32u - bin_shift));
+            atomicAdd(&q.hist[bin], 1u);                          // the histogram counts exactly the records that are stored
+            if (!ABL(6)) __builtin_nontemporal_store(rec, q.out + (size_t)sub * cap_w + slot);
+        }
+        const uint32_t rem = f - nl;
+        const uint32_t mv = lb[lane < rem ? nl + lane : 0u];      // (all lanes read before any writes: one instruction each)
+        if (lane < rem) lb[lane] = mv;
+        if (lane == 0) q.sub_n[sub] = base + nl;
+        f = rem;
+    };
+    for (uint32_t k0 = 0; k0 < n; k0 += 64u) {
+        const uint32_t k = k0 + lane;
+        const bool on = k < n;
+        const uint32_t gt = q.qg[on ? k : 0u], rd = q.qr[on ? k : 0u];
+        const uint32_t g = gt & (MAX_REFS - 1u);
+        // the scan's fast emitters do not look at the document ids: a genome id beyond the table is caught here, on
+        // full waves (the entry is dropped; the pass fails with LIME_ERR_DOCID)
+        const bool bad = on && g >= n_refs;
+        if (__ballot(bad)) { if (bad) atomicOr(&cold(a).stats->flags, LIME_FLAG_DOCID); }
+        const uint32_t rec = rd * n_refs + g;                     // the cell's low 32 bits
+        const bool hi = rd > sub_rb || (rd == sub_rb && g >= sub_gb);
+        uint32_t left = (on && !bad) ? gt >> T_SHIFT : 0u;
+        while (__ballot(left != 0u)) {                            // once, unless a pair scored more than 1
+            const bool act = left != 0u;
+            const uint64_t m1 = __ballot(act && hi), m0 = __ballot(act && !hi);
+            if (act) q.lbuf[hi ? LBUF + f1 + rank_in(m1) : f0 + rank_in(m0)] = rec;
+            f0 += (uint32_t)__popcll(m0); f1 += (uint32_t)__popcll(m1);
+            left -= (uint32_t)act;
+            flush(0u, f0, 15u);
+            if (m1) flush(1u, f1, 15u);
+        }
     }
-    uint32_t seen0 = 0, seen1 = 0, kept = 0;                      // entries of each sub-region met so far; entries kept
+    q.n = 0;
+    if (final) { flush(0u, f0, 0u); flush(1u, f1, 0u); }
+    if (lane == 0) { q.lfill[0] = f0; q.lfill[1] = f1; }
+}
+
+// Binned mode: the queue's entries become 4-byte pool records in the wave's own region: the LOW 32 bits of the cell; the
+// high part picks one of the wave's n_sub sub-regions and the score is implicit (a pair that scores t > 1 -- repeated
+// documents only -- leaves t records).  Every byte the scan stores costs its read stream dearly -- a gigabyte of appended
+// records slows 8 GB of loads from 1.15 to 1.76 ms whatever the layout of the stores (tools/load_bench.hip) -- so the
+// records are as short as they can be.  Records beyond a sub-region's capacity are only counted (the host repeats the pass
+// with a larger pool: LIME_FLAG_POOL_FULL).  One or two sub-regions (tables up to 8 GB): drain_lines above; more: here,
+// 64 records at a time as they come.
+__device__ __forceinline__ void drain_bin(UpdQueue &q, const ScanArgs &a)
+{
+    if (cold(a).n_sub <= 2u) { drain_lines(q, a, false); return; }         // (re-read: a flag held through the window loop is a pair of SGPRs)
+    const uint32_t lane = lane_id();
+    const ScanArgs &ca = cold(a);
+    const uint32_t n = q.n, n_sub = ca.n_sub, cap_w = ca.cap_w, n_refs = ca.n_refs, bin_shift = ca.bin_shift;
     for (uint32_t k0 = 0; k0 < n; k0 += 64u) {
         const uint32_t k = k0 + lane;
         const bool on = k < n;
         const uint32_t gt = q.qg[on ? k : 0u], rd = q.qr[on ? k : 0u];
         // the scan's fast emitters do not look at the document ids: a genome id beyond the table is caught here, on
         // full waves (the entry is dropped; the pass fails with LIME_ERR_DOCID)
-        const bool bad = on && (gt & (MAX_REFS - 1u)) >= a.n_refs;
+        const bool bad = on && (gt & (MAX_REFS - 1u)) >= n_refs;
         if (__ballot(bad)) { if (bad) atomicOr(&cold(a).stats->flags, LIME_FLAG_DOCID); }
-        const uint64_t cell = (uint64_t)rd * a.n_refs + (gt & (MAX_REFS - 1u));
+        const uint64_t cell = (uint64_t)rd * n_refs + (gt & (MAX_REFS - 1u));
         const uint32_t hi = (uint32_t)(cell >> 32);
-        bool go = on;                                             // leaves now (else stays queued)
-        if (lines) {
-            const uint64_t m1 = __ballot(on && hi == 1u), m0 = __ballot(on && hi != 1u);
-            const uint32_t r = hi == 1u ? seen1 + rank_in(m1) : seen0 + rank_in(m0);
-            go = on && r < (hi == 1u ? lim1 : lim0);
-            seen0 += (uint32_t)__popcll(m0); seen1 += (uint32_t)__popcll(m1);
-            const uint64_t mk = __ballot(on && !go);
-            if (mk) {                                             // kept entries close up at the queue's front (index <= their own)
-                if (on && !go) { const uint32_t d = kept + rank_in(mk); q.qg[d] = gt; q.qr[d] = rd; }
-                kept += (uint32_t)__popcll(mk);
-            }
-        }
-        uint32_t left = (go && !bad) ? gt >> T_SHIFT : 0u;
+        uint32_t left = (on && !bad) ? gt >> T_SHIFT : 0u;
         while (__ballot(left != 0u)) {                            // once, unless a pair scored more than 1
-            for (uint32_t sub = 0; sub < a.n_sub; ++sub) {        // wave-uniform; one sub-region for tables below 4 GB
+            for (uint32_t sub = 0; sub < n_sub; ++sub) {          // wave-uniform
                 const bool mine = left != 0u && hi == sub;
                 const uint64_t m = __ballot(mine);
                 if (!m) continue;
                 const uint32_t base = q.sub_n[sub];               // LDS, one address: a broadcast read
                 const uint32_t slot = base + rank_in(m);
-                if (mine && slot < a.cap_w && !ABL(7)) {          // a full sub-region only counts (sub_n): the pass is repeated with a larger pool
-                    atomicAdd(&q.hist[(uint32_t)(cell >> a.bin_shift)], 1u);     // the histogram counts exactly the records that are stored
-                    if (!ABL(6)) __builtin_nontemporal_store((uint32_t)cell, q.out + (size_t)sub * a.cap_w + slot);
+                if (mine && slot < cap_w && !ABL(7)) {            // a full sub-region only counts (sub_n): the pass is repeated with a larger pool
+                    atomicAdd(&q.hist[(uint32_t)(cell >> bin_shift)], 1u);     // the histogram counts exactly the records that are stored
+                    if (!ABL(6)) __builtin_nontemporal_store((uint32_t)cell, q.out + (size_t)sub * cap_w + slot);
                 }
                 if (lane == 0) q.sub_n[sub] = base + (uint32_t)__popcll(m);
             }
             left -= (uint32_t)(left != 0u);
         }
     }
-    q.n = kept;
+    q.n = 0;
 }
-
 __device__ __forceinline__ void drain(UpdQueue &q, const ScanArgs &a)
 {
-    if (q.async) { if (q.binned) drain_bin<false>(q, a); else drain_async(q, a); return; }     // both flags are compile-time constants of the kernel
+    if (q.async) { if (q.binned) drain_bin(q, a); else drain_async(q, a); return; }     // both flags are compile-time constants of the kernel
 #ifdef LIME_PHASE_TIMING
     const uint64_t t0 = __builtin_readcyclecounter();
 #endif
@@ -1071,7 +1099,7 @@ __device__ __forceinline__ void window_load(WinRegs &t, const ScanArgs &a, uint6
 // (position, length) of its accepted clusters into an LDS list at the slots a wave prefix sum gives
 // it; the scoring rounds read that list 64 clusters at a time.
 // =========================================================================================
-template <int EBWT>                          // EBWT == 0: no symbols are staged (a kilobyte less per wave)
+template <int EBWT, int BIN>                 // EBWT == 0: no symbols are staged (a kilobyte less per wave); BIN: the line buffers of the record drains
 struct alignas(16) ScanLdsT {
     uint32_t da[WPOS + SMALL_MAX];
     uint8_t fl[EBWT ? WPOS + SMALL_MAX : 16];
@@ -1084,6 +1112,7 @@ struct alignas(16) ScanLdsT {
     uint16_t m_tstart[64];                   // the round's clusters of 9..SMALL_MAX symbols (position | (len-1) << 12)
     uint32_t q_read[QCAP_SCAN], q_gen[QCAP_SCAN];
     uint32_t sub_n[MAX_SUB];                 // binned updates: records in each of the wave's sub-regions
+    uint32_t lfill[2], lbuf[BIN ? 2 * LBUF : 2];   // records waiting for their 64-byte line (drain_lines)
     uint32_t g_doc[DUP_SLOTS][SMALL_MAX];
     uint8_t g_sym[EBWT ? DUP_SLOTS : 1][SMALL_MAX], g_len[DUP_SLOTS];
 };
@@ -1164,7 +1193,7 @@ __global__ __launch_bounds__(ScanCfg<EBWT>::wg) __attribute__((amdgpu_waves_per_
 {
     constexpr int SCANK_WG = ScanCfg<EBWT>::wg;
     static_assert(BIN == 0 || MODE == 0, "records are made by the scoring scan only");
-    typedef ScanLdsT<EBWT> ScanLds;
+    typedef ScanLdsT<EBWT, BIN> ScanLds;
     __shared__ ScanLds lds[SCANK_WG / 64];
     __shared__ WgTables T;
     // per wave the in-flight compare-and-swap slots (entry read, genome | t, expected word: 3 x 64 NJ words, NJ slots per
@@ -1193,16 +1222,19 @@ __global__ __launch_bounds__(ScanCfg<EBWT>::wg) __attribute__((amdgpu_waves_per_
     const uint32_t wave_gid = blockIdx.x * (SCANK_WG / 64) + wave;
     qu.binned = binned;
     if (binned) {
-        qu.out = a.pool + (size_t)wave_gid * a.n_sub * a.cap_w; qu.hist = fslots; qu.sub_n = (lds_vu32 *)L.sub_n;
+        qu.out = cold(a).pool + (size_t)wave_gid * cold(a).n_sub * cold(a).cap_w; qu.hist = fslots; qu.sub_n = (lds_vu32 *)L.sub_n;
+        qu.lbuf = L.lbuf; qu.lfill = (lds_vu32 *)L.lfill;
         if (lane < MAX_SUB) L.sub_n[lane] = 0u;
+        if (lane < 2u) L.lfill[lane] = 0u;
     }
     // binned mode, end of a wave: its record count; the workgroup's last wave writes the bin histogram
     auto finish_binned = [&]() {
-        if (lane < a.n_sub) {
+        const uint32_t n_sub = cold(a).n_sub, cap_w = cold(a).cap_w;
+        if (lane < n_sub) {
             const uint32_t n = qu.sub_n[lane];
-            cold(a).wave_cnt[(size_t)wave_gid * a.n_sub + lane] = n < a.cap_w ? n : a.cap_w;
+            cold(a).wave_cnt[(size_t)(blockIdx.x * (SCANK_WG / 64) + wave) * n_sub + lane] = n < cap_w ? n : cap_w;
             atomicMax(&wg_rec_max, n);
-            if (n > a.cap_w) {                                 // the pass's first overflow also counts the pass as unsettled
+            if (n > cap_w) {                                 // the pass's first overflow also counts the pass as unsettled
                 const uint32_t old = atomicOr(&cold(a).stats->flags, LIME_FLAG_POOL_FULL);
                 if (!(old & LIME_FLAG_POOL_FULL)) atomicAdd(cold(a).sticky, 1u);
             }
@@ -1320,8 +1352,10 @@ __global__ __launch_bounds__(ScanCfg<EBWT>::wg) __attribute__((amdgpu_waves_per_
             if (EBWT)
 #pragma unroll
                 for (int k = 0; k < (int)PPL / 4; ++k) reinterpret_cast<u32u *>(L.fl)[64 * k + (int)lane] = regs.bv[k];
-            if (lane < HALO) { L.da[WIN + lane] = regs.hd; if (EBWT) L.fl[WIN + lane] = (uint8_t)regs.hb; }
-            if (lane <= WIN / 64) {
+            uint32_t lane_v = lane;                         // opaque per window: the lane masks below are compared here instead of living in SGPR pairs through the loop
+            asm volatile("" : "+v"(lane_v));
+            if (lane_v < HALO) { L.da[WIN + lane] = regs.hd; if (EBWT) L.fl[WIN + lane] = (uint8_t)regs.hb; }
+            if (lane_v <= WIN / 64) {
                 *reinterpret_cast<u64a *>(&L.hb[8u * lane]) = h;
                 *reinterpret_cast<u64a *>(&L.rb[8u * lane]) = r;
             }
@@ -1338,7 +1372,7 @@ __global__ __launch_bounds__(ScanCfg<EBWT>::wg) __attribute__((amdgpu_waves_per_
         // its acknowledgement when it wants to stage the loaded window (measured on configs[2]: 0.34 of 2.06 ms with the
         // stores issued from the scoring rounds).  Issued here they are older than the loads and long done by then.
         if (MODE == 0 && !ABL(8)) {
-            if (binned) drain_bin<true>(qu, a); else drain(qu, a);
+            if (binned) drain_bin(qu, a); else drain(qu, a);
             asm volatile("" ::: "memory");                    // the loads below stay below
         }
         // ---- the next window's loads go out now and land while this one is processed ----------
@@ -1524,6 +1558,7 @@ __global__ __launch_bounds__(ScanCfg<EBWT>::wg) __attribute__((amdgpu_waves_per_
     if (MODE == 0) {
         if (n_dup) acc_upd += dup_flush<EBWT>(L, n_dup, a, T, qu);
         do drain(qu, a); while (qu.n != 0u || __ballot(qu.f_pend != 0u));      // until every update has landed
+        if (binned && cold(a).n_sub <= 2u) drain_lines(qu, a, true);           // the records still waiting for their line
         if (binned) finish_binned();
     }
 #ifdef LIME_PHASE_TIMING
