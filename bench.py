@@ -122,6 +122,16 @@ def run_pass_series(torch, lime_amd, ldist, wl, n_total, steps, warmup, world, r
     sim_bytes = lime_amd.sim_bytes(wl["nr"], wl["ng"])
     blk_bytes = ldist.table_block_bytes(sim_bytes, world)
     nbuf = 2 if (world > 1 and overlap) else 1
+    stream0 = torch.cuda.current_stream().cuda_stream
+    if world > 1 and exchange == "auto":
+        # one pass that stops at the binned records tells how many updates this rank's range makes; the ranks agree on the
+        # largest count and take the exchange that moves fewer bytes (lime_amd/dist.py:choose_exchange)
+        ctx.synth_dev(SEED, lo, n_avail, wl["nr"], wl["ng"], ALPHA, wl["mode"], lcp, da, eb, stream0)
+        ctx.fused_records_dev(lcp, da, eb, n_own, n_avail, hi_halo == n_total, wl["nr"], wl["ng"], ALPHA, stream0)
+        s0, rc0 = ctx.stats(stream0)
+        if rc0:
+            sys.exit(f"scan failed: rc={rc0}")
+        exchange = ldist.choose_exchange(comm.max_float(float(s0.n_updates)), sim_bytes)
     sparse = world > 1 and exchange == "sparse"
     if sparse:
         # owner-partitioned exchange: no table per rank, only this rank's block of it (T / world bytes)
@@ -208,7 +218,7 @@ def run_pass_series(torch, lime_amd, ldist, wl, n_total, steps, warmup, world, r
     s, rc = ctx.stats(stream)
     if rc:
         sys.exit(f"scan failed: rc={rc}")
-    res = {"dt": dt, "parts": parts, "launches": launches, "n_own": n_own, "n_clusters": int(s.n_clusters), "max_len": int(s.max_len),
+    res = {"exchange": exchange, "dt": dt, "parts": parts, "launches": launches, "n_own": n_own, "n_clusters": int(s.n_clusters), "max_len": int(s.max_len),
            "updates": int(s.n_updates), "binned": bool(s.wave_records_max > 0), "lcp": lcp, "da": da, "eb": eb}
     ctx.close()
     return res
@@ -235,8 +245,9 @@ def main():
     ap.add_argument("--scaling", default=None, choices=["strong", "weak"], help="N>1: strong (fixed --n-total, default) or weak (workload per GPU)")
     ap.add_argument("--n-total", type=float, default=None, help="symbols of the whole collection (strong scaling)")
     ap.add_argument("--n", type=float, default=None, help="symbols per GPU (overrides the workload's size)")
-    ap.add_argument("--exchange", default=os.environ.get("LIME_BENCH_EXCHANGE", "dense"), choices=["dense", "sparse"],
-                    help="N>1: dense = a uint8 reduce-scatter of whole tables (default); sparse = owner-partitioned exchange of update records")
+    ap.add_argument("--exchange", default=os.environ.get("LIME_BENCH_EXCHANGE", "dense"), choices=["dense", "sparse", "auto"],
+                    help="N>1: dense = a uint8 reduce-scatter of whole tables (default); sparse = owner-partitioned exchange of update records; "
+                         "auto = whichever moves fewer bytes for this workload (decided from a probe pass)")
     ap.add_argument("--no-cpu", action="store_true", help="skip the cpu_baseline leg")
     ap.add_argument("--no-also", action="store_true", help="skip the secondary workloads")
     ap.add_argument("--cpu-sample", type=int, default=200_000_000)
@@ -310,7 +321,7 @@ def main():
             "higher_is_better": True, "scaling": scaling, "vs_baseline": None, "dtype": "u8", "data": "synthetic",
             "config": {"workload": describe(wl, n_total, world), "symbols_total": n_total,
                        "sharding": ((f"position ranges x{world}; tables combined by one uint8 reduce-scatter per step through the C ABI "
-                                     f"(RCCL), exposed (the step waits for it)") if args.exchange == "dense" else
+                                     f"(RCCL), exposed (the step waits for it)") if r["exchange"] == "dense" else
                                     (f"position ranges x{world}; update records exchanged owner-partitioned through the C ABI (RCCL all-gather + "
                                      f"send/receive), every rank builds its block of the table")) if world > 1 else "one GPU",
                        "update_path": "binned (records -> bins -> table regions built in LDS)" if r["binned"] else "compare-and-swap on the table",
@@ -352,7 +363,7 @@ def main():
             also["overlapped"] = {"what": "the same series with the exchange of step k under the scan of step k+1 (two table buffers)",
                                   "value": n_total * args.steps / dt2, "ms_per_step": dt2 / args.steps * 1e3}
             del r2
-            if os.environ.get("LIME_BENCH_SPARSE") == "1" and args.exchange == "dense":
+            if os.environ.get("LIME_BENCH_SPARSE") == "1" and r["exchange"] == "dense":
                 r3 = run_pass_series(torch, lime_amd, ldist, wl, n_total, args.steps, args.warmup, world, rank, dev, comm, overlap=False, exchange="sparse")
                 dt3 = comm.max_float(r3["dt"])
                 also["sparse_exchange"] = {"what": "the same series with the owner-partitioned exchange of update records instead of the dense reduce-scatter",

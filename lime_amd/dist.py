@@ -35,6 +35,14 @@ def allreduce_tables(sim_t, group=None):
     return sim_t
 
 
+def choose_exchange(max_updates_per_rank, sim_bytes):
+    """dense (reduce-scatter of the ranks' byte tables: sim_bytes (G-1)/G over the links per rank, and every rank writes a
+    whole table) or sparse (owner-partitioned exchange of 4-byte update records, lime_comm_exchange_records: 4 x updates
+    (G-1)/G per rank, a rank writes its block only): whichever moves fewer bytes.  All ranks must call it with the same
+    numbers (the largest update count of any rank)."""
+    return "sparse" if 4 * int(max_updates_per_rank) < int(sim_bytes) else "dense"
+
+
 def table_block_bytes(sim_bytes, world):
     """bytes of one rank's block when the table is cut into `world` equal, 16-byte aligned blocks
     (the buffer handed to reduce_scatter_tables must hold world * this many bytes, zero padded)"""

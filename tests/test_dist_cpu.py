@@ -84,3 +84,14 @@ def test_two_rank_sharding_allreduce_mod256(world):
         p.join(120)
         assert p.exitcode == 0
     assert out.get(timeout=10) == (True, True, True)
+
+
+def test_choose_exchange_moves_fewer_bytes():
+    """dense = the table over the links, sparse = 4 bytes per update (lime_amd/dist.py:choose_exchange); the shapes of
+    BASELINE.json configs[4] over 8 GPUs and of a sparse pass over a small table"""
+    from lime_amd.dist import choose_exchange
+    assert choose_exchange(150_000_000, 1_000_000_000) == "sparse"      # N = 1e10 over 8 ranks: 0.6 GB of records, 1 GB table
+    assert choose_exchange(3_500_000, 50_000_000) == "sparse"           # configs[1]: 14 MB of records, 50 MB table
+    assert choose_exchange(120_000_000, 50_000_000) == "dense"
+    assert choose_exchange(0, 16) == "sparse"
+

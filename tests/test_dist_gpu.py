@@ -135,6 +135,12 @@ def test_bench_control_flow_with_two_ranks():
     d2 = json.loads([ln for ln in r.stdout.decode().splitlines() if ln.startswith("{")][-1])
     assert d2["n_gpus"] == 2 and d2["value"] > 0 and "owner-partitioned" in d2["config"]["sharding"]
     assert d2["config"]["n_clusters"] == d["config"]["n_clusters"]
+    # and with the exchange chosen from a probe pass: 14 MB of records against a 50 MB table -> records
+    r = _torchrun(["bench.py", "--gpus", "2", "--steps", "2", "--warmup", "1", "--workload", "c2", "--scaling", "strong",
+                   "--n-total", "30000000", "--exchange", "auto", "--no-also"], {"LIME_BENCH_BACKEND": "gloo"})
+    assert r.returncode == 0, r.stderr.decode()[-3000:]
+    d3 = json.loads([ln for ln in r.stdout.decode().splitlines() if ln.startswith("{")][-1])
+    assert "owner-partitioned" in d3["config"]["sharding"] and d3["config"]["n_clusters"] == d["config"]["n_clusters"]
 
 
 def test_rccl_calls_through_the_c_abi_on_one_rank():

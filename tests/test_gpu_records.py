@@ -98,3 +98,69 @@ def test_records_of_a_pool_that_is_too_small_are_repaired(monkeypatch):
     exp = O.score(da, eb, cl, nr, ng, threads=4)
     got, tot_c, tot_m, _ = _exchange_on_one_gpu(lime_amd, torch, lcp, da, eb, n, nr, ng, 16, 2)
     assert (tot_c, tot_m) == (nc, ml) and np.array_equal(got, exp)
+
+
+def test_blocks_at_the_shape_of_configs3():
+    """BASELINE.json configs[3]'s shapes (setB2: 20 249 373 reads x 930 genomes = 18.8 GB table, README.md:137; 4 GPUs) on
+    2 * 10^9 synthetic symbols generated on the device, EBWT=1: four position-range shards leave their updates as records (five
+    sub-regions per wave: the table is beyond 16 GB), every owner gathers the slices of its quarter of the bins and builds
+    its 4.7 GB block alone; block r must equal bytes [cell_lo, cell_lo + block_bytes) of the table of ONE fused pass over the
+    whole collection (which tests/test_gpu_parity.py::test_full_size_paths_agree[C4] ties to the other paths)."""
+    import torch
+    import lime_amd
+    from lime_amd.dist import shard_ranges, combine_edges
+    n, nr, ng, alpha, world = 2_000_000_000, 20_249_373, 930, 16, 4
+    dev = torch.device("cuda:0")
+    lcp = torch.empty(n, dtype=torch.int32, device=dev); da = torch.empty_like(lcp)
+    eb = torch.empty(n, dtype=torch.uint8, device=dev)
+    c0 = lime_amd.Context()
+    c0.synth_dev(42, 0, n, nr, ng, alpha, 0, lcp, da, eb)
+    tb = lime_amd.sim_bytes(nr, ng)
+    A = torch.empty(tb, dtype=torch.uint8, device=dev)
+    c0.fused_dev(lcp, da, eb, n, n, True, nr, ng, alpha, A, True)
+    sA, rc = c0.stats(); assert rc == 0
+    n_bins, bin_shift = c0.records_layout(nr, ng)
+    c0.close()
+    ctxs = [lime_amd.Context() for _ in range(world)]
+    recs, bases, bigs, tot_c, tot_u, edges = [], [], [], 0, 0, []
+    for r, (lo, hi, hh) in enumerate(shard_ranges(n, world)):
+        c = ctxs[r]
+        c.fused_records_dev(lcp[lo:], da[lo:], eb[lo:], hi - lo, hh - lo, hh == n, nr, ng, alpha)
+        s, rc = c.stats(); assert rc == 0, rc
+        tot_c += s.n_clusters; tot_u += s.n_updates; edges.append(s.edge)
+        R, base = c.records_get()
+        assert (R.n_bins, R.bin_shift) == (n_bins, bin_shift)
+        recs.append(R); bases.append(base)
+        bt = torch.empty(max(int(R.n_bigrecs), 1), dtype=torch.int64, device=dev)      # updates of clusters that left the scan (a few window-crossing ones)
+        if R.n_bigrecs:
+            assert lime_amd._lib.hip_memcpy_d2d(bt.data_ptr(), R.d_bigrecs, int(R.n_bigrecs) * 8) == 0
+        bigs.append(bt[:int(R.n_bigrecs)])
+    combine_edges(edges)
+    assert (tot_c, tot_u) == (sA.n_clusters, sA.n_updates)
+    del lcp, da, eb
+    per = (n_bins + world - 1) // world
+    n_big = sum(len(b) for b in bigs)
+    big_all = torch.cat(bigs) if n_big else torch.empty(1, dtype=torch.int64, device=dev)
+    for r in range(world):
+        b0 = min(per * r, n_bins); b1 = min(b0 + per, n_bins); nb = b1 - b0
+        cell_lo = b0 << bin_shift
+        block_bytes = max(min(b1 << bin_shift, tb) - cell_lo, 0)
+        srcoff = np.zeros((world, nb + 1), dtype=np.uint64)
+        total = sum(int(bases[s][b1] - bases[s][b0]) for s in range(world))
+        rx = torch.empty(max(total, 1), dtype=torch.int32, device=dev)
+        at = 0
+        for s in range(world):
+            sl = bases[s][b0:b1 + 1].astype(np.int64)
+            srcoff[s] = at + (sl - sl[0])
+            cnt = int(sl[-1] - sl[0])
+            if cnt:
+                assert lime_amd._lib.hip_memcpy_d2d(rx.data_ptr() + 4 * at, recs[s].d_recs + 4 * int(sl[0]), 4 * cnt) == 0
+            at += cnt
+        blk = torch.full((max(block_bytes, 16),), 0xAB, dtype=torch.uint8, device=dev)     # every byte must be written
+        ctxs[r].apply_records_dev(world, rx, srcoff, nb, bin_shift, big_all, n_big, cell_lo, block_bytes, blk)
+        torch.cuda.synchronize()
+        assert torch.equal(blk[:block_bytes], A[cell_lo:cell_lo + block_bytes]), r
+        del blk, rx
+    for c in ctxs:
+        c.close()
+
