@@ -40,7 +40,11 @@ constexpr uint32_t HT_EMPTY = 0xFFFFFFFFu;
 // on into their regions; k_apply builds each 64 KB region of the table in LDS from its records and writes it
 // out once
 constexpr uint32_t BIN_MAX = 3072;           // bins: one u32 counter each in the 12 KB of LDS the CAS slots use otherwise
-constexpr uint32_t REGION_SHIFT = 16;        // k_apply builds 2^16 = 64 KB of the table per workgroup
+#ifndef LIME_REGION_SHIFT
+#define LIME_REGION_SHIFT 16
+#endif
+constexpr uint32_t REGION_SHIFT = LIME_REGION_SHIFT;   // k_apply / k_apply_tiles build 2^REGION_SHIFT bytes of the table per workgroup (<= 16: the second level's records are 16-bit)
+static_assert(REGION_SHIFT >= 12 && REGION_SHIFT <= 16, "region offsets are 16-bit records");
 constexpr uint32_t BIN_ONE_LEVEL = 1024;     // tables of up to this many regions: one bin per region, no second level
 constexpr uint32_t BIN_TWO_LEVEL = 2048;     // larger tables: at most this many bins of 2^k regions each (while k allows); measured best of 256..2048 on configs[2]
 constexpr uint32_t BIN_SHIFT_MAX = 25;       // bin-relative cell offset + 7 bits of t must fit 32 bits

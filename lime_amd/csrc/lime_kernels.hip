@@ -2024,7 +2024,7 @@ __global__ __launch_bounds__(PART_WG) void k_sort_tiles(const uint32_t *recs, co
         part_scan(cnt, toff, f2, wsum);
 #pragma unroll
         for (uint32_t j = 0; j < PART_PER; ++j)
-            if (dr[j] != ~0u) stage[toff[dr[j] & 0xFFFu] + (dr[j] >> 12)] = (uint16_t)(val[j] & 0xFFFFu);
+            if (dr[j] != ~0u) stage[toff[dr[j] & 0xFFFu] + (dr[j] >> 12)] = (uint16_t)(val[j] & ((1u << REGION_SHIFT) - 1u));
         for (uint32_t i = tid; i <= f2; i += PART_WG)
             bidx[(size_t)i * n_rows + row] = (uint16_t)(i < f2 ? toff[i] : toff[f2 - 1u] + cnt[f2 - 1u]);
         __syncthreads();
@@ -2042,23 +2042,14 @@ __global__ __launch_bounds__(PART_WG) void k_sort_tiles(const uint32_t *recs, co
 // the other, four 16-bit records per lane and step from 8-byte-aligned loads; the loads of the next four runs are in
 // flight while four are added.
 __global__ __launch_bounds__(APPLY_WG) void k_apply_tiles(uint8_t *sim, size_t sim_bytes, const uint16_t *recs16, const uint32_t *tbase,
-                                                          const uint16_t *idx, uint32_t bin_shift)
+                                                          const uint16_t *idx, uint32_t bin_shift, uint32_t n_regions)
 {
     constexpr uint32_t RW = (1u << REGION_SHIFT) / 4u;           // words per region
     constexpr uint32_t NWV = APPLY_WG / 64, UR = 4;
     __shared__ uint4 reg4[RW / 4];
     uint32_t *reg = reinterpret_cast<uint32_t *>(reg4);
-    const uint32_t region = blockIdx.x, lane = lane_id(), wave = threadIdx.x >> 6;
-    const size_t reg_base = (size_t)region << REGION_SHIFT;      // grid = regions that start inside the table
-    const uint32_t f2 = 1u << (bin_shift - REGION_SHIFT), bin = region >> (bin_shift - REGION_SHIFT), sub = region & (f2 - 1u);
-    const uint32_t row0 = tbase[bin], n_rows = tbase[bin + 1] - row0;
-    const uint16_t *ia = idx + (size_t)row0 * (f2 + 1u) + (size_t)sub * n_rows, *ie = ia + n_rows;
-    // lane l reads the index entries of the l-th of the wave's tiles (the first 64 before the region is cleared: the
-    // loads fly meanwhile)
-    uint32_t a = 0, e = 0;
-    { const uint32_t t = wave + NWV * lane; if (t < n_rows) { a = ia[t]; e = ie[t]; } }
-    for (uint32_t i = threadIdx.x; i < RW / 4; i += APPLY_WG) reg4[i] = make_uint4(0u, 0u, 0u, 0u);
-    __syncthreads();
+    const uint32_t lane = lane_id(), wave = threadIdx.x >> 6;
+    const uint32_t f2 = 1u << (bin_shift - REGION_SHIFT);
     auto add = [&](uint32_t o) {                                  // one record: + 1 modulo 256 on byte o of the region
         const uint32_t sh = (o & 3u) * 8u;
         uint32_t *w = &reg[o >> 2];
@@ -2071,49 +2062,82 @@ __global__ __launch_bounds__(APPLY_WG) void k_apply_tiles(uint8_t *sim, size_t s
         }
     };
     struct Step { uint2 v[UR]; uint32_t fa[UR], fe[UR], q[UR]; const uint16_t *src[UR]; };
-    for (uint32_t outer = 0; outer < n_rows; outer += NWV * 64u) {
-        if (outer) { a = 0u; e = 0u; const uint32_t t = outer + wave + NWV * lane; if (t < n_rows) { a = ia[t]; e = ie[t]; } }
-        const uint32_t left = n_rows - outer;                      // tiles of this round: the wave's are wave, wave + NWV, ... < left
-        const uint32_t nl = left > wave ? ((left - wave + NWV - 1u) / NWV < 64u ? (left - wave + NWV - 1u) / NWV : 64u) : 0u;
-        auto load_step = [&](uint32_t l0, Step &s) {              // the first 256 records of the runs l0 .. l0 + UR of this wave
+    // A workgroup walks regions blockIdx.x, + gridDim.x, ... (two workgroups per CU).  What a region needs before its records
+    // can be read -- its bin's tile range, then its index entries -- is fetched while the region before it is worked on: a
+    // workgroup per region paid that chain of dependent loads per region (configs[2]: 76 k regions of 1.6 k records each).
+    uint32_t region = blockIdx.x;
+    if (region >= n_regions) return;
+    uint32_t row0 = tbase[region >> (bin_shift - REGION_SHIFT)], n_rows = tbase[(region >> (bin_shift - REGION_SHIFT)) + 1u] - row0;
+    uint32_t a = 0, e = 0;                                        // lane l: the index entries of tile wave + NWV * l of the region's bin
+    {
+        const uint16_t *ia = idx + (size_t)row0 * (f2 + 1u) + (size_t)(region & (f2 - 1u)) * n_rows;
+        const uint32_t t = wave + NWV * lane;
+        if (t < n_rows) { a = ia[t]; e = ia[n_rows + t]; }
+    }
+    for (;;) {
+        const uint32_t next = region + gridDim.x;
+        const bool more = next < n_regions;
+        uint32_t nrow0 = 0, nrow1 = 0;                            // the next region's tile range: needed only after this one's records
+        if (more) { nrow0 = tbase[next >> (bin_shift - REGION_SHIFT)]; nrow1 = tbase[(next >> (bin_shift - REGION_SHIFT)) + 1u]; }
+        const uint32_t sub = region & (f2 - 1u);
+        const uint16_t *ia = idx + (size_t)row0 * (f2 + 1u) + (size_t)sub * n_rows, *ie = ia + n_rows;
+        for (uint32_t i = threadIdx.x; i < RW / 4; i += APPLY_WG) reg4[i] = make_uint4(0u, 0u, 0u, 0u);
+        __syncthreads();
+        for (uint32_t outer = 0; outer < n_rows; outer += NWV * 64u) {
+            if (outer) { a = 0u; e = 0u; const uint32_t t = outer + wave + NWV * lane; if (t < n_rows) { a = ia[t]; e = ie[t]; } }
+            const uint32_t left = n_rows - outer;                  // tiles of this round: the wave's are wave, wave + NWV, ... < left
+            const uint32_t nl = left > wave ? ((left - wave + NWV - 1u) / NWV < 64u ? (left - wave + NWV - 1u) / NWV : 64u) : 0u;
+            auto load_step = [&](uint32_t l0, Step &s) {          // the first 256 records of the runs l0 .. l0 + UR of this wave
 #pragma unroll
-            for (uint32_t u = 0; u < UR; ++u) {
-                const uint32_t l = l0 + u;
-                s.fa[u] = l < nl ? rl32(a, l) : 0u; s.fe[u] = l < nl ? rl32(e, l) : 0u;
-                s.q[u] = (s.fa[u] >> 2) + lane;                   // this lane's group of four records
-                s.src[u] = recs16 + (size_t)(row0 + outer + wave + NWV * l) * PART_TILE;
-                s.v[u] = make_uint2(0u, 0u);
-                if (s.q[u] * 4u < s.fe[u]) s.v[u] = *reinterpret_cast<const uint2 *>(s.src[u] + (size_t)s.q[u] * 4u);
-            }
-        };
-        Step nxt;
-        if (nl) load_step(0u, nxt);
-        for (uint32_t l0 = 0; l0 < nl; l0 += UR) {
-            Step cur = nxt;
-            if (l0 + UR < nl) load_step(l0 + UR, nxt);            // the next runs' loads go out before these are added
+                for (uint32_t u = 0; u < UR; ++u) {
+                    const uint32_t l = l0 + u;
+                    s.fa[u] = l < nl ? rl32(a, l) : 0u; s.fe[u] = l < nl ? rl32(e, l) : 0u;
+                    s.q[u] = (s.fa[u] >> 2) + lane;               // this lane's group of four records
+                    s.src[u] = recs16 + (size_t)(row0 + outer + wave + NWV * l) * PART_TILE;
+                    s.v[u] = make_uint2(0u, 0u);
+                    if (s.q[u] * 4u < s.fe[u]) s.v[u] = *reinterpret_cast<const uint2 *>(s.src[u] + (size_t)s.q[u] * 4u);
+                }
+            };
+            Step nxt;
+            if (nl) load_step(0u, nxt);
+            for (uint32_t l0 = 0; l0 < nl; l0 += UR) {
+                Step cur = nxt;
+                if (l0 + UR < nl) load_step(l0 + UR, nxt);        // the next runs' loads go out before these are added
 #pragma unroll
-            for (uint32_t u = 0; u < UR; ++u) {
-                uint32_t q = cur.q[u];
-                uint2 w = cur.v[u];
-                const uint32_t fa = cur.fa[u], fe = cur.fe[u];
-                while (__ballot(q * 4u < fe)) {
-                    if (q * 4u < fe) {
-                        const uint32_t p = q * 4u;
-                        if (p >= fa) add(w.x & 0xFFFFu);
-                        if (p + 1u >= fa && p + 1u < fe) add(w.x >> 16);
-                        if (p + 2u >= fa && p + 2u < fe) add(w.y & 0xFFFFu);
-                        if (p + 3u >= fa && p + 3u < fe) add(w.y >> 16);
+                for (uint32_t u = 0; u < UR; ++u) {
+                    uint32_t q = cur.q[u];
+                    uint2 w = cur.v[u];
+                    const uint32_t fa = cur.fa[u], fe = cur.fe[u];
+                    while (__ballot(q * 4u < fe)) {
+                        if (q * 4u < fe) {
+                            const uint32_t p = q * 4u;
+                            if (p >= fa) add(w.x & 0xFFFFu);
+                            if (p + 1u >= fa && p + 1u < fe) add(w.x >> 16);
+                            if (p + 2u >= fa && p + 2u < fe) add(w.y & 0xFFFFu);
+                            if (p + 3u >= fa && p + 3u < fe) add(w.y >> 16);
+                        }
+                        q += 64u;                                 // (runs beyond 256 records: further steps, loaded here)
+                        if (q * 4u < fe) w = *reinterpret_cast<const uint2 *>(cur.src[u] + (size_t)q * 4u);
                     }
-                    q += 64u;                                     // (runs beyond 256 records: further steps, loaded here)
-                    if (q * 4u < fe) w = *reinterpret_cast<const uint2 *>(cur.src[u] + (size_t)q * 4u);
                 }
             }
         }
+        __syncthreads();
+        // the next region's index entries go out now and land while this region is written
+        uint32_t na = 0, ne = 0;
+        if (more) {
+            const uint32_t nn = nrow1 - nrow0, t = wave + NWV * lane;
+            const uint16_t *nia = idx + (size_t)nrow0 * (f2 + 1u) + (size_t)(next & (f2 - 1u)) * nn;
+            if (t < nn) { na = nia[t]; ne = nia[nn + t]; }
+        }
+        const size_t reg_base = (size_t)region << REGION_SHIFT;  // regions start inside the table
+        uint4 *dst = reinterpret_cast<uint4 *>(sim + reg_base);
+        const size_t left16 = (sim_bytes - reg_base) / 16u;      // sim_bytes is a multiple of 16
+        for (uint32_t i = threadIdx.x; i < RW / 4 && i < left16; i += APPLY_WG) dst[i] = reg4[i];
+        if (!more) break;
+        __syncthreads();                                          // (the region's LDS copy has been read: it may be cleared)
+        region = next; row0 = nrow0; n_rows = nrow1 - nrow0; a = na; e = ne;
     }
-    __syncthreads();
-    uint4 *dst = reinterpret_cast<uint4 *>(sim + reg_base);
-    const size_t left = (sim_bytes - reg_base) / 16u;            // sim_bytes is a multiple of 16
-    for (uint32_t i = threadIdx.x; i < RW / 4 && i < left; i += APPLY_WG) dst[i] = reg4[i];
 }
 
 // k_apply: one workgroup builds one 64 KB region of the table in LDS -- zero, add the region's records (exact
@@ -2539,8 +2563,13 @@ void launch_apply_by_tiles(uint8_t *sim, size_t sim_bytes, const uint32_t *recs,
 {
     hipLaunchKernelGGL(k_tile_bases, dim3(1), dim3(PART_WG), 0, st, binbase, n_bins, tbase);
     hipLaunchKernelGGL(k_sort_tiles, dim3(n_bins), dim3(PART_WG), 0, st, recs, binbase, bin_shift, tbase, idx, out16);
-    const uint32_t grid = (uint32_t)((sim_bytes + ((size_t)1 << REGION_SHIFT) - 1) >> REGION_SHIFT);
-    hipLaunchKernelGGL(k_apply_tiles, dim3(grid), dim3(APPLY_WG), 0, st, sim, sim_bytes, out16, tbase, idx, bin_shift);
+    const uint32_t n_regions = (uint32_t)((sim_bytes + ((size_t)1 << REGION_SHIFT) - 1) >> REGION_SHIFT);
+    static std::atomic<uint32_t> resident_of[MAX_DEV];           // workgroups that fit the device at once (two per CU: 64 KB of LDS each)
+    std::atomic<uint32_t> &slot = resident_of[cur_device()];
+    uint32_t resident = slot.load(std::memory_order_relaxed);
+    if (!resident) { resident = resident_blocks(k_apply_tiles, APPLY_WG); slot.store(resident, std::memory_order_relaxed); }
+    const uint32_t grid = n_regions < resident ? n_regions : resident;
+    hipLaunchKernelGGL(k_apply_tiles, dim3(grid ? grid : 1u), dim3(APPLY_WG), 0, st, sim, sim_bytes, out16, tbase, idx, bin_shift, n_regions);
 }
 uint64_t tiles_bound(uint64_t n_records, uint32_t n_bins) { return n_records / PART_TILE + n_bins; }
 uint32_t part_tile() { return PART_TILE; }
