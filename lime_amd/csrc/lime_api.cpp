@@ -79,7 +79,8 @@ struct lime_ctx {
     bool density_known = false; double density = 0.0;          // table updates per owned symbol of the last pass read back
     bool bin_levels_forced = false;
     uint32_t bin_one_level = BIN_ONE_LEVEL, bin_two_level = BIN_TWO_LEVEL;   // LIME_BIN_LEVELS="a,b" (tests: force the second level on small tables)
-    double pool_density = 0.20;             // records per owned symbol the pool is sized for (grows on LIME_FLAG_POOL_FULL)
+    double pool_density = 0.20;             // records per owned symbol the pool is sized for before a pass has been measured (grows on LIME_FLAG_POOL_FULL)
+    bool pool_density_fixed = false;        // set by LIME_POOL_DENSITY or by a repeated pass: sizing_density() then leaves it alone
     uint32_t scan_static_pct = 75;          // share of the scan's rounds of window chunks that go round-robin; the rest is handed out as workgroups get there (LIME_SCAN_STATIC_PCT: tests)
     uint32_t pool_slack = 512;              // + this many records per wave and sub-region (LIME_POOL_SLACK: tests make pools overflow)
     struct Last {                           // the last lime_fused_dev call, so that lime_get_stats can repeat it with a larger pool
@@ -152,7 +153,7 @@ extern "C" int lime_init(int device, lime_ctx **out)
         unsigned a1 = 0, a2 = 0;
         if (sscanf(s, "%u,%u", &a1, &a2) == 2 && a1 >= 1 && a2 >= 1 && a1 <= BIN_MAX && a2 <= BIN_MAX) { c->bin_one_level = a1; c->bin_two_level = a2; c->bin_levels_forced = true; }
     }
-    if (const char *s = getenv("LIME_POOL_DENSITY")) { const double v = atof(s); if (v > 0) c->pool_density = v; }   // tests: force a small pool
+    if (const char *s = getenv("LIME_POOL_DENSITY")) { const double v = atof(s); if (v > 0) { c->pool_density = v; c->pool_density_fixed = true; } }   // tests: force a small pool
     if (const char *s = getenv("LIME_SCAN_STATIC_PCT")) { const long v = atol(s); if (v >= 0 && v <= 100) c->scan_static_pct = (uint32_t)v; }
     if (const char *s = getenv("LIME_SECOND_LEVEL")) c->by_tiles = strcmp(s, "sweeps") != 0;
     if (const char *s = getenv("LIME_POOL_SLACK")) { const long v = atol(s); if (v >= 0) c->pool_slack = (uint32_t)v; }
@@ -314,15 +315,30 @@ static bool want_binned(const lime_ctx *c, uint64_t n_own, size_t sim_bytes, int
     if (c->upd_pref >= 0) return c->upd_pref == 1;
     if (n_own < (1u << 24)) return false;                 // short passes: the extra launches cost more than they save
     if (sim_bytes < (1u << 20)) return false;             // tiny tables: all updates would land in one or two bins
-    if (c->density_known) return c->density >= 0.06;
+    // Measured (tools/r03_big.sh, 0.03 updates per symbol, EBWT=1): a table the Infinity Cache holds takes the compare-and-swaps
+    // under the scan (configs[1], 50 MB: 0.24 ms against 0.3-0.4 binned); beyond it every update is a 64-byte request to
+    // HBM at ~20 G/s while a record costs the later kernels ~7 ps (10^10 symbols: 1 GB table 26.7 ms against 18.4 binned,
+    // configs[4]'s 10.3 GB table 31.5 against 20.8, configs[3]'s shape 8.3 against 7.6) -- worth ~0.3 ms of extra launches
+    // from about 5 million records on.
+    if (c->density_known) return sim_bytes > (256u << 20) ? c->density * (double)n_own >= 5e6 : c->density >= 0.06;
     return sim_bytes > (256u << 20);                      // nothing known yet: tables beyond the Infinity Cache
+}
+
+// records per owned symbol the pool of the next pass is sized for: what the last pass measured, with a margin (the waves'
+// shares differ: ensure_binned adds its own), once one has been read back; the default before that; and never below what
+// a repeated pass (pool too small) settled on
+static double sizing_density(const lime_ctx *c)
+{
+    if (c->pool_density_fixed || !c->density_known) return c->pool_density;
+    const double d = c->density * 1.25 + 0.002;
+    return d < c->pool_density ? d : c->pool_density;
 }
 
 static int ensure_binned(lime_ctx *c, uint64_t n_own, uint32_t n_waves, uint32_t n_prod, uint32_t n_bins, uint32_t bin_shift,
                          uint32_t n_sub, uint32_t *cap_w, hipStream_t st)
 {
     int rc;
-    const double per_wave = (double)n_own * c->pool_density / (double)n_waves;
+    const double per_wave = (double)n_own * sizing_density(c) / (double)n_waves;
     uint64_t cw = (((uint64_t)(per_wave * 1.35) + c->pool_slack) & ~15ull) + 16u;   // a multiple of 16 records: sub-regions start on a 64-byte line
     const size_t segs = (size_t)n_waves * n_sub;                          // every sub-region can take a wave's whole share (no assumption on how the cells spread)
     if (c->pool_cap / segs > cw) cw = (c->pool_cap / segs) & ~15ull;      // grow-only: use all of what is there
@@ -404,7 +420,7 @@ static int fused_dev_impl(lime_ctx *c, const uint32_t *d_lcp, const uint32_t *d_
         binned = true;
     }
     const uint32_t n_sub_want = (uint32_t)((sim_bytes + 0xFFFFFFFFull) >> 32);
-    if (binned && ((double)n_own * c->pool_density * 1.10 + 512.0 * 4096.0) * n_sub_want > 3.9e9) {   // more records than 32-bit positions hold: compare-and-swap path
+    if (binned && ((double)n_own * sizing_density(c) * 1.35 + 512.0 * 4096.0) * n_sub_want > 3.9e9) {   // more records than 32-bit positions hold: compare-and-swap path
         if (records_only) return fail(LIME_ERR_ARG, "lime_fused_records_dev: shard too long for 32-bit record positions (cut it in two)");
         binned = false;
     }
@@ -631,7 +647,8 @@ extern "C" int lime_get_stats(lime_ctx *c, lime_stats_t *out, void *stream)
         const int pref = c->upd_pref;
         if (attempt == 2 && !l.records_only) c->upd_pref = 0;
         const double need = (double)s.wave_records_max * (double)l.n_waves / (double)(l.n_own ? l.n_own : 1);
-        c->pool_density = need * 1.08 > c->pool_density * 1.5 ? need * 1.08 : c->pool_density * 1.5;
+        const double was = sizing_density(c);
+        c->pool_density = need * 1.08 > was * 1.5 ? need * 1.08 : was * 1.5; c->pool_density_fixed = true;
         const bool timing = c->timing; c->timing = false;
         rc = fused_dev_impl(c, l.lcp, l.da, l.ebwt, l.n_own, l.n_avail, l.eof, l.n_reads, l.n_refs, l.alpha, l.sim, l.zero_sim,
                             false, l.st, nullptr, false, l.records_only);
