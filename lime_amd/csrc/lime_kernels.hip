@@ -726,188 +726,10 @@ __device__ __forceinline__ uint32_t score_len2(LDS &L, const WgTables &T, UpdQue
     return hit ? 1u : 0u;
 }
 
-// Clusters of 2..4 symbols (the bulk), one lane per cluster, no loops.  `p` is the window
-// position of the cluster's head; its length and which of its symbols are reads come from the
-// window's head / read bytes; the 4 documents and ebwt bytes sit in registers.  Two equal
-// documents hand the cluster to the medium list (general routine there); otherwise each of the
-// 6 position pairs that joins a read with a genome scores 1 if their symbols are compatible.
-// Hits go straight into the update queue at slots from one wave prefix sum.
-template <int EBWT, typename LDS>
-__device__ __forceinline__ uint32_t score_small(LDS &L, const WgTables &T, UpdQueue &qu, uint32_t &n_dup, const ScanArgs &a,
-                                                bool on, uint32_t p, uint32_t len)
-{
-    const uint32_t kb = p >> 3, sh = p & 7u;
-    const uint32_t rbits = (uint32_t)L.rb[kb] | ((uint32_t)L.rb[kb + 1u] << 8);
-    const uint32_t rmask = (rbits >> sh) & ((1u << len) - 1u);
-    const uint32_t pl = T.pairlut[rmask | (((len - 1u) & 3u) << 4)];
-    uint32_t d[4], sy[4], cs[4];
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {
-        d[i] = L.da[p + i];
-        const uint32_t by = EBWT ? L.fl[p + i] : 0u;
-        sy[i] = EBWT ? T.symidx[by] : 0u;
-        cs[i] = EBWT ? T.compatb[by] : 0xFFFFu;          // same depth as symidx: one LDS round trip less
-    }
-    // positions past the cluster get values no document has (the API bounds n_reads + n_refs), so that
-    // the six equality tests need no length checks
-    d[2] = len > 2u ? d[2] : 0xFFFFFFFEu;
-    d[3] = len > 3u ? d[3] : 0xFFFFFFFFu;
-    const bool dup = on && ((d[0] == d[1]) | (d[0] == d[2]) | (d[0] == d[3]) | (d[1] == d[2]) | (d[1] == d[3]) | (d[2] == d[3]));
-    const uint32_t nflush = dup_push<EBWT>(L, n_dup, a, T, qu, dup, p, len);
-    uint32_t compat6 = 0;
-    {
-        int pi = 0;
-#pragma unroll
-        for (int i = 0; i < 4; ++i)
-#pragma unroll
-            for (int j = i + 1; j < 4; ++j, ++pi) compat6 |= ((cs[i] >> sy[j]) & 1u) << pi;
-    }
-    const uint32_t hits = (dup || !on) ? 0u : (pl & compat6 & 0x3Fu), rsel = pl >> 8;
-    const uint32_t nh = (uint32_t)__popc(hits);
-    const uint32_t incl = wave_incl_scan(nh), total = rl32(incl, 63);
-    while (qu.n + total > qu.cap) drain(qu, a);              // total <= 4 per lane = 256 <= cap
-    uint32_t slot = qu.n + incl - nh, bad = 0;
-    {
-        int pi = 0;
-#pragma unroll
-        for (int i = 0; i < 4; ++i)
-#pragma unroll
-            for (int j = i + 1; j < 4; ++j, ++pi) {
-                if ((hits >> pi) & 1u) {
-                    const bool ri = (rsel >> pi) & 1u;
-                    uint32_t gd = (ri ? d[j] : d[i]) - a.n_reads;
-                    if (gd >= a.n_refs) { bad = 1u; gd = 0u; }      // reported below; the result is void anyway
-                    qu.qr[slot] = ri ? d[i] : d[j];
-                    qu.qg[slot] = gd | (1u << T_SHIFT);
-                    ++slot;
-                }
-            }
-    }
-    if (__ballot(bad != 0u)) { if (bad) atomicOr(&cold(a).stats->flags, LIME_FLAG_DOCID); }
-    qu.n += total;
-    return nh + nflush;
-}
-
-// position pair (i < j) number t of a cluster of L symbols, rows i = 0.. of lengths L-1-i (L <= 16)
-__host__ __device__ __forceinline__ void tri_decode(uint32_t t, uint32_t L, uint32_t &i, uint32_t &j)
-{
-    const float b = (float)(2u * L - 1u);
-    uint32_t r = (uint32_t)((b - sqrtf(b * b - 8.0f * (float)t)) * 0.5f);
-    for (int k = 0; k < 3 && r > 0u && r * (2u * L - 1u - r) / 2u > t; ++k) --r;       // float root: off by one at most
-    for (int k = 0; k < 3 && r + 2u < L && (r + 1u) * (2u * L - 2u - r) / 2u <= t; ++k) ++r;
-    i = r; j = t - r * (2u * L - 1u - r) / 2u + r + 1u;
-}
-
-// Clusters of 5..SMALL_MAX symbols of the window (a few per window), scored by ROWS: every position
-// i of a listed cluster except its last goes to one lane, which compares it with the positions
-// j > i of the cluster (<= 15, all loads issued together).  Equal documents in a row mark the
-// cluster as repeated (-> list for the general kernel); otherwise a read x genome pair scores 1
-// if the two symbols are compatible.  Row -> cluster: clusters flag the slot of their first row
-// in the 64-row chunk, a ballot turns the flags into a mask, the popcount below the lane gives the
-// cluster.  A chunk normally holds all rows of the window: one pass; else a first pass over all
-// chunks settles the repeated-document marks before hits are emitted.
-template <int EBWT, typename LDS>
-__device__ __forceinline__ uint32_t score_medium(LDS &L, const WgTables &T, UpdQueue &qu, uint32_t &n_dup, const ScanArgs &a,
-                                                 uint32_t nM, uint64_t *ptm = nullptr)
-{
-#ifdef LIME_PHASE_TIMING
-    uint64_t pt_t = __builtin_readcyclecounter(); uint64_t *pt_acc = ptm;
-#endif
-    const uint32_t lane = lane_id();
-    const uint64_t lt = (1ull << lane) - 1ull, le = lt | (1ull << lane);
-    // lanes talk through these LDS bytes with no barrier in between: volatile, or the compiler
-    // (LDS address space: a volatile GENERIC pointer turns into flat accesses that wait for vmcnt)
-    // forwards a lane's own store to its later load and never sees the other lanes' stores
-    lds_vu8 *flag = (lds_vu8 *)L.m_flag, *dupf = (lds_vu8 *)L.m_dup;
-    uint32_t nupd = 0;
-    for (uint32_t c0 = 0; c0 < nM; c0 += 64u) {
-        const bool valid = c0 + lane < nM;
-        const uint32_t item = valid ? L.listM[c0 + lane] : 0u;
-        const uint32_t len = valid ? (item >> 12) + 1u : 0u;
-        const uint32_t nrow = valid ? len - 1u : 0u;
-        const uint32_t tincl = wave_incl_scan(nrow), tstart = tincl - nrow, ttotal = rl32(tincl, 63);
-        L.m_tstart[lane] = (uint16_t)tstart;
-        dupf[lane] = 0;
-#pragma unroll 1
-        for (int pass = ttotal <= 64u ? 1 : 0; pass < 2; ++pass) {
-#pragma unroll 1
-            for (uint32_t base = 0; base < ttotal; base += 64u) {
-                flag[lane] = 0;
-                if (valid && tstart >= base && tstart < base + 64u) flag[tstart - base] = 1;
-                const uint64_t M = __ballot(flag[lane] != 0);
-                const uint32_t cb = (uint32_t)__popcll(__ballot(valid && tstart < base));
-                const uint32_t t = base + lane;
-                const bool on = t < ttotal;
-                const uint32_t c = on ? cb + (uint32_t)__popcll(M & le) - 1u : 0u;
-                const uint32_t it = L.listM[c0 + c], p = it & 0xFFFu, cl = (it >> 12) + 1u;
-                const uint32_t i = on ? t - L.m_tstart[c] : 0u, q = p + i;
-                PT(0)
-                const uint32_t rem = on ? cl - 1u - i : 0u;                 // positions after i in the cluster
-                const uint32_t di = L.da[q];
-                const uint32_t ci = EBWT ? T.compatb[L.fl[q]] : 0xFFFFu;
-                // read bits of q .. q+15 from the staged mask bytes
-                const uint32_t kb = q >> 3;
-                const uint32_t rb16 = ((uint32_t)L.rb[kb] | ((uint32_t)L.rb[kb + 1u] << 8) | ((uint32_t)L.rb[kb + 2u] << 16)) >> (q & 7u);
-                const uint32_t ri = rb16 & 1u;
-                // bit k: position q+k holds the same document / a compatible symbol.  Positions past
-                // the cluster are read too (the arrays are padded) and masked afterwards.
-                uint32_t dupb = 0, cb16 = EBWT ? 0u : 0xFFFFu;
-#pragma unroll
-                for (int k0 = 1; k0 < (int)SMALL_MAX; k0 += 8) {      // positions 1..8 always (one batch of loads), 9..15 if any row needs them
-                    if (k0 == 1 || __ballot(rem >= (uint32_t)k0)) {   // wave-uniform
-#pragma unroll
-                        for (int k = k0; k < k0 + 8 && k < (int)SMALL_MAX; ++k) {
-                            dupb |= (uint32_t)(L.da[q + (uint32_t)k] == di) << k;
-                            if (EBWT) cb16 |= ((ci >> T.symidx[L.fl[q + (uint32_t)k]]) & 1u) << k;
-                        }
-                    }
-                }
-                const uint32_t vmask = (2u << rem) - 2u;                    // bits 1..rem
-                uint32_t hits = (ri ? ~rb16 : rb16) & cb16 & vmask;
-                if (on && (dupb & vmask)) dupf[c] = 1;
-                PT(1)
-                if (pass == 1) {
-                    if (!on || dupf[c]) hits = 0u;
-                    // hits -> update queue, at most 4 per lane and round, slots from one prefix sum
-                    while (__ballot(hits != 0u)) {
-                        const uint32_t nh = (uint32_t)__popc(hits), take = nh < 4u ? nh : 4u;
-                        const uint32_t incl = wave_incl_scan(take), tot = rl32(incl, 63);
-                        while (qu.n + tot > qu.cap) drain(qu, a);
-                        uint32_t slot = qu.n + incl - take, bad = 0;
-                        uint32_t djs[4];                             // the partners' documents: four loads issued together
-#pragma unroll
-                        for (int e = 0; e < 4; ++e) {
-                            const uint32_t k = hits ? (uint32_t)__builtin_ctz(hits) : 0u;
-                            hits &= hits - 1u;
-                            djs[e] = L.da[q + k];
-                        }
-#pragma unroll
-                        for (int e = 0; e < 4; ++e)
-                            if ((uint32_t)e < take) {
-                                const uint32_t dj = djs[e];
-                                uint32_t gd = (ri ? dj : di) - a.n_reads;
-                                if (gd >= a.n_refs) { bad = 1u; gd = 0u; }   // reported below; the result is void anyway
-                                qu.qr[slot] = ri ? di : dj; qu.qg[slot] = gd | (1u << T_SHIFT);
-                                ++slot;
-                            }
-                        if (__ballot(bad != 0u)) { if (bad) atomicOr(&cold(a).stats->flags, LIME_FLAG_DOCID); }
-                        qu.n += tot; nupd += take;
-                    }
-                }
-                PT(2)
-            }
-        }
-        nupd += dup_push<EBWT>(L, n_dup, a, T, qu, valid && dupf[lane] != 0, item & 0xFFFu, len);
-        PT(3)
-    }
-    return nupd;
-}
-
-
 // =========================================================================================
 // Round 3 back end of the scan: the same results with about a third of the vector instructions.
 // (PMC, configs[2], per 1024-position window, round 2: staging 131, chunk acceptance 82, cluster list 159,
-// 2-4-symbol round 214, rows 212 vector instructions; the six predicated emission blocks of score_small alone
+// 2-4-symbol round 214, rows 212 vector instructions; the six predicated emission blocks of the 2-4-symbol routine alone
 // compiled to 26 each.)
 // =========================================================================================
 
