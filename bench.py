@@ -44,6 +44,9 @@ WORKLOADS = {
     "c2": dict(n=100_000_000, nr=100_000, ng=500, ebwt=1, mode=0, what="BASELINE.json configs[1]"),
     "c2_clustered": dict(n=100_000_000, nr=100_000, ng=500, ebwt=1, mode=1, what="configs[1] shape, clustered generator (SURVEY 8d)"),
     "n1e10": dict(n=10_000_000_000, nr=1_000_000, ng=1000, ebwt=0, mode=0, what="north_star scaling series, N = 10^10"),
+    # the reference's default build (EBWT=1) at the shapes of configs[3] and configs[4], on one GPU (synthetic generator: the real collections are not in the image)
+    "c4_shape": dict(n=2_000_000_000, nr=20_249_373, ng=930, ebwt=1, mode=0, what="shape of BASELINE.json configs[3] (setB2: 20 249 373 reads x 930 genomes), 2*10^9 symbols on one GPU"),
+    "c5_shape": dict(n=10_000_000_000, nr=3_000_000, ng=3423, ebwt=1, mode=0, what="shape of BASELINE.json configs[4] (3*10^6 reads x 3423 genomes), 10^10 symbols on one GPU"),
     # text-derived statistics: tests/golden/text_example.npz (2000 example reads x 3 surrogate genomes, 442 003 symbols, 49.5 % of
     # them in clusters, 0.24 table updates per symbol) laid side by side 226 times, every copy with its own reads and genomes
     "text_tiled": dict(n=226 * 442_003, nr=226 * 2000, ng=226 * 3, ebwt=1, mode=-1, tiled=226,
@@ -339,18 +342,19 @@ def main():
             out["cpu_baseline"] = cpu_baseline(wl, r["lcp"], r["da"], r["eb"], r["n_own"], args.cpu_sample)
         except Exception as e:   # a missing baseline must not hide the GPU number
             out["cpu_baseline"] = {"value": None, "unit": "symbols/s", "cores": os.cpu_count(), "kind": "port", "sample": f"failed: {e}"}
+    first_exchange = r["exchange"]
     del r
     torch.cuda.empty_cache()
 
     if not args.no_also:
         also = {}
         if world == 1:
-            for name in ("c2", "c2_clustered", "text_tiled", "n1e10"):
+            for name in ("c2", "c2_clustered", "text_tiled", "n1e10", "c5_shape", "c4_shape"):
                 if name == wname:
                     continue
                 w2 = WORKLOADS[name]
                 try:
-                    k = max(3, args.steps // 2) if name == "n1e10" else max(10, args.steps)
+                    k = max(3, args.steps // 2) if name == "n1e10" else 3 if name in ("c5_shape", "c4_shape") else max(10, args.steps)
                     r2 = run_pass_series(torch, lime_amd, ldist, w2, w2["n"], k, 2, 1, 0, dev, None, overlap=False)
                     also[name] = summarize(w2, r2, w2["n"], k)
                     del r2
@@ -363,7 +367,7 @@ def main():
             also["overlapped"] = {"what": "the same series with the exchange of step k under the scan of step k+1 (two table buffers)",
                                   "value": n_total * args.steps / dt2, "ms_per_step": dt2 / args.steps * 1e3}
             del r2
-            if os.environ.get("LIME_BENCH_SPARSE") == "1" and r["exchange"] == "dense":
+            if os.environ.get("LIME_BENCH_SPARSE") == "1" and first_exchange == "dense":
                 r3 = run_pass_series(torch, lime_amd, ldist, wl, n_total, args.steps, args.warmup, world, rank, dev, comm, overlap=False, exchange="sparse")
                 dt3 = comm.max_float(r3["dt"])
                 also["sparse_exchange"] = {"what": "the same series with the owner-partitioned exchange of update records instead of the dense reduce-scatter",

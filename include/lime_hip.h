@@ -67,6 +67,7 @@ typedef struct {
 #define LIME_FLAG_BADCLUSTER 8u
 #define LIME_FLAG_OVERFLOW 16u   /* an internal cluster list was too small (cannot happen with the default sizing) */
 #define LIME_FLAG_POOL_FULL 32u  /* binned table updates: the record pool was too small; lime_get_stats repeats the pass */
+#define LIME_FLAG_INTERNAL 64u   /* a device-side invariant did not hold (the scan's window hand-out): the pass is invalid, LIME_ERR_HIP */
 
 /* Edge word of a shard (lime_stats_t.edge): what the host needs to decide about a run that crosses shard borders
  * and is longer than the read-ahead halo.  LEAD_*: the positions before the shard's first cluster head (they belong

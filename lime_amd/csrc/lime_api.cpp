@@ -82,6 +82,7 @@ struct lime_ctx {
     double pool_density = 0.20;             // records per owned symbol the pool is sized for before a pass has been measured (grows on LIME_FLAG_POOL_FULL)
     bool pool_density_fixed = false;        // set by LIME_POOL_DENSITY or by a repeated pass: sizing_density() then leaves it alone
     uint32_t scan_static_pct = 75;          // share of the scan's rounds of window chunks that go round-robin; the rest is handed out as workgroups get there (LIME_SCAN_STATIC_PCT: tests)
+    uint32_t part_split = 4;                // producers (of k_part) per scan workgroup at most (LIME_PART_SPLIT: comparison runs)
     uint32_t pool_slack = 512;              // + this many records per wave and sub-region (LIME_POOL_SLACK: tests make pools overflow)
     struct Last {                           // the last lime_fused_dev call, so that lime_get_stats can repeat it with a larger pool
         bool valid = false, binned = false;
@@ -156,6 +157,7 @@ extern "C" int lime_init(int device, lime_ctx **out)
     if (const char *s = getenv("LIME_POOL_DENSITY")) { const double v = atof(s); if (v > 0) { c->pool_density = v; c->pool_density_fixed = true; } }   // tests: force a small pool
     if (const char *s = getenv("LIME_SCAN_STATIC_PCT")) { const long v = atol(s); if (v >= 0 && v <= 100) c->scan_static_pct = (uint32_t)v; }
     if (const char *s = getenv("LIME_SECOND_LEVEL")) c->by_tiles = strcmp(s, "sweeps") != 0;
+    if (const char *s = getenv("LIME_PART_SPLIT")) { const long v = atol(s); if (v >= 1 && v <= 16) c->part_split = (uint32_t)v; }
     if (const char *s = getenv("LIME_POOL_SLACK")) { const long v = atol(s); if (v >= 0) c->pool_slack = (uint32_t)v; }
     if (const char *s = getenv("LIME_MAX_BLOCKS")) { long v = atol(s); if (v > 0) c->max_blocks = (uint32_t)v; }
     *out = c;
@@ -253,6 +255,7 @@ static ScanArgs base_args(lime_ctx *c, const uint32_t *lcp, const uint32_t *da, 
 
 static int flags_to_rc(uint32_t flags)
 {
+    if (flags & LIME_FLAG_INTERNAL) return fail(LIME_ERR_HIP, "the scan's window hand-out failed (a wave lost its chunk): the pass is invalid");
     if (flags & LIME_FLAG_BADCLUSTER) return fail(LIME_ERR_ARG, "a cluster record lies outside the arrays");
     if (flags & LIME_FLAG_OVERFLOW) return fail(LIME_ERR_NOMEM, "internal cluster list overflow");
     if (flags & LIME_FLAG_POOL_FULL) return fail(LIME_ERR_NOMEM, "update record pool too small (the pass could not be repeated)");
@@ -327,6 +330,20 @@ static bool want_binned(const lime_ctx *c, uint64_t n_own, size_t sim_bytes, int
 // records per owned symbol the pool of the next pass is sized for: what the last pass measured, with a margin (the waves'
 // shares differ: ensure_binned adds its own), once one has been read back; the default before that; and never below what
 // a repeated pass (pool too small) settled on
+// waves of a scan workgroup that count their records together = one producer of k_part: as few as the LDS histogram allows
+// (its BIN_MAX counters are shared by the workgroup's producers), so that the partition runs several workgroups per CU
+static uint32_t part_prod_waves(const lime_ctx *c, int ebwt, uint32_t n_bins)
+{
+    const uint32_t wpw = scan_waves_per_wg(ebwt, 0);
+    uint32_t best = wpw;
+    for (uint32_t pw = wpw; pw >= 1u; --pw) {
+        if (wpw % pw) continue;
+        const uint32_t h = wpw / pw;
+        if (h <= c->part_split && (uint64_t)h * n_bins <= BIN_MAX) best = pw;
+    }
+    return best;
+}
+
 static double sizing_density(const lime_ctx *c)
 {
     if (c->pool_density_fixed || !c->density_known) return c->pool_density;
@@ -424,12 +441,14 @@ static int fused_dev_impl(lime_ctx *c, const uint32_t *d_lcp, const uint32_t *d_
         if (records_only) return fail(LIME_ERR_ARG, "lime_fused_records_dev: shard too long for 32-bit record positions (cut it in two)");
         binned = false;
     }
-    uint32_t grid = 0, cap_w = 0, n_bins = 0, bin_shift = REGION_SHIFT, n_sub = 1;
+    uint32_t grid = 0, cap_w = 0, n_bins = 0, bin_shift = REGION_SHIFT, n_sub = 1, prod_waves = 0, n_prod = 0;
     if (binned) {
         grid = scan_grid(ebwt, 0, 1, n_tiles, c->max_blocks);
         bin_layout(c, sim_bytes, &n_bins, &bin_shift);
         n_sub = (uint32_t)((sim_bytes + 0xFFFFFFFFull) >> 32);
-        if ((rc = ensure_binned(c, n_own, grid * scan_waves_per_wg(ebwt, 0), grid, n_bins, bin_shift, n_sub, &cap_w, st))) return rc;
+        prod_waves = part_prod_waves(c, ebwt, n_bins);
+        n_prod = grid * (scan_waves_per_wg(ebwt, 0) / prod_waves);
+        if ((rc = ensure_binned(c, n_own, grid * scan_waves_per_wg(ebwt, 0), n_prod, n_bins, bin_shift, n_sub, &cap_w, st))) return rc;
     }
     if ((rc = timing_mark(c, st))) return rc;
     if (keep_stats) {
@@ -453,7 +472,7 @@ static int fused_dev_impl(lime_ctx *c, const uint32_t *d_lcp, const uint32_t *d_
     if (d_edge) a.edge = d_edge;                          // a chunk of a stream: its own (cleared) word
     if (binned) {
         a.upd_mode = 1; a.pool = c->d_pool; a.cap_w = cap_w; a.n_sub = n_sub; a.wave_cnt = c->d_wave_cnt; a.counts = c->d_counts;
-        a.n_bins = n_bins; a.bin_shift = bin_shift; a.prod_waves = scan_waves_per_wg(ebwt, 0);
+        a.n_bins = n_bins; a.bin_shift = bin_shift; a.prod_waves = prod_waves;
         a.sub_rb = 0xFFFFFFFFu; a.sub_gb = 0u;
         if (n_sub == 2) { a.sub_rb = (uint32_t)((1ull << 32) / n_refs); a.sub_gb = (uint32_t)((1ull << 32) - (uint64_t)a.sub_rb * n_refs); }
     }
@@ -463,9 +482,9 @@ static int fused_dev_impl(lime_ctx *c, const uint32_t *d_lcp, const uint32_t *d_
     if ((rc = timing_mark(c, st))) return rc;
     launch_resolve(0, a, st);
     if (binned && !c->ablate) {                          // (timing experiments cut the scan short: nothing to partition)
-        launch_bin_rowscan(c->d_counts, c->d_totals, n_bins, grid, st);
+        launch_bin_rowscan(c->d_counts, c->d_totals, n_bins, n_prod, st);
         launch_scan_tiles(c->d_totals, c->d_binbase, n_bins, reinterpret_cast<unsigned long long *>(c->d_binbase + n_bins), st);
-        launch_part(a, grid, c->d_binbase, c->d_recs, st);
+        launch_part(a, n_prod, c->d_binbase, c->d_recs, st);
         if (records_only) {
             // the records grouped by bin are the result: the owners of the bins build the table (lime_apply_records_dev)
         } else if (bin_shift > REGION_SHIFT && c->by_tiles) {      // second level tile by tile into the (by now free) pool, regions from the tiles' runs

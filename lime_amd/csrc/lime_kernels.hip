@@ -333,6 +333,7 @@ __device__ __forceinline__ void drain_lines(UpdQueue &q, const ScanArgs &a, bool
     const ScanArgs &ca = cold(a);                                 // the fields a drain needs are loaded here, not held through the window loop
     const uint32_t cap_w = ca.cap_w, bin_shift = ca.bin_shift, n_sub = ca.n_sub, sub_rb = ca.sub_rb, sub_gb = ca.sub_gb, n_refs = ca.n_refs;
     uint32_t f0 = (uint32_t)__builtin_amdgcn_readfirstlane((int)q.lfill[0]), f1 = (uint32_t)__builtin_amdgcn_readfirstlane((int)q.lfill[1]);
+    const uint32_t hoff = (uint32_t)__builtin_amdgcn_readfirstlane((int)q.sub_n[MAX_SUB]);
     auto flush = [&](uint32_t sub, uint32_t &f, uint32_t keep_mask) {      // keep_mask = 15: whole lines only; 0: everything
         const uint32_t nl = f & ~keep_mask;
         if (!nl) return;
@@ -342,7 +343,7 @@ __device__ __forceinline__ void drain_lines(UpdQueue &q, const ScanArgs &a, bool
         const uint32_t slot = base + lane;
         if (lane < nl && slot < cap_w && !ABL(7)) {               // a full sub-region only counts (sub_n): the pass is repeated with a larger pool
             const uint32_t bin = n_sub == 1u ? rec >> bin_shift : (rec >> bin_shift) | (sub << (32u - bin_shift));
-            atomicAdd(&q.hist[bin], 1u);                          // the histogram counts exactly the records that are stored
+            atomicAdd(&q.hist[hoff + bin], 1u);                   // the histogram counts exactly the records that are stored
             if (!ABL(6)) __builtin_nontemporal_store(rec, q.out + (size_t)sub * cap_w + slot);
         }
         const uint32_t rem = f - nl;
@@ -391,6 +392,7 @@ __device__ __forceinline__ void drain_bin(UpdQueue &q, const ScanArgs &a)
     const uint32_t lane = lane_id();
     const ScanArgs &ca = cold(a);
     const uint32_t n = q.n, n_sub = ca.n_sub, cap_w = ca.cap_w, n_refs = ca.n_refs, bin_shift = ca.bin_shift;
+    const uint32_t hoff = (uint32_t)__builtin_amdgcn_readfirstlane((int)q.sub_n[MAX_SUB]);
     for (uint32_t k0 = 0; k0 < n; k0 += 64u) {
         const uint32_t k = k0 + lane;
         const bool on = k < n;
@@ -410,7 +412,7 @@ __device__ __forceinline__ void drain_bin(UpdQueue &q, const ScanArgs &a)
                 const uint32_t base = q.sub_n[sub];               // LDS, one address: a broadcast read
                 const uint32_t slot = base + rank_in(m);
                 if (mine && slot < cap_w && !ABL(7)) {            // a full sub-region only counts (sub_n): the pass is repeated with a larger pool
-                    atomicAdd(&q.hist[(uint32_t)(cell >> bin_shift)], 1u);     // the histogram counts exactly the records that are stored
+                    atomicAdd(&q.hist[hoff + (uint32_t)(cell >> bin_shift)], 1u);     // the histogram counts exactly the records that are stored
                     if (!ABL(6)) __builtin_nontemporal_store((uint32_t)cell, q.out + (size_t)sub * cap_w + slot);
                 }
                 if (lane == 0) q.sub_n[sub] = base + (uint32_t)__popcll(m);
@@ -933,7 +935,7 @@ struct alignas(16) ScanLdsT {
     uint16_t listM[WIN / 2];
     uint16_t m_tstart[64];                   // the round's clusters of 9..SMALL_MAX symbols (position | (len-1) << 12)
     uint32_t q_read[QCAP_SCAN], q_gen[QCAP_SCAN];
-    uint32_t sub_n[MAX_SUB];                 // binned updates: records in each of the wave's sub-regions
+    uint32_t sub_n[MAX_SUB + 1];             // binned updates: records in each of the wave's sub-regions; [MAX_SUB]: offset of the wave's producer group in the workgroup's bin histogram
     uint32_t lfill[2], lbuf[BIN ? 2 * LBUF : 2];   // records waiting for their 64-byte line (drain_lines)
     uint32_t g_doc[DUP_SLOTS][SMALL_MAX];
     uint8_t g_sym[EBWT ? DUP_SLOTS : 1][SMALL_MAX], g_len[DUP_SLOTS];
@@ -1044,10 +1046,13 @@ __global__ __launch_bounds__(ScanCfg<EBWT>::wg) __attribute__((amdgpu_waves_per_
     const uint32_t wave_gid = blockIdx.x * (SCANK_WG / 64) + wave;
     qu.binned = binned;
     if (binned) {
+        // the workgroup's waves count their records in groups of prod_waves: every group is one "producer" of k_part (more, smaller
+        // producers = more partition workgroups per CU); the groups' histograms lie one after the other
         qu.out = cold(a).pool + (size_t)wave_gid * cold(a).n_sub * cold(a).cap_w; qu.hist = fslots; qu.sub_n = (lds_vu32 *)L.sub_n;
         qu.lbuf = L.lbuf; qu.lfill = (lds_vu32 *)L.lfill;
         if (lane < MAX_SUB) L.sub_n[lane] = 0u;
         if (lane < 2u) L.lfill[lane] = 0u;
+        if (lane == 0u) L.sub_n[MAX_SUB] = (wave / cold(a).prod_waves) * cold(a).n_bins;   // where this wave's group counts (read back per drain: held in a register it costs the loop an SGPR)
     }
     // binned mode, end of a wave: its record count; the workgroup's last wave writes the bin histogram
     auto finish_binned = [&]() {
@@ -1067,7 +1072,11 @@ __global__ __launch_bounds__(ScanCfg<EBWT>::wg) __attribute__((amdgpu_waves_per_
         old = (uint32_t)__builtin_amdgcn_readfirstlane((int)old);
         if (old == SCANK_WG / 64 - 1) {
             __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
-            for (uint32_t b = lane; b < cold(a).n_bins; b += 64u) cold(a).counts[(size_t)b * gridDim.x + blockIdx.x] = qu.hist[b];
+            const uint32_t nb = cold(a).n_bins, H = (uint32_t)(SCANK_WG / 64) / cold(a).prod_waves, np = gridDim.x * H;
+            for (uint32_t i = lane; i < nb * H; i += 64u) {
+                const uint32_t h = i / nb, b = i - h * nb;
+                cold(a).counts[(size_t)b * np + blockIdx.x * H + h] = fslots[i];
+            }
         }
     };
     // The workgroup takes chunks of its wave count of consecutive windows and its waves draw the windows of those chunks
@@ -1084,8 +1093,22 @@ __global__ __launch_bounds__(ScanCfg<EBWT>::wg) __attribute__((amdgpu_waves_per_
         const uint32_t k = i / WPW, j = i % WPW, ks = (EBWT ? cold(a) : a).n_static;
         uint32_t chunk = k * gridDim.x + blockIdx.x;
         if (k >= ks) {
+            // slot k & 15 carries the tags k + 1 - 16 (or 0), k + 1, k + 1 + 16, ... in turn.  A wave that finds a LATER tag than its own was
+            // parked, between its draw and this read, while its workgroup went through 16 more chunks: its chunk's number is gone.
+            // Practically out of reach (every other wave of the workgroup would have to draw 16 windows meanwhile), but a spin
+            // without an exit is not: such a wave -- or one that has polled for seconds -- flags the pass as failed and stops.
             uint64_t v;
-            while ((uint32_t)((v = __hip_atomic_load(&wg_slot[k & 15u], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP)) >> 32) != k + 1u) __builtin_amdgcn_s_sleep(2);
+            uint32_t spins = 0;
+            for (;;) {
+                v = __hip_atomic_load(&wg_slot[k & 15u], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                const uint32_t tag = (uint32_t)(v >> 32);
+                if (tag == k + 1u) break;
+                if (tag > k + 1u || ++spins > (1u << 24)) {
+                    if (lane == 0) atomicOr(&cold(a).stats->flags, LIME_FLAG_INTERNAL);
+                    return NONE32;                     // >= n_win: the wave ends
+                }
+                __builtin_amdgcn_s_sleep(2);
+            }
             chunk = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)v);
         }
         // (after chunk k is known: the workgroup's fetches follow each other, so its chunks ascend and a wave that draws a
