@@ -92,6 +92,12 @@ int load_rccl()
 struct lime_comm {
     ncclComm_t comm = nullptr;
     int rank = 0, world = 1, device = 0;
+    // lime_comm_exchange_records: grow-only buffers, kept for the life of the communicator (an exchange is part of every timed
+    // step: nothing is allocated or freed inside it once the sizes have settled)
+    uint64_t *d_rows = nullptr, *h_rows = nullptr; size_t rows_cap = 0;       // the ranks' gathered rows (+ this rank's own), device and pinned host
+    uint32_t *d_rx = nullptr; size_t rx_cap = 0;                             // records received for this rank's bins
+    uint64_t *d_big = nullptr, *d_pad = nullptr; size_t big_cap = 0;          // all ranks' long-cluster records, padded to big_cap each; this rank's padded list
+    uint64_t *d_st2 = nullptr, *h_st2 = nullptr;                              // second agreement (a rank had to grow a buffer): one word per rank
 };
 
 extern "C" const char *lime_comm_error(void) { return g_comm_err.c_str(); }
@@ -126,6 +132,10 @@ extern "C" int lime_comm_init(const uint8_t id[LIME_COMM_ID_BYTES], int rank, in
 extern "C" void lime_comm_destroy(lime_comm *c)
 {
     if (!c) return;
+    (void)hipSetDevice(c->device);
+    (void)hipDeviceSynchronize();
+    (void)hipFree(c->d_rows); (void)hipHostFree(c->h_rows); (void)hipFree(c->d_rx); (void)hipFree(c->d_big); (void)hipFree(c->d_pad);
+    (void)hipFree(c->d_st2); (void)hipHostFree(c->h_st2);
     if (c->comm && g_rccl.CommDestroy) (void)g_rccl.CommDestroy(c->comm);
     delete c;
 }
@@ -165,8 +175,27 @@ extern "C" int lime_comm_combine_counters(lime_comm *c, uint64_t *d_sum_max, voi
 // slice of records of those bins (ncclSend / ncclRecv inside one group, after an all-gather of the ranks' bin bases) and
 // all ranks' long-cluster records (all-gather), and builds bytes [cell_lo, cell_lo + block_bytes) of the table in d_block
 // (capacity: per << bin_shift bytes).  About 4 bytes per update cross xGMI instead of T (G-1)/G, and a rank writes T/G
-// bytes of table instead of T.  Synchronises `stream` (the slice sizes size the receive buffer).
-namespace { struct ExBuf { void *p = nullptr; ~ExBuf() { if (p) (void)hipFree(p); } }; }
+// bytes of table instead of T.
+// A COLLECTIVE: every rank enters the same RCCL calls or none.  What a rank finds wrong locally (block too small, records of
+// another table shape, a long-cluster list that overflowed) travels as a status word in the row that is gathered anyway, and
+// all ranks return the same error together; the row also carries the rank's buffer capacities, so that every rank knows
+// whether ANY rank has to grow a buffer -- only then a second one-word agreement follows the allocations.  Once the sizes
+// have settled an exchange allocates nothing and synchronises the stream ONCE (the slice sizes have to reach the host).
+int lime_internal_records_peek(lime_ctx *c, lime_records_t *out, const uint32_t **d_bigrec_n, uint32_t *bigrec_cap);   // lime_api.cpp: no synchronisation
+
+namespace {
+template <typename T> int grow_dev(T *&p, size_t &cap, size_t want)
+{
+    if (want <= cap) return LIME_OK;
+    T *q = nullptr;
+    const size_t n = want + want / 4;
+    hipError_t e = hipMalloc(&q, n * sizeof(T));
+    if (e != hipSuccess) return cfail(e == hipErrorOutOfMemory ? LIME_ERR_NOMEM : LIME_ERR_HIP, "hipMalloc of %zu bytes: %s", n * sizeof(T), hipGetErrorString(e));
+    (void)hipFree(p);
+    p = q; cap = n;
+    return LIME_OK;
+}
+}
 
 extern "C" int lime_comm_exchange_records(lime_comm *c, lime_ctx *ctx, uint32_t n_reads, uint32_t n_refs, uint8_t *d_block,
                                           size_t block_cap, uint64_t *cell_lo, uint64_t *block_bytes, void *stream)
@@ -175,65 +204,115 @@ extern "C" int lime_comm_exchange_records(lime_comm *c, lime_ctx *ctx, uint32_t 
     hipStream_t st = (hipStream_t)stream;
     const int W = c->world, me = c->rank;
     uint32_t n_bins = 0, bin_shift = 0;
+    // ---- local checks: their outcome is this rank's status word, not a return (the others would wait in the all-gather).
+    // The layout is a pure function of the table's shape: it fails on every rank or on none.
     int rc = lime_records_layout(ctx, n_reads, n_refs, &n_bins, &bin_shift);
     if (rc) return cfail(rc, "%s", lime_last_error());
     const size_t sim_bytes = lime_sim_bytes(n_reads, n_refs);
     const uint32_t per = (n_bins + (uint32_t)W - 1u) / (uint32_t)W;
-    const uint32_t b0 = per * (uint32_t)me < n_bins ? per * (uint32_t)me : n_bins, b1 = b0 + per < n_bins ? b0 + per : n_bins, nb = b1 - b0;
+    auto first_bin = [&](int p) { return per * (uint32_t)p < n_bins ? per * (uint32_t)p : n_bins; };
+    const uint32_t b0 = first_bin(me), b1 = b0 + per < n_bins ? b0 + per : n_bins, nb = b1 - b0;
     *cell_lo = (uint64_t)b0 << bin_shift;
     const uint64_t hi = ((uint64_t)b1 << bin_shift) < sim_bytes ? ((uint64_t)b1 << bin_shift) : sim_bytes;
     *block_bytes = hi > *cell_lo ? hi - *cell_lo : 0;
-    if (*block_bytes > block_cap) return cfail(LIME_ERR_ARG, "lime_comm_exchange_records: block of %llu bytes, room for %zu", (unsigned long long)*block_bytes, block_cap);
-    // my records and their bin bases; everybody's bin bases (+ the long clusters' record counts as one more word)
-    std::vector<uint64_t> base((size_t)n_bins + 2);
-    lime_records_t R;
-    if ((rc = lime_records_get(ctx, &R, base.data(), st))) return cfail(rc, "%s", lime_last_error());
-    if (R.n_bins != n_bins || R.bin_shift != bin_shift) return cfail(LIME_ERR_ARG, "lime_comm_exchange_records: the ctx holds records of another table shape");
-    base[(size_t)n_bins + 1] = R.n_bigrecs;
-    const size_t row = (size_t)n_bins + 2;
-    ExBuf d_all; HIP_TRYC(hipMalloc(&d_all.p, row * sizeof(uint64_t) * ((size_t)W + 1)));
-    uint64_t *d_mine = (uint64_t *)d_all.p + row * (size_t)W;
-    HIP_TRYC(hipMemcpyAsync(d_mine, base.data(), row * sizeof(uint64_t), hipMemcpyHostToDevice, st));
-    NCCL_TRY(g_rccl.AllGather(d_mine, d_all.p, row, nccl_Uint64, c->comm, st));
-    std::vector<uint64_t> all(row * (size_t)W);
-    HIP_TRYC(hipMemcpyAsync(all.data(), d_all.p, all.size() * sizeof(uint64_t), hipMemcpyDeviceToHost, st));
-    HIP_TRYC(hipStreamSynchronize(st));
-    // what I receive: source s's records of my bins, one source after the other
-    std::vector<uint64_t> srcoff((size_t)W * (nb + 1));
-    uint64_t rx_total = 0, big_total = 0, big_max = 0;
+    uint64_t status = 0;
+    std::string local_err;
+    if (*block_bytes > block_cap) { status = (uint64_t)(uint32_t)(-LIME_ERR_ARG); local_err = "block of " + std::to_string(*block_bytes) + " bytes, room for " + std::to_string(block_cap); }
+    lime_records_t R; const uint32_t *d_bigrec_n = nullptr; uint32_t bigrec_cap = 0;
+    rc = lime_internal_records_peek(ctx, &R, &d_bigrec_n, &bigrec_cap);
+    if (rc && !status) { status = (uint64_t)(uint32_t)(-rc); local_err = lime_last_error(); }
+    if (!rc && !status && (R.n_bins != n_bins || R.bin_shift != bin_shift)) { status = (uint64_t)(uint32_t)(-LIME_ERR_ARG); local_err = "the ctx holds records of another table shape"; }
+    // ---- the row: bin bases [0 .. n_bins], long-cluster records, their list's capacity, status, receive capacities
+    const size_t ROW = (size_t)n_bins + 6;
+    enum { W_NBIG = 1, W_BIGCAP = 2, W_STATUS = 3, W_RXCAP = 4, W_BIGBUF = 5 };       // offsets behind the n_bins + 1 bases
+    if (ROW * ((size_t)W + 1) > c->rows_cap) {                 // (first call, or another table shape; a failure HERE cannot be agreed on: nothing has been gathered yet)
+        (void)hipStreamSynchronize(st);
+        (void)hipFree(c->d_rows); (void)hipHostFree(c->h_rows); c->d_rows = nullptr; c->h_rows = nullptr; c->rows_cap = 0;
+        HIP_TRYC(hipMalloc(&c->d_rows, ROW * ((size_t)W + 1) * sizeof(uint64_t)));
+        HIP_TRYC(hipHostMalloc(&c->h_rows, ROW * ((size_t)W + 1) * sizeof(uint64_t)));
+        c->rows_cap = ROW * ((size_t)W + 1);
+    }
+    if (!c->d_st2) { HIP_TRYC(hipMalloc(&c->d_st2, ((size_t)W + 1) * sizeof(uint64_t))); HIP_TRYC(hipHostMalloc(&c->h_st2, ((size_t)W + 1) * sizeof(uint64_t))); }
+    uint64_t *d_mine = c->d_rows + ROW * (size_t)W, *h_mine = c->h_rows + ROW * (size_t)W;
+    for (size_t i = 0; i < ROW; ++i) h_mine[i] = 0;
+    h_mine[n_bins + W_BIGCAP] = bigrec_cap; h_mine[n_bins + W_STATUS] = status; h_mine[n_bins + W_RXCAP] = c->rx_cap; h_mine[n_bins + W_BIGBUF] = c->big_cap;
+    HIP_TRYC(hipMemcpyAsync(d_mine, h_mine, ROW * sizeof(uint64_t), hipMemcpyHostToDevice, st));
+    if (!status) {                                            // bases and the long-cluster count straight from the device: no host round trip before the gather
+        HIP_TRYC(hipMemcpyAsync(d_mine, R.d_binbase, ((size_t)n_bins + 1) * sizeof(uint64_t), hipMemcpyDeviceToDevice, st));
+        HIP_TRYC(hipMemcpyAsync(d_mine + n_bins + W_NBIG, d_bigrec_n, sizeof(uint32_t), hipMemcpyDeviceToDevice, st));      // (little-endian low word; the high word is zero)
+    }
+    NCCL_TRY(g_rccl.AllGather(d_mine, c->d_rows, ROW, nccl_Uint64, c->comm, st));
+    HIP_TRYC(hipMemcpyAsync(c->h_rows, c->d_rows, ROW * (size_t)W * sizeof(uint64_t), hipMemcpyDeviceToHost, st));
+    HIP_TRYC(hipStreamSynchronize(st));                       // the one synchronisation of an exchange
+    const uint64_t *all = c->h_rows, *base = all + ROW * (size_t)me;
+    // ---- the same verdict on every rank
     for (int s = 0; s < W; ++s) {
-        const uint64_t *bs = all.data() + row * (size_t)s;
+        const uint64_t *bs = all + ROW * (size_t)s;
+        if (bs[n_bins + W_STATUS])
+            return cfail(-(int)(uint32_t)bs[n_bins + W_STATUS], "lime_comm_exchange_records: rank %d: %s", s, s == me ? local_err.c_str() : "failed its local checks");
+        if (bs[n_bins + W_NBIG] > bs[n_bins + W_BIGCAP])
+            return cfail(LIME_ERR_NOMEM, "lime_comm_exchange_records: rank %d: more update records of long clusters (%llu) than their list holds (%llu)", s,
+                         (unsigned long long)bs[n_bins + W_NBIG], (unsigned long long)bs[n_bins + W_BIGCAP]);
+    }
+    // what I receive: source s's records of my bins, one source after the other; what everybody needs (from the same rows)
+    std::vector<uint64_t> srcoff((size_t)W * (nb + 1));
+    uint64_t rx_total = 0, big_max = 0;
+    for (int s = 0; s < W; ++s) {
+        const uint64_t *bs = all + ROW * (size_t)s;
         for (uint32_t b = 0; b <= nb; ++b) srcoff[(size_t)s * (nb + 1) + b] = rx_total + (bs[b0 + b] - bs[b0]);
         rx_total += bs[b1] - bs[b0];
-        big_total += bs[n_bins + 1]; if (bs[n_bins + 1] > big_max) big_max = bs[n_bins + 1];
+        if (bs[n_bins + W_NBIG] > big_max) big_max = bs[n_bins + W_NBIG];
     }
-    ExBuf d_rx, d_big; HIP_TRYC(hipMalloc(&d_rx.p, (rx_total + 16) * sizeof(uint32_t)));
-    HIP_TRYC(hipMalloc(&d_big.p, ((size_t)W * big_max + 2) * sizeof(uint64_t)));
+    bool any_grows = false;
+    for (int p = 0; p < W; ++p) {
+        const uint32_t pb0 = first_bin(p), pb1 = pb0 + per < n_bins ? pb0 + per : n_bins;
+        uint64_t need = 0;
+        for (int s = 0; s < W; ++s) { const uint64_t *bs = all + ROW * (size_t)s; need += bs[pb1] - bs[pb0]; }
+        const uint64_t *bp = all + ROW * (size_t)p;
+        if (need + 16 > bp[n_bins + W_RXCAP] || big_max + 2 > bp[n_bins + W_BIGBUF]) any_grows = true;
+    }
+    if (any_grows) {                                          // somebody allocates: agree on the outcome before the first send or receive
+        int arc = LIME_OK;
+        if (rx_total + 16 > c->rx_cap) arc = grow_dev(c->d_rx, c->rx_cap, (size_t)rx_total + 16);
+        if (!arc && big_max + 2 > c->big_cap) {
+            size_t cap_pad = 0, cap_big = 0;
+            (void)hipFree(c->d_pad); (void)hipFree(c->d_big); c->d_pad = nullptr; c->d_big = nullptr; c->big_cap = 0;
+            arc = grow_dev(c->d_pad, cap_pad, (size_t)big_max + 2);
+            if (!arc) arc = grow_dev(c->d_big, cap_big, (cap_pad) * (size_t)W);
+            if (!arc) c->big_cap = cap_pad;
+        }
+        c->h_st2[W] = arc ? (uint64_t)(uint32_t)(-arc) : 0;
+        HIP_TRYC(hipMemcpyAsync(c->d_st2 + W, c->h_st2 + W, sizeof(uint64_t), hipMemcpyHostToDevice, st));
+        NCCL_TRY(g_rccl.AllGather(c->d_st2 + W, c->d_st2, 1, nccl_Uint64, c->comm, st));
+        HIP_TRYC(hipMemcpyAsync(c->h_st2, c->d_st2, (size_t)W * sizeof(uint64_t), hipMemcpyDeviceToHost, st));
+        HIP_TRYC(hipStreamSynchronize(st));
+        for (int s = 0; s < W; ++s)
+            if (c->h_st2[s]) return cfail(-(int)(uint32_t)c->h_st2[s], "lime_comm_exchange_records: rank %d could not allocate its receive buffers%s%s", s,
+                                          s == me ? ": " : "", s == me ? g_comm_err.c_str() : "");
+    }
     NCCL_TRY(g_rccl.GroupStart());
     for (int p = 0; p < W; ++p) {
-        const uint32_t pb0 = per * (uint32_t)p < n_bins ? per * (uint32_t)p : n_bins, pb1 = pb0 + per < n_bins ? pb0 + per : n_bins;
+        const uint32_t pb0 = first_bin(p), pb1 = pb0 + per < n_bins ? pb0 + per : n_bins;
         const uint64_t n_send = base[pb1] - base[pb0];                         // my records of p's bins
-        const uint64_t *bs = all.data() + row * (size_t)p;
+        const uint64_t *bs = all + ROW * (size_t)p;
         const uint64_t n_recv = bs[b1] - bs[b0];                               // p's records of my bins
         if (n_send) NCCL_TRY(g_rccl.Send(R.d_recs + base[pb0], n_send, nccl_Uint32, p, c->comm, st));
-        if (n_recv) NCCL_TRY(g_rccl.Recv((uint32_t *)d_rx.p + srcoff[(size_t)p * (nb + 1)], n_recv, nccl_Uint32, p, c->comm, st));
+        if (n_recv) NCCL_TRY(g_rccl.Recv(c->d_rx + srcoff[(size_t)p * (nb + 1)], n_recv, nccl_Uint32, p, c->comm, st));
     }
     NCCL_TRY(g_rccl.GroupEnd());
     // the long clusters' records of every rank, padded to the longest list (few: clusters beyond the in-window limit)
     uint64_t n_big_all = 0;
     if (big_max) {
-        ExBuf d_pad; HIP_TRYC(hipMalloc(&d_pad.p, (big_max + 1) * sizeof(uint64_t)));
-        HIP_TRYC(hipMemsetAsync(d_pad.p, 0, big_max * sizeof(uint64_t), st));   // t == 0: no update
-        if (R.n_bigrecs) HIP_TRYC(hipMemcpyAsync(d_pad.p, R.d_bigrecs, R.n_bigrecs * sizeof(uint64_t), hipMemcpyDeviceToDevice, st));
-        NCCL_TRY(g_rccl.AllGather(d_pad.p, d_big.p, big_max, nccl_Uint64, c->comm, st));
-        HIP_TRYC(hipStreamSynchronize(st));
+        const uint64_t mine = base[n_bins + W_NBIG];
+        HIP_TRYC(hipMemsetAsync(c->d_pad, 0, big_max * sizeof(uint64_t), st));   // t == 0: no update
+        if (mine) HIP_TRYC(hipMemcpyAsync(c->d_pad, R.d_bigrecs, mine * sizeof(uint64_t), hipMemcpyDeviceToDevice, st));
+        NCCL_TRY(g_rccl.AllGather(c->d_pad, c->d_big, big_max, nccl_Uint64, c->comm, st));
         n_big_all = (uint64_t)W * big_max;
     }
-    rc = lime_apply_records_dev(ctx, (uint32_t)W, (const uint32_t *)d_rx.p, srcoff.data(), nb, bin_shift, (const uint64_t *)d_big.p, n_big_all,
+    rc = lime_apply_records_dev(ctx, (uint32_t)W, c->d_rx, srcoff.data(), nb, bin_shift, c->d_big, n_big_all,
                                 *cell_lo, *block_bytes, d_block, st);
     if (rc) return cfail(rc, "%s", lime_last_error());
-    HIP_TRYC(hipStreamSynchronize(st));                   // the receive buffers are freed on return
-    return LIME_OK;
+    return LIME_OK;                                           // asynchronous from here on: the block is complete when `stream` gets there
 }
 
 // the communicators of one process driving several GPUs: created once per device list (ncclCommInitAll costs hundreds of
