@@ -17,6 +17,7 @@
 // work only: no MFMA, HBM-bound.
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <stdlib.h>
 #include <atomic>
 #include "lime_device.h"
 #include "lime_kernels.h"
@@ -1664,6 +1665,22 @@ __device__ __forceinline__ void part_scan(const uint32_t *cnt, uint32_t *toff, u
 // the threads that scan them; the counters are cleared by the scan, and the NEXT tile is counted while this one is written
 // out: three barriers a tile.
 typedef uint32_t u32x4u __attribute__((ext_vector_type(4), aligned(4)));   // four words at any 4-byte alignment
+#ifdef LIME_PART_TIMING      // debug build: cycles of k_part's phases, summed over the first wave of every workgroup (tools/r04_part_phases.sh)
+__device__ unsigned long long g_part_pt[8];
+extern "C" int lime_debug_part_times(unsigned long long *out)
+{
+    int rc = (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_part_pt), sizeof(g_part_pt));
+    void *p = nullptr; (void)hipGetSymbolAddress(&p, HIP_SYMBOL(g_part_pt)); (void)hipMemset(p, 0, sizeof(g_part_pt));
+    return rc;
+}
+#define PP_DECL uint64_t pp_t = __builtin_readcyclecounter(), pp_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+#define PP(i) { const uint64_t n_ = __builtin_readcyclecounter(); pp_acc[i] += n_ - pp_t; pp_t = n_; }
+#define PP_END if (threadIdx.x == 0) { for (int i_ = 0; i_ < 8; ++i_) atomicAdd(&g_part_pt[i_], (unsigned long long)pp_acc[i_]); }
+#else
+#define PP_DECL
+#define PP(i)
+#define PP_END
+#endif
 constexpr uint32_t PART_BPT = (BIN_MAX + PART_WG - 1) / PART_WG;           // bins a thread scans at most
 
 __global__ __launch_bounds__(PART_WG) void k_part(ScanArgs a, const uint64_t *binbase, uint32_t *out)
@@ -1686,7 +1703,12 @@ __global__ __launch_bounds__(PART_WG) void k_part(ScanArgs a, const uint64_t *bi
     // the producer's segments -- (wave, sub-region): 32-bit records, the cell's high part is the sub-region's number -- as one
     // sequence of tiles
     const uint32_t n_seg = a.prod_waves * a.n_sub, seg0 = blockIdx.x * n_seg;
-    auto seg_n = [&](uint32_t w) { return a.wave_cnt[seg0 + w]; };
+    // (the segments' record counts from LDS: fetched from memory when the walk needs them, each tile waited a memory round trip
+    // for the next one's -- 30 % of the kernel's cycles)
+    __shared__ uint32_t segn_s[16u * MAX_SUB];
+    for (uint32_t i = tid; i < n_seg; i += PART_WG) segn_s[i] = a.wave_cnt[seg0 + i];
+    __syncthreads();
+    auto seg_n = [&](uint32_t w) { return segn_s[w]; };
     struct Tile { uint32_t w, t0, tn, binoff; bool any; };
     auto tile_at = [&](uint32_t w, uint32_t t0) {
         Tile t; t.w = w; t.t0 = t0; t.any = w < n_seg; t.tn = 0u; t.binoff = 0u;
@@ -1731,11 +1753,14 @@ __global__ __launch_bounds__(PART_WG) void k_part(ScanArgs a, const uint64_t *bi
     count_tile(tc, v4);
     Tile tn_ = next_tile(tc);
     if (tn_.any) load_tile(tn_, rv);
+    PP_DECL
     for (;;) {
         // ---- scan of the tile's counts: bin cursors (LDS slots), position - slot per bin; the counters go back to zero
         {
             uint32_t c[PART_BPT], mine = 0;
+            PP(0)
             __syncthreads();                                             // the counts are complete
+            PP(1)
 #pragma unroll
             for (uint32_t k = 0; k < PART_BPT; ++k) { c[k] = (k < per && b0 + k < nb) ? cnt[b0 + k] : 0u; mine += c[k]; }
             const uint32_t incl = wave_incl_scan(mine);
@@ -1747,6 +1772,7 @@ __global__ __launch_bounds__(PART_WG) void k_part(ScanArgs a, const uint64_t *bi
             for (uint32_t k = 0; k < PART_BPT; ++k)
                 if (k < per && b0 + k < nb) { cur[b0 + k] = run; delta[b0 + k] = G[k] - run; G[k] += c[k]; cnt[b0 + k] = 0u; run += c[k]; }
             __syncthreads();
+            PP(2)
         }
         // ---- every record to the next slot of its bin, with its final position
 #pragma unroll
@@ -1761,7 +1787,9 @@ __global__ __launch_bounds__(PART_WG) void k_part(ScanArgs a, const uint64_t *bi
                     stage[slot] = make_uint2(slot + delta[b], (v[k] & omask) | tbit);      // t = 1
                 }
         }
+        PP(3)
         __syncthreads();
+        PP(4)
         // ---- the next tile is counted now (its records have landed; nobody reads the counters before the next scan) ...
         const Tile tnext = tn_;
         if (tnext.any) {
@@ -1771,6 +1799,7 @@ __global__ __launch_bounds__(PART_WG) void k_part(ScanArgs a, const uint64_t *bi
             tn_ = next_tile(tnext);
             if (tn_.any) load_tile(tn_, rv);                             // ... and the one after it is on its way
         }
+        PP(5)
         // ---- ... while this one leaves LDS, four slots a lane: consecutive positions as one 16-byte store
         for (uint32_t q = tid; 4u * q < tc.tn; q += PART_WG) {
             const uint4 s0 = stage4[2u * q], s1 = stage4[2u * q + 1u];   // (p0, v0, p1, v1), (p2, v2, p3, v3)
@@ -1784,9 +1813,201 @@ __global__ __launch_bounds__(PART_WG) void k_part(ScanArgs a, const uint64_t *bi
                 if (4u * q + 3u < tc.tn) out[s1.z] = s1.w;
             }
         }
+        PP(6)
         if (!tnext.any) break;
         tc = tnext;
     }
+    PP_END
+}
+
+// k_part_lines: k_part writing WHOLE 64-byte lines.  What bounds the scatter is not its instructions (the leaner kernel above runs
+// no faster than round 3's) but the memory side: stores are written through, every (store instruction, 64-byte line) pair is a
+// request of its own, and a request that does not cover its line is a read-modify-write at the memory: a tile's run of 7..17
+// records per bin costs two of those (tools/store_bench.hip: scattered pieces below 64 bytes write at 0.4 .. 2.9 TB/s, whole
+// lines at 7; WRITE_SIZE of round 3's k_part: 1.85 .. 2.06 x its records).  Here every bin keeps the records that do not fill
+// a line yet -- at most 15 -- in LDS (64 bytes per bin) until the next tiles complete it: after a producer's first, aligning
+// piece of a bin every store to that bin is an aligned 64-byte line (16 lanes), and each line is written once.  Per tile: count
+// per bin; scan (per bin: stage cursor, records to emit = up to the last line border, lines = tasks); records to their bins'
+// stage slots; one 16-lane group per line writes it from (carry, stage); the bins' owner threads move the tiles' tails into the
+// carries.  Needs 64 + 18 bytes of LDS per bin next to the 32 KB stage: up to ~1500 bins (launch_part falls back to k_part).
+constexpr uint32_t PL_TASKS = PART_TILE / 16u + 16u;                     // + one task per bin (a first, aligning piece)
+// (tasks of a tile: its lines -- at most (PART_TILE + 15 nb) / 16 -- plus one per bin whose first piece is not aligned)
+__host__ __device__ inline size_t part_lines_lds(uint32_t nb) { return (size_t)nb * (16u + 64u) + ((size_t)nb + 1u) / 2u * 4u + ((size_t)PL_TASKS + 2u * nb + 1u) / 2u * 4u; }
+
+__global__ __launch_bounds__(PART_WG) void k_part_lines(ScanArgs a, const uint64_t *binbase, uint32_t *out)
+{
+    __shared__ uint4 stage4[PART_TILE / 4];                              // the tile's records, grouped by bin
+    extern __shared__ uint32_t part_lds[];
+    __shared__ uint32_t wsum[PART_WG / 64], n_tasks_s;
+    uint32_t *stage = reinterpret_cast<uint32_t *>(stage4);
+    const uint32_t nb = a.n_bins, tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
+    uint32_t *cnt = part_lds, *cur = cnt + nb, *desc = cur + nb, *gpos = desc + nb;      // desc: stage start | carried records << 14 | records to emit << 18
+    uint32_t *cb = gpos + nb;                                            // [nb][16]: the bins' carried records
+    uint16_t *tfirst = reinterpret_cast<uint16_t *>(cb + (size_t)nb * 16u);
+    uint16_t *taskbin = tfirst + ((nb + 1u) & ~1u);
+    const uint32_t per = (nb + PART_WG - 1u) / PART_WG, b0 = tid * per;
+    constexpr uint32_t BPT = 3;                                          // bins a thread owns at most (launch_part: nb <= 3 * PART_WG)
+    uint32_t G[BPT], C[BPT];                                             // per owned bin: position of its next record in out; records carried
+#pragma unroll
+    for (uint32_t k = 0; k < BPT; ++k) {
+        G[k] = 0u; C[k] = 0u;
+        if (k < per && b0 + k < nb) { G[k] = (uint32_t)binbase[b0 + k] + a.counts[(size_t)(b0 + k) * gridDim.x + blockIdx.x]; cnt[b0 + k] = 0u; }
+    }
+    __syncthreads();
+    const uint32_t sh = a.bin_shift, omask = (1u << sh) - 1u, tbit = 1u << sh;
+    const uint32_t n_seg = a.prod_waves * a.n_sub, seg0 = blockIdx.x * n_seg;
+    // (the segments' record counts from LDS: fetched from memory when the walk needs them, each tile waited a memory round trip
+    // for the next one's -- 30 % of the kernel's cycles)
+    __shared__ uint32_t segn_s[16u * MAX_SUB];
+    for (uint32_t i = tid; i < n_seg; i += PART_WG) segn_s[i] = a.wave_cnt[seg0 + i];
+    __syncthreads();
+    auto seg_n = [&](uint32_t w) { return segn_s[w]; };
+    struct Tile { uint32_t w, t0, tn, binoff; bool any; };
+    auto tile_at = [&](uint32_t w, uint32_t t0) {
+        Tile t; t.w = w; t.t0 = t0; t.any = w < n_seg; t.tn = 0u; t.binoff = 0u;
+        if (t.any) { const uint32_t n = seg_n(w); t.tn = n - t0 < PART_TILE ? n - t0 : PART_TILE; t.binoff = (w % a.n_sub) << (32u - sh); }
+        return t;
+    };
+    auto next_tile = [&](const Tile &c) {
+        uint32_t w = c.w, t0 = c.t0 + PART_TILE;
+        if (t0 >= seg_n(w)) { t0 = 0u; ++w; while (w < n_seg && seg_n(w) == 0u) ++w; }
+        return tile_at(w, t0);
+    };
+    auto load_tile = [&](const Tile &t, uint4 (&r)[PART_PER / 4]) {
+        typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+        const u32x4 *src = reinterpret_cast<const u32x4 *>(a.pool + (size_t)(seg0 + t.w) * a.cap_w + t.t0);
+        const uint32_t lastq = (t.tn - 1u) >> 2;
+#pragma unroll
+        for (uint32_t j = 0; j < PART_PER / 4; ++j) {
+            const uint32_t q = j * PART_WG + tid;
+            const u32x4 x = __builtin_nontemporal_load(src + (q < lastq ? q : lastq));
+            r[j] = make_uint4(x.x, x.y, x.z, x.w);
+        }
+    };
+    auto count_tile = [&](const Tile &t, const uint4 (&r)[PART_PER / 4]) {
+#pragma unroll
+        for (uint32_t j = 0; j < PART_PER / 4; ++j) {
+            const uint32_t i = 4u * (j * PART_WG + tid);
+            const uint32_t v[4] = {r[j].x, r[j].y, r[j].z, r[j].w};
+#pragma unroll
+            for (uint32_t k = 0; k < 4; ++k) if (i + k < t.tn) atomicAdd(&cnt[(v[k] >> sh) + t.binoff], 1u);
+        }
+    };
+    uint32_t w0 = 0;
+    while (w0 < n_seg && seg_n(w0) == 0u) ++w0;
+    Tile tc = tile_at(w0, 0u);
+    if (!tc.any) return;
+    uint4 rv[PART_PER / 4], v4[PART_PER / 4];
+    load_tile(tc, rv);
+#pragma unroll
+    for (uint32_t j = 0; j < PART_PER / 4; ++j) v4[j] = rv[j];
+    count_tile(tc, v4);
+    Tile tn_ = next_tile(tc);
+    if (tn_.any) load_tile(tn_, rv);
+    PP_DECL
+    for (;;) {
+        uint32_t N[BPT], S[BPT], E[BPT], Cold[BPT];
+        // ---- scan: per owned bin the tile's records n, with the carried ones T; emit E = up to the last line border reached;
+        // L lines = tasks.  One prefix sum over (n | L << 16).
+        {
+            uint32_t L[BPT], mine = 0;
+            PP(0)
+            __syncthreads();                                             // the counts are complete, the carries up to date
+            PP(1)
+#pragma unroll
+            for (uint32_t k = 0; k < BPT; ++k) {
+                N[k] = 0u; E[k] = 0u; L[k] = 0u; Cold[k] = C[k];
+                if (k < per && b0 + k < nb) {
+                    N[k] = cnt[b0 + k]; cnt[b0 + k] = 0u;
+                    const uint32_t end = G[k] + C[k] + N[k], border = end & ~15u;
+                    if (border > G[k]) { E[k] = border - G[k]; L[k] = (border >> 4) - (G[k] >> 4); }
+                }
+                mine += N[k] | (L[k] << 16);
+            }
+            const uint32_t incl = wave_incl_scan(mine);
+            if (lane == 63u) wsum[wave] = incl;
+            __syncthreads();
+            uint32_t run = incl - mine;
+            for (uint32_t k = 0; k < wave; ++k) run += wsum[k];
+#pragma unroll
+            for (uint32_t k = 0; k < BPT; ++k)
+                if (k < per && b0 + k < nb) {
+                    const uint32_t b = b0 + k, s0 = run & 0xFFFFu, t0_ = run >> 16;
+                    S[k] = s0; cur[b] = s0; desc[b] = s0 | (C[k] << 14) | (E[k] << 18); gpos[b] = G[k]; tfirst[b] = (uint16_t)t0_;
+                    for (uint32_t i = 0; i < L[k]; ++i) taskbin[t0_ + i] = (uint16_t)b;
+                    G[k] += E[k]; C[k] = C[k] + N[k] - E[k];
+                    run += N[k] | (L[k] << 16);
+                }
+            if (tid == PART_WG - 1u) n_tasks_s = run >> 16;              // (the last thread's running sum is the total)
+            __syncthreads();
+            PP(2)
+        }
+        // ---- every record to the next stage slot of its bin
+#pragma unroll
+        for (uint32_t j = 0; j < PART_PER / 4; ++j) {
+            const uint32_t i = 4u * (j * PART_WG + tid);
+            const uint32_t v[4] = {v4[j].x, v4[j].y, v4[j].z, v4[j].w};
+#pragma unroll
+            for (uint32_t k = 0; k < 4; ++k)
+                if (i + k < tc.tn) stage[atomicAdd(&cur[(v[k] >> sh) + tc.binoff], 1u)] = (v[k] & omask) | tbit;      // t = 1
+        }
+        PP(3)
+        __syncthreads();
+        PP(4)
+        // ---- a line per 16-lane group: element e of the bin's stream (its carried records, then the tile's) goes to g + e
+        {
+            // (four lines a turn: each is a chain of dependent LDS reads -- task -> bin -> its descriptors -> the record -- and one at a
+            // time the write-out was the longest phase of the kernel)
+            constexpr uint32_t GRPS = PART_WG / 16u, UT = 4;
+            const uint32_t grp = tid >> 4, l16 = tid & 15u, n_tasks = n_tasks_s;
+            for (uint32_t j0 = grp; j0 < n_tasks; j0 += GRPS * UT) {
+                uint32_t bb[UT], dd[UT], gg[UT], tf[UT], pp[UT], ee[UT], val[UT];
+                bool on[UT];
+#pragma unroll
+                for (uint32_t u = 0; u < UT; ++u) { const uint32_t j = j0 + u * GRPS; on[u] = j < n_tasks; bb[u] = taskbin[on[u] ? j : 0u]; }
+#pragma unroll
+                for (uint32_t u = 0; u < UT; ++u) { dd[u] = desc[bb[u]]; gg[u] = gpos[bb[u]]; tf[u] = tfirst[bb[u]]; }
+#pragma unroll
+                for (uint32_t u = 0; u < UT; ++u) {
+                    const uint32_t j = j0 + u * GRPS, s0 = dd[u] & 0x3FFFu, c = (dd[u] >> 14) & 15u, e_n = dd[u] >> 18;
+                    pp[u] = (((gg[u] >> 4) + (j - tf[u])) << 4) + l16; ee[u] = pp[u] - gg[u];
+                    on[u] = on[u] && ee[u] < e_n;
+                    const uint32_t *srcp = ee[u] < c ? cb + (bb[u] * 16u + ee[u]) : stage + (s0 + ee[u] - c);
+                    val[u] = on[u] ? *srcp : 0u;
+                }
+#pragma unroll
+                for (uint32_t u = 0; u < UT; ++u) if (on[u]) out[pp[u]] = val[u];
+            }
+        }
+        PP(5)
+        // ---- the next tile is counted now (only the counters are touched) ...
+        const Tile tnext = tn_;
+        if (tnext.any) {
+#pragma unroll
+            for (uint32_t j = 0; j < PART_PER / 4; ++j) v4[j] = rv[j];
+            count_tile(tnext, v4);
+            tn_ = next_tile(tnext);
+            if (tn_.any) load_tile(tn_, rv);
+        }
+        PP(6)
+        __syncthreads();                                                 // the lines have been read from the carries and the stage
+        // ---- the tails into the carries: a bin that emitted keeps the last C records of the tile, one that did not appends all of them
+#pragma unroll
+        for (uint32_t k = 0; k < BPT; ++k)
+            if (k < per && b0 + k < nb) {
+                uint32_t *cbb = cb + (size_t)(b0 + k) * 16u;
+                if (E[k]) { for (uint32_t i = 0; i < C[k]; ++i) cbb[i] = stage[S[k] + N[k] - C[k] + i]; }
+                else      { for (uint32_t i = 0; i < N[k]; ++i) cbb[Cold[k] + i] = stage[S[k] + i]; }
+            }
+        PP(7)
+        if (!tnext.any) break;
+        tc = tnext;
+    }
+    PP_END
+    // ---- the end of the producer's records: what the bins still carry (a last, partial line each)
+#pragma unroll
+    for (uint32_t k = 0; k < BPT; ++k)
+        if (k < per && b0 + k < nb) for (uint32_t i = 0; i < C[k]; ++i) out[G[k] + i] = cb[(size_t)(b0 + k) * 16u + i];
 }
 
 // k_part2: second level, one workgroup per bin (bins wider than a region only): the bin's records are counted per
@@ -1966,9 +2187,20 @@ __global__ __launch_bounds__(APPLY_WG) void k_apply_tiles(uint8_t *sim, size_t s
     uint32_t *reg = reinterpret_cast<uint32_t *>(reg4);
     const uint32_t lane = lane_id(), wave = threadIdx.x >> 6;
     const uint32_t f2 = 1u << (bin_shift - REGION_SHIFT);
-    auto add = [&](uint32_t o) {                                  // one record: + 1 modulo 256 on byte o of the region
+    // one record: + 1 modulo 256 on byte o of the region.  Fast form: ONE returning LDS add of 1 << (8 x byte) on the word -- exact as long
+    // as no cell of the word passes 255 (a carry would run into its neighbour); an add that finds its cell at 255 raises the region's
+    // flag, and the region is then built again with the exact form, a compare-and-swap per record (real collections never get
+    // there: a cell's sum is bounded by the read length; the wrap-around fixtures and the iid generator at few reads do).
+    __shared__ uint32_t ovf_s;
+    bool exact = false;
+    auto add = [&](uint32_t o) {
         const uint32_t sh = (o & 3u) * 8u;
         uint32_t *w = &reg[o >> 2];
+        if (!exact) {
+            const uint32_t old = atomicAdd(w, 1u << sh);
+            if (((old >> sh) & 255u) == 255u) ovf_s = 1u;
+            return;
+        }
         uint32_t seen = *w;
         for (;;) {
             const uint32_t b = ((seen >> sh) + 1u) & 255u;
@@ -1978,6 +2210,7 @@ __global__ __launch_bounds__(APPLY_WG) void k_apply_tiles(uint8_t *sim, size_t s
         }
     };
     struct Step { uint2 v[UR]; uint32_t fa[UR], fe[UR], q[UR]; const uint16_t *src[UR]; };
+    if (threadIdx.x == 0) ovf_s = 0u;
     // A workgroup walks regions blockIdx.x, + gridDim.x, ... (two workgroups per CU).  What a region needs before its records
     // can be read -- its bin's tile range, then its index entries -- is fetched while the region before it is worked on: a
     // workgroup per region paid that chain of dependent loads per region (configs[2]: 76 k regions of 1.6 k records each).
@@ -1997,10 +2230,11 @@ __global__ __launch_bounds__(APPLY_WG) void k_apply_tiles(uint8_t *sim, size_t s
         if (more) { nrow0 = tbase[next >> (bin_shift - REGION_SHIFT)]; nrow1 = tbase[(next >> (bin_shift - REGION_SHIFT)) + 1u]; }
         const uint32_t sub = region & (f2 - 1u);
         const uint16_t *ia = idx + (size_t)row0 * (f2 + 1u) + (size_t)sub * n_rows, *ie = ia + n_rows;
+        for (exact = false;; exact = true) {                      // once; twice if a cell passed 255 under the fast adds
         for (uint32_t i = threadIdx.x; i < RW / 4; i += APPLY_WG) reg4[i] = make_uint4(0u, 0u, 0u, 0u);
         __syncthreads();
         for (uint32_t outer = 0; outer < n_rows; outer += NWV * 64u) {
-            if (outer) { a = 0u; e = 0u; const uint32_t t = outer + wave + NWV * lane; if (t < n_rows) { a = ia[t]; e = ie[t]; } }
+            if (outer || exact) { a = 0u; e = 0u; const uint32_t t = outer + wave + NWV * lane; if (t < n_rows) { a = ia[t]; e = ie[t]; } }
             const uint32_t left = n_rows - outer;                  // tiles of this round: the wave's are wave, wave + NWV, ... < left
             const uint32_t nl = left > wave ? ((left - wave + NWV - 1u) / NWV < 64u ? (left - wave + NWV - 1u) / NWV : 64u) : 0u;
             auto load_step = [&](uint32_t l0, Step &s) {          // the first 256 records of the runs l0 .. l0 + UR of this wave
@@ -2040,6 +2274,10 @@ __global__ __launch_bounds__(APPLY_WG) void k_apply_tiles(uint8_t *sim, size_t s
             }
         }
         __syncthreads();
+        if (exact || !ovf_s) break;
+        __syncthreads();                                          // (everybody has seen the flag)
+        if (threadIdx.x == 0) ovf_s = 0u;
+        }
         // the next region's index entries go out now and land while this region is written
         uint32_t na = 0, ne = 0;
         if (more) {
@@ -2720,6 +2958,31 @@ void launch_part(const ScanArgs &a, uint32_t n_prod, const uint64_t *binbase, ui
     if (!set.load(std::memory_order_relaxed)) {
         (void)hipFuncSetAttribute(reinterpret_cast<const void *>(k_part), hipFuncAttributeMaxDynamicSharedMemorySize, (int)(BIN_MAX * 12u));
         set.store(true, std::memory_order_relaxed);
+    }
+    // whole-line writes (k_part_lines) wherever the bins' line buffers fit the LDS next to the stage; LIME_PART_LINES=0: comparison runs
+    static const bool lines_ok = !(getenv("LIME_PART_LINES") && atoi(getenv("LIME_PART_LINES")) == 0);
+    static std::atomic<uint32_t> lines_room[MAX_DEV];        // dynamic LDS k_part_lines may ask for on this device (0: not asked yet)
+    const size_t lds_lines = part_lines_lds(a.n_bins);
+    if (lines_ok && a.n_bins <= 3u * PART_WG) {
+        std::atomic<uint32_t> &room = lines_room[cur_device()];
+        uint32_t r = room.load(std::memory_order_relaxed);
+        if (!r) {
+            hipFuncAttributes fa;
+            r = 1u;
+            if (hipFuncGetAttributes(&fa, reinterpret_cast<const void *>(k_part_lines)) == hipSuccess && fa.sharedSizeBytes < 160u * 1024u) {
+                const uint32_t dyn = 160u * 1024u - (uint32_t)fa.sharedSizeBytes;
+                if (hipFuncSetAttribute(reinterpret_cast<const void *>(k_part_lines), hipFuncAttributeMaxDynamicSharedMemorySize, (int)dyn) == hipSuccess) r = dyn;
+            }
+            (void)hipGetLastError();
+            room.store(r, std::memory_order_relaxed);
+        }
+        // two workgroups per CU must fit (the kernel is a chain of short phases: alone on a CU it is slower than k_part -- configs[2], 1193 bins:
+        // 0.72 against 0.48 ms; N = 1e10, 477 bins, two per CU: 3.8 against 4.2 .. 4.7 ms)
+        const size_t stat = 160u * 1024u - (r > 1u ? r : 0u);               // the kernel's static LDS
+        if (lds_lines <= r && 2u * (lds_lines + stat + 512u) <= 160u * 1024u) {
+            hipLaunchKernelGGL(k_part_lines, dim3(n_prod), dim3(PART_WG), lds_lines, st, a, binbase, out);
+            return;
+        }
     }
     hipLaunchKernelGGL(k_part, dim3(n_prod), dim3(PART_WG), (size_t)a.n_bins * 12u, st, a, binbase, out);
 }
