@@ -25,8 +25,17 @@ constexpr int SCAN_WG = 256;                 // 4 independent waves per workgrou
 #define LIME_SCAN_WG1 768
 #define LIME_SCAN_WAVES1 3
 #endif
-template <int EBWT> struct ScanCfg { static constexpr int wg = EBWT ? LIME_SCAN_WG1 : LIME_SCAN_WG0, waves = EBWT ? LIME_SCAN_WAVES1 : LIME_SCAN_WAVES0; };
-inline uint32_t scan_waves_per_wg(int ebwt, int mode) { return (uint32_t)((ebwt && mode == 0 ? ScanCfg<1>::wg : ScanCfg<0>::wg) / 64); }
+// Round 4: the EBWT=1 scan that emits update records (BIN) also runs 16 waves = 4 per SIMD: it fits 128 VGPRs, and its LDS fits a CU
+// with a shorter update queue (ScanLdsT); the compare-and-swap EBWT=1 scan stays at 12 waves (its in-flight slots need the room).
+#ifndef LIME_SCAN_WG1B
+#define LIME_SCAN_WG1B 1024
+#define LIME_SCAN_WAVES1B 4
+#endif
+template <int EBWT, int BIN> struct ScanCfg {
+    static constexpr int wg = EBWT ? (BIN ? LIME_SCAN_WG1B : LIME_SCAN_WG1) : LIME_SCAN_WG0, waves = EBWT ? (BIN ? LIME_SCAN_WAVES1B : LIME_SCAN_WAVES1) : LIME_SCAN_WAVES0;
+};
+// waves per workgroup of the scan that emits update records (the only one whose waves the host counts: pool regions, producers)
+inline uint32_t scan_waves_per_wg(int ebwt, int mode) { return (uint32_t)((ebwt && mode == 0 ? ScanCfg<1, 1>::wg : ScanCfg<0, 1>::wg) / 64); }
 constexpr int WGSZ = 512;                    // workgroup of the helper kernels (big clusters, choose, synth)
 constexpr uint32_t SMALL_MAX = 16;           // longest cluster scored inside a window
 constexpr uint32_t NONE32 = 0xFFFFFFFFu;

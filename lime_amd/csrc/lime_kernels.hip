@@ -97,6 +97,7 @@ extern "C" int lime_debug_winmark(uint32_t *out)
 // EBWT = 0: 16 waves = 4 per SIMD; EBWT = 1: 12 waves = 3 per SIMD); the LDS of one wave is kept small: it bounds them
 constexpr uint32_t DUP_SLOTS = 8;     // clusters with a repeated document a wave of k_scan holds before scoring them
 constexpr uint32_t QCAP_SCAN = 286;   // >= the 256 hits one batch of 64 clusters of <= 4 symbols can add + the 2 x 15 entries a binned drain leaves behind
+constexpr uint32_t QCAP_SCAN_SHORT = 160;   // EBWT=1 with records (16 waves per CU): a batch that would not fit is emitted in two halves (score_small3)
 
 __device__ __forceinline__ uint32_t lane_id() { return threadIdx.x & 63u; }
 // The kernel's ScanArgs (always its first argument) re-read from the kernarg segment at the point of use: fields that only
@@ -776,21 +777,30 @@ __device__ __forceinline__ uint32_t score_small3(LDS &L, const WgTables &T, UpdQ
     }
     if (dup || !on) hits = 0u;
     const uint32_t nh = (uint32_t)__popc(hits);
-    const uint32_t incl = wave_incl_scan(nh), total = rl32(incl, 63);
-    while (qu.n + total > qu.cap) drain(qu, a);                               // total <= 4 per lane = 256 <= cap
-    const uint32_t slot0 = qu.n + incl - nh;
+    const uint32_t incl_all = wave_incl_scan(nh), total_all = rl32(incl_all, 63);
+    // a batch adds at most 4 entries per lane = 256; where the queue is shorter than that (the 16-wave EBWT=1 kernel) a batch
+    // that cannot fit even an emptied queue goes in two halves, slots 0..1 then 2..3 of the pair lists (at most 128 each)
+    const uint32_t halves = total_all + 2u * 15u > qu.cap ? 2u : 1u;          // wave-uniform (a binned drain leaves up to 2 x 15 records behind in its line buffers, not in the queue)
+#pragma unroll 1
+    for (uint32_t half = 0; half < halves; ++half) {
+        const uint32_t hp = halves == 1u ? hits : (half ? hits & 12u : hits & 3u);
+        const uint32_t nhp = (uint32_t)__popc(hp);
+        const uint32_t incl = halves == 1u ? incl_all : wave_incl_scan(nhp), total = halves == 1u ? total_all : rl32(incl, 63);
+        while (qu.n + total > qu.cap) drain(qu, a);
+        const uint32_t slot0 = qu.n + incl - nhp;
 #pragma unroll
-    for (int e = 0; e < 4; ++e) {
-        const bool he = (hits >> e) & 1u;
-        if (e >= 2 && !__ballot(he)) continue;                                // wave-uniform: most rounds have no cluster with 3 or 4 pairs
-        if (he) {
-            const uint32_t rp = (pl >> (7 * e)) & 3u, gp = (pl >> (7 * e + 2)) & 3u;
-            const uint32_t slot = EBWT ? slot0 + (uint32_t)__popc(hits & ((1u << e) - 1u)) : slot0 + (uint32_t)e;
-            qu.qr[slot] = L.da[p + rp];
-            qu.qg[slot] = (L.da[p + gp] - a.n_reads) | (1u << T_SHIFT);
+        for (int e = 0; e < 4; ++e) {
+            const bool he = (hp >> e) & 1u;
+            if (e >= 2 && !__ballot(he)) continue;                            // wave-uniform: most rounds have no cluster with 3 or 4 pairs
+            if (he) {
+                const uint32_t rp = (pl >> (7 * e)) & 3u, gp = (pl >> (7 * e + 2)) & 3u;
+                const uint32_t slot = (EBWT || halves != 1u) ? slot0 + (uint32_t)__popc(hp & ((1u << e) - 1u)) : slot0 + (uint32_t)e;
+                qu.qr[slot] = L.da[p + rp];
+                qu.qg[slot] = (L.da[p + gp] - a.n_reads) | (1u << T_SHIFT);
+            }
         }
+        qu.n += total;
     }
-    qu.n += total;
     return nh + nflush;
 }
 
@@ -935,7 +945,8 @@ struct alignas(16) ScanLdsT {
     // its already consumed head: the k-th such cluster is at most the k-th cluster read.
     uint16_t listM[WIN / 2];
     uint16_t m_tstart[64];                   // the round's clusters of 9..SMALL_MAX symbols (position | (len-1) << 12)
-    uint32_t q_read[QCAP_SCAN], q_gen[QCAP_SCAN];
+    static constexpr uint32_t QCAP = (EBWT && BIN) ? QCAP_SCAN_SHORT : QCAP_SCAN;
+    uint32_t q_read[QCAP], q_gen[QCAP];
     uint32_t sub_n[MAX_SUB + 1];             // binned updates: records in each of the wave's sub-regions; [MAX_SUB]: offset of the wave's producer group in the workgroup's bin histogram
     uint32_t lfill[2], lbuf[BIN ? 2 * LBUF : 2];   // records waiting for their 64-byte line (drain_lines)
     uint32_t g_doc[DUP_SLOTS][SMALL_MAX];
@@ -1014,9 +1025,9 @@ __device__ __forceinline__ Ctx16 chunk_context(uint32_t h, uint32_t r, uint32_t 
 // bound by the vector ALU's issue rate and the memory system together, not by latency a fourth wave would hide.)
 
 template <int EBWT, int MODE, int BIN>
-__global__ __launch_bounds__(ScanCfg<EBWT>::wg) __attribute__((amdgpu_waves_per_eu(ScanCfg<EBWT>::waves, ScanCfg<EBWT>::waves))) void k_scan(ScanArgs a)
+__global__ __launch_bounds__((ScanCfg<EBWT, BIN>::wg)) __attribute__((amdgpu_waves_per_eu((ScanCfg<EBWT, BIN>::waves), (ScanCfg<EBWT, BIN>::waves)))) void k_scan(ScanArgs a)
 {
-    constexpr int SCANK_WG = ScanCfg<EBWT>::wg;
+    constexpr int SCANK_WG = ScanCfg<EBWT, BIN>::wg;
     static_assert(BIN == 0 || MODE == 0, "records are made by the scoring scan only");
     typedef ScanLdsT<EBWT, BIN> ScanLds;
     __shared__ ScanLds lds[SCANK_WG / 64];
@@ -1041,7 +1052,7 @@ __global__ __launch_bounds__(ScanCfg<EBWT>::wg) __attribute__((amdgpu_waves_per_
     tables_init(T);                                        // the only workgroup barrier of the kernel
     const uint32_t n_win = a.n_tiles;
     constexpr uint32_t WPW = SCANK_WG / 64;
-    UpdQueue qu; qu.qr = L.q_read; qu.qg = L.q_gen; qu.n = 0; qu.cap = QCAP_SCAN;
+    UpdQueue qu; qu.qr = L.q_read; qu.qg = L.q_gen; qu.n = 0; qu.cap = ScanLds::QCAP;
     qu.async = true;
     if (!binned) { qu.nj = NJ; qu.fr = fslots + 192u * NJ * wave; qu.fg = qu.fr + 64u * NJ; qu.fe = qu.fr + 128u * NJ; }
     const uint32_t wave_gid = blockIdx.x * (SCANK_WG / 64) + wave;
@@ -2941,9 +2952,9 @@ template <int ID, int WG, typename K> static void launch_scan_kernel(K kernel, c
 
 uint32_t scan_grid(int ebwt, int mode, int binned, uint32_t n_tiles, uint32_t max_blocks)
 {
-    if (mode != 0) return scan_grid_of<2, ScanCfg<0>::wg>(k_scan<0, 1, 0>, n_tiles, max_blocks);
-    if (binned) return ebwt ? scan_grid_of<4, ScanCfg<1>::wg>(k_scan<1, 0, 1>, n_tiles, max_blocks) : scan_grid_of<3, ScanCfg<0>::wg>(k_scan<0, 0, 1>, n_tiles, max_blocks);
-    return ebwt ? scan_grid_of<1, ScanCfg<1>::wg>(k_scan<1, 0, 0>, n_tiles, max_blocks) : scan_grid_of<0, ScanCfg<0>::wg>(k_scan<0, 0, 0>, n_tiles, max_blocks);
+    if (mode != 0) return scan_grid_of<2, ScanCfg<0, 0>::wg>(k_scan<0, 1, 0>, n_tiles, max_blocks);
+    if (binned) return ebwt ? scan_grid_of<4, ScanCfg<1, 1>::wg>(k_scan<1, 0, 1>, n_tiles, max_blocks) : scan_grid_of<3, ScanCfg<0, 1>::wg>(k_scan<0, 0, 1>, n_tiles, max_blocks);
+    return ebwt ? scan_grid_of<1, ScanCfg<1, 0>::wg>(k_scan<1, 0, 0>, n_tiles, max_blocks) : scan_grid_of<0, ScanCfg<0, 0>::wg>(k_scan<0, 0, 0>, n_tiles, max_blocks);
 }
 
 void launch_bin_rowscan(uint32_t *counts, uint32_t *totals, uint32_t n_bins, uint32_t n_prod, hipStream_t st)
@@ -3100,13 +3111,13 @@ void launch_apply_bigrecs(const uint64_t *recs, uint64_t n, uint64_t cell_lo, ui
 
 void launch_tile(int ebwt, int mode, const ScanArgs &a, uint32_t max_blocks, hipStream_t st)
 {
-    if (mode != 0) launch_scan_kernel<2, ScanCfg<0>::wg>(k_scan<0, 1, 0>, a, max_blocks, st);
+    if (mode != 0) launch_scan_kernel<2, ScanCfg<0, 0>::wg>(k_scan<0, 1, 0>, a, max_blocks, st);
     else if (a.upd_mode) {
-        if (ebwt) launch_scan_kernel<4, ScanCfg<1>::wg>(k_scan<1, 0, 1>, a, max_blocks, st);
-        else      launch_scan_kernel<3, ScanCfg<0>::wg>(k_scan<0, 0, 1>, a, max_blocks, st);
+        if (ebwt) launch_scan_kernel<4, ScanCfg<1, 1>::wg>(k_scan<1, 0, 1>, a, max_blocks, st);
+        else      launch_scan_kernel<3, ScanCfg<0, 1>::wg>(k_scan<0, 0, 1>, a, max_blocks, st);
     } else {
-        if (ebwt) launch_scan_kernel<1, ScanCfg<1>::wg>(k_scan<1, 0, 0>, a, max_blocks, st);
-        else      launch_scan_kernel<0, ScanCfg<0>::wg>(k_scan<0, 0, 0>, a, max_blocks, st);
+        if (ebwt) launch_scan_kernel<1, ScanCfg<1, 0>::wg>(k_scan<1, 0, 0>, a, max_blocks, st);
+        else      launch_scan_kernel<0, ScanCfg<0, 0>::wg>(k_scan<0, 0, 0>, a, max_blocks, st);
     }
 }
 
