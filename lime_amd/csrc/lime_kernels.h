@@ -26,7 +26,8 @@ constexpr int SCAN_WG = 256;                 // 4 independent waves per workgrou
 #define LIME_SCAN_WAVES1 3
 #endif
 // Round 4: the EBWT=1 scan that emits update records (BIN) also runs 16 waves = 4 per SIMD: it fits 128 VGPRs, and its LDS fits a CU
-// with a shorter update queue (ScanLdsT); the compare-and-swap EBWT=1 scan stays at 12 waves (its in-flight slots need the room).
+// with a shorter update queue (ScanLdsT); the compare-and-swap EBWT=1 scan stays at 12 waves: at 16 it fits the LDS too (160 064 bytes) but
+// not 128 VGPRs -- 8 spilled to scratch, configs[1] 0.247 against 0.216 ms (tools/r04_libs.sh, round 4).
 #ifndef LIME_SCAN_WG1B
 #define LIME_SCAN_WG1B 1024
 #define LIME_SCAN_WAVES1B 4

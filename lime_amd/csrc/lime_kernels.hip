@@ -96,6 +96,7 @@ extern "C" int lime_debug_winmark(uint32_t *out)
 // threads per workgroup of k_scan and waves per SIMD it is compiled for: ScanCfg in lime_kernels.h (one workgroup per CU:
 // EBWT = 0: 16 waves = 4 per SIMD; EBWT = 1: 12 waves = 3 per SIMD); the LDS of one wave is kept small: it bounds them
 constexpr uint32_t DUP_SLOTS = 8;     // clusters with a repeated document a wave of k_scan holds before scoring them
+constexpr uint32_t DUP_SLOTS_E = 4;   // ... with symbols (EBWT=1: 16 waves per CU, the LDS is short): one flush of four 16-lane groups
 constexpr uint32_t QCAP_SCAN = 286;   // >= the 256 hits one batch of 64 clusters of <= 4 symbols can add + the 2 x 15 entries a binned drain leaves behind
 constexpr uint32_t QCAP_SCAN_SHORT = 160;   // EBWT=1 with records (16 waves per CU): a batch that would not fit is emitted in two halves (score_small3)
 
@@ -568,9 +569,9 @@ __device__ __forceinline__ uint32_t dup_push(LDS &L, uint32_t &n_dup, const Scan
     uint64_t m = __ballot(on);
     uint32_t nupd = 0;
     while (m) {                                            // wave-uniform; one round unless the store fills up
-        if (n_dup == DUP_SLOTS) nupd += dup_flush<EBWT>(L, n_dup, a, T, qu);
+        if (n_dup == LDS::NDUP) nupd += dup_flush<EBWT>(L, n_dup, a, T, qu);
         const uint32_t rank = (uint32_t)__popcll(m & ((1ull << lane_id()) - 1ull));
-        const bool take = on && rank < DUP_SLOTS - n_dup;
+        const bool take = on && rank < LDS::NDUP - n_dup;
         if (take) {
             const uint32_t slot = n_dup + rank;
             for (uint32_t k = 0; k < len; ++k) { L.g_doc[slot][k] = L.da[p + k]; if (EBWT) L.g_sym[slot][k] = L.fl[p + k]; }
@@ -945,12 +946,13 @@ struct alignas(16) ScanLdsT {
     // its already consumed head: the k-th such cluster is at most the k-th cluster read.
     uint16_t listM[WIN / 2];
     uint16_t m_tstart[64];                   // the round's clusters of 9..SMALL_MAX symbols (position | (len-1) << 12)
-    static constexpr uint32_t QCAP = (EBWT && BIN) ? QCAP_SCAN_SHORT : QCAP_SCAN;
+    static constexpr uint32_t QCAP = EBWT ? QCAP_SCAN_SHORT : QCAP_SCAN;
     uint32_t q_read[QCAP], q_gen[QCAP];
     uint32_t sub_n[MAX_SUB + 1];             // binned updates: records in each of the wave's sub-regions; [MAX_SUB]: offset of the wave's producer group in the workgroup's bin histogram
     uint32_t lfill[2], lbuf[BIN ? 2 * LBUF : 2];   // records waiting for their 64-byte line (drain_lines)
-    uint32_t g_doc[DUP_SLOTS][SMALL_MAX];
-    uint8_t g_sym[EBWT ? DUP_SLOTS : 1][SMALL_MAX], g_len[DUP_SLOTS];
+    uint32_t g_doc[EBWT ? DUP_SLOTS_E : DUP_SLOTS][SMALL_MAX];
+    uint8_t g_sym[EBWT ? DUP_SLOTS_E : 1][SMALL_MAX], g_len[DUP_SLOTS];
+    static constexpr uint32_t NDUP = EBWT ? DUP_SLOTS_E : DUP_SLOTS;
 };
 
 struct Ctx16 {
@@ -1391,7 +1393,7 @@ __global__ __launch_bounds__((ScanCfg<EBWT, BIN>::wg)) __attribute__((amdgpu_wav
                 }
             }
             if (nM && !ABL(10) && !ABL(11) && !ABL(4)) acc_upd += score_rows3<EBWT, 8>(L, T, qu, n_dup, a, L.listM, nM);
-            if (n_dup >= DUP_SLOTS / 2u) acc_upd += dup_flush<EBWT>(L, n_dup, a, T, qu);
+            if (n_dup >= ScanLds::NDUP / 2u) acc_upd += dup_flush<EBWT>(L, n_dup, a, T, qu);
             PT(6)
         } else {
             // ---- count: records of the window, its masks for k_emit, the longest record -----------
