@@ -2142,12 +2142,15 @@ __global__ __launch_bounds__(PART_WG) void k_sort_tiles(const uint32_t *recs, co
     uint16_t *stage = reinterpret_cast<uint16_t *>(stage4);
     const uint32_t tid = threadIdx.x;
     const uint32_t f2 = 1u << (bin_shift - REGION_SHIFT), omask = (1u << bin_shift) - 1u;
-    const uint32_t bin = blockIdx.x;
+    // workgroup (bin, k) of gridDim.y takes the bin's tiles k, k + gridDim.y, ...: tiles are independent of each other, and a
+    // workgroup per BIN left the CUs unevenly loaded (477 or 1193 workgroups of 8 waves over 256 CUs, 292 on the text workload)
+    const uint32_t bin = blockIdx.x, kq = blockIdx.y, nq = gridDim.y;
     const uint64_t lo = binbase[bin], hi = binbase[bin + 1];
     const uint32_t row0 = tbase[bin], n_rows = tbase[bin + 1] - row0;
     uint16_t *bidx = idx + (size_t)row0 * (f2 + 1u);
     for (uint32_t i = tid; i < f2; i += PART_WG) cnt[i] = 0u;
     __syncthreads();
+    const uint64_t step = (uint64_t)PART_TILE * nq, first = lo + (uint64_t)PART_TILE * kq;
     auto load_tile = [&](uint64_t t0, uint32_t (&v)[PART_PER]) {
         const uint32_t tn = hi - t0 < PART_TILE ? (uint32_t)(hi - t0) : PART_TILE;
 #pragma unroll
@@ -2157,9 +2160,9 @@ __global__ __launch_bounds__(PART_WG) void k_sort_tiles(const uint32_t *recs, co
         }
     };
     uint32_t nxt[PART_PER];
-    if (lo < hi) load_tile(lo, nxt);
-    uint32_t row = 0;
-    for (uint64_t t0 = lo; t0 < hi; t0 += PART_TILE, ++row) {
+    if (first < hi) load_tile(first, nxt);
+    uint32_t row = kq;
+    for (uint64_t t0 = first; t0 < hi; t0 += step, row += nq) {
         uint32_t val[PART_PER], dr[PART_PER];
 #pragma unroll
         for (uint32_t j = 0; j < PART_PER; ++j) {
@@ -2169,7 +2172,7 @@ __global__ __launch_bounds__(PART_WG) void k_sort_tiles(const uint32_t *recs, co
                 dr[j] = d | (atomicAdd(&cnt[d], 1u) << 12);
             }
         }
-        if (t0 + PART_TILE < hi) load_tile(t0 + PART_TILE, nxt);
+        if (t0 + step < hi) load_tile(t0 + step, nxt);
         __syncthreads();
         part_scan(cnt, toff, f2, wsum);
 #pragma unroll
@@ -3018,7 +3021,9 @@ void launch_apply_by_tiles(uint8_t *sim, size_t sim_bytes, const uint32_t *recs,
                            uint32_t *tbase, uint16_t *idx, uint16_t *out16, hipStream_t st)
 {
     hipLaunchKernelGGL(k_tile_bases, dim3(1), dim3(PART_WG), 0, st, binbase, n_bins, tbase);
-    hipLaunchKernelGGL(k_sort_tiles, dim3(n_bins), dim3(PART_WG), 0, st, recs, binbase, bin_shift, tbase, idx, out16);
+    // enough workgroups to fill the device evenly: about 8 per CU (two are resident at a time)
+    const uint32_t per_bin = n_bins >= 2048u ? 1u : (2048u + n_bins - 1u) / n_bins;
+    hipLaunchKernelGGL(k_sort_tiles, dim3(n_bins, per_bin), dim3(PART_WG), 0, st, recs, binbase, bin_shift, tbase, idx, out16);
     const uint32_t n_regions = (uint32_t)((sim_bytes + ((size_t)1 << REGION_SHIFT) - 1) >> REGION_SHIFT);
     static std::atomic<uint32_t> resident_of[MAX_DEV];           // workgroups that fit the device at once (two per CU: 64 KB of LDS each)
     std::atomic<uint32_t> &slot = resident_of[cur_device()];
