@@ -1694,10 +1694,13 @@ extern "C" int lime_debug_part_times(unsigned long long *out)
 #define PP(i)
 #define PP_END
 #endif
-constexpr uint32_t PART_BPT = (BIN_MAX + PART_WG - 1) / PART_WG;           // bins a thread scans at most
 
-__global__ __launch_bounds__(PART_WG) void k_part(ScanArgs a, const uint64_t *binbase, uint32_t *out)
+// WGS threads and tiles of 16 WGS records: 512 / 8192, or -- few bins: the runs stay long enough -- 256 / 4096 with twice as many
+// workgroups per CU: a tile is a chain of short phases between barriers, and what hides their latencies is other workgroups
+template <int WGS, uint32_t NB_MAX>
+__global__ __launch_bounds__(WGS) void k_part(ScanArgs a, const uint64_t *binbase, uint32_t *out)
 {
+    constexpr uint32_t PART_WG = WGS, PART_TILE = WGS * PART_PER, PART_BPT = (NB_MAX + WGS - 1) / WGS;   // (shadow the file's constants)
     __shared__ uint4 stage4[PART_TILE / 2];                              // (position in out, record) per slot
     extern __shared__ uint32_t part_lds[];                               // per bin: tile count, cursor (LDS slot), position - slot
     __shared__ uint32_t wsum[PART_WG / 64];
@@ -1845,7 +1848,8 @@ __global__ __launch_bounds__(PART_WG) void k_part(ScanArgs a, const uint64_t *bi
 // carries.  Needs 64 + 18 bytes of LDS per bin next to the 32 KB stage: up to ~1500 bins (launch_part falls back to k_part).
 constexpr uint32_t PL_TASKS = PART_TILE / 16u + 16u;                     // + one task per bin (a first, aligning piece)
 // (tasks of a tile: its lines -- at most (PART_TILE + 15 nb) / 16 -- plus one per bin whose first piece is not aligned)
-__host__ __device__ inline size_t part_lines_lds(uint32_t nb) { return (size_t)nb * (16u + 64u) + ((size_t)nb + 1u) / 2u * 4u + ((size_t)PL_TASKS + 2u * nb + 1u) / 2u * 4u; }
+constexpr uint32_t PL_CS = 17;                                          // words per bin's carry row: 16 records on a stride that spreads the bins over the LDS banks (a stride of 16 put every bin's record i on two banks: 77 % of the LDS cycles were bank conflicts)
+__host__ __device__ inline size_t part_lines_lds(uint32_t nb) { return (size_t)nb * (16u + 4u * PL_CS) + ((size_t)nb + 1u) / 2u * 4u + ((size_t)PL_TASKS + 2u * nb + 1u) / 2u * 4u; }
 
 __global__ __launch_bounds__(PART_WG) void k_part_lines(ScanArgs a, const uint64_t *binbase, uint32_t *out)
 {
@@ -1855,8 +1859,8 @@ __global__ __launch_bounds__(PART_WG) void k_part_lines(ScanArgs a, const uint64
     uint32_t *stage = reinterpret_cast<uint32_t *>(stage4);
     const uint32_t nb = a.n_bins, tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
     uint32_t *cnt = part_lds, *cur = cnt + nb, *desc = cur + nb, *gpos = desc + nb;      // desc: stage start | carried records << 14 | records to emit << 18
-    uint32_t *cb = gpos + nb;                                            // [nb][16]: the bins' carried records
-    uint16_t *tfirst = reinterpret_cast<uint16_t *>(cb + (size_t)nb * 16u);
+    uint32_t *cb = gpos + nb;                                            // [nb][PL_CS]: the bins' carried records
+    uint16_t *tfirst = reinterpret_cast<uint16_t *>(cb + (size_t)nb * PL_CS);
     uint16_t *taskbin = tfirst + ((nb + 1u) & ~1u);
     const uint32_t per = (nb + PART_WG - 1u) / PART_WG, b0 = tid * per;
     constexpr uint32_t BPT = 3;                                          // bins a thread owns at most (launch_part: nb <= 3 * PART_WG)
@@ -1985,7 +1989,7 @@ __global__ __launch_bounds__(PART_WG) void k_part_lines(ScanArgs a, const uint64
                     const uint32_t j = j0 + u * GRPS, s0 = dd[u] & 0x3FFFu, c = (dd[u] >> 14) & 15u, e_n = dd[u] >> 18;
                     pp[u] = (((gg[u] >> 4) + (j - tf[u])) << 4) + l16; ee[u] = pp[u] - gg[u];
                     on[u] = on[u] && ee[u] < e_n;
-                    const uint32_t *srcp = ee[u] < c ? cb + (bb[u] * 16u + ee[u]) : stage + (s0 + ee[u] - c);
+                    const uint32_t *srcp = ee[u] < c ? cb + (bb[u] * PL_CS + ee[u]) : stage + (s0 + ee[u] - c);
                     val[u] = on[u] ? *srcp : 0u;
                 }
 #pragma unroll
@@ -2008,7 +2012,7 @@ __global__ __launch_bounds__(PART_WG) void k_part_lines(ScanArgs a, const uint64
 #pragma unroll
         for (uint32_t k = 0; k < BPT; ++k)
             if (k < per && b0 + k < nb) {
-                uint32_t *cbb = cb + (size_t)(b0 + k) * 16u;
+                uint32_t *cbb = cb + (size_t)(b0 + k) * PL_CS;
                 if (E[k]) { for (uint32_t i = 0; i < C[k]; ++i) cbb[i] = stage[S[k] + N[k] - C[k] + i]; }
                 else      { for (uint32_t i = 0; i < N[k]; ++i) cbb[Cold[k] + i] = stage[S[k] + i]; }
             }
@@ -2020,7 +2024,7 @@ __global__ __launch_bounds__(PART_WG) void k_part_lines(ScanArgs a, const uint64
     // ---- the end of the producer's records: what the bins still carry (a last, partial line each)
 #pragma unroll
     for (uint32_t k = 0; k < BPT; ++k)
-        if (k < per && b0 + k < nb) for (uint32_t i = 0; i < C[k]; ++i) out[G[k] + i] = cb[(size_t)(b0 + k) * 16u + i];
+        if (k < per && b0 + k < nb) for (uint32_t i = 0; i < C[k]; ++i) out[G[k] + i] = cb[(size_t)(b0 + k) * PL_CS + i];
 }
 
 // k_part2: second level, one workgroup per bin (bins wider than a region only): the bin's records are counted per
@@ -2972,7 +2976,7 @@ void launch_part(const ScanArgs &a, uint32_t n_prod, const uint64_t *binbase, ui
     static std::atomic<bool> attr_set[MAX_DEV];              // the attribute is per device
     std::atomic<bool> &set = attr_set[cur_device()];
     if (!set.load(std::memory_order_relaxed)) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(k_part), hipFuncAttributeMaxDynamicSharedMemorySize, (int)(BIN_MAX * 12u));
+        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(k_part<PART_WG, BIN_MAX>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)(BIN_MAX * 12u));
         set.store(true, std::memory_order_relaxed);
     }
     // whole-line writes (k_part_lines) wherever the bins' line buffers fit the LDS next to the stage; LIME_PART_LINES=0: comparison runs
@@ -3000,7 +3004,10 @@ void launch_part(const ScanArgs &a, uint32_t n_prod, const uint64_t *binbase, ui
             return;
         }
     }
-    hipLaunchKernelGGL(k_part, dim3(n_prod), dim3(PART_WG), (size_t)a.n_bins * 12u, st, a, binbase, out);
+    if (a.n_bins <= 512u && !(getenv("LIME_PART_WG") && atoi(getenv("LIME_PART_WG")) == 512))
+        hipLaunchKernelGGL((k_part<256, 512>), dim3(n_prod), dim3(256), (size_t)a.n_bins * 12u, st, a, binbase, out);
+    else
+        hipLaunchKernelGGL((k_part<PART_WG, BIN_MAX>), dim3(n_prod), dim3(PART_WG), (size_t)a.n_bins * 12u, st, a, binbase, out);
 }
 
 void launch_part2(const uint32_t *recs, const uint64_t *binbase, uint32_t n_bins, uint32_t bin_shift, uint64_t *regbase,
