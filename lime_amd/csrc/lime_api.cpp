@@ -70,11 +70,6 @@ struct lime_ctx {
     uint32_t *d_tbase = nullptr;            // second level by tiles: tiles before each bin, and the tiles' region index
     uint16_t *d_tidx = nullptr; size_t tidx_cap = 0;
     bool by_tiles = true;                   // LIME_SECOND_LEVEL=sweeps: k_part2 + k_apply instead (comparison runs)
-    bool no_scatter = false;                // LIME_SECOND_LEVEL=noscatter: both levels tile by tile without a bin-major scatter (k_l1_sort / k_l2_sort: measured slower)
-    uint16_t *d_idx1 = nullptr; size_t idx1_cap = 0;          // no-scatter path: the first level's index, the second level's plan
-    uint32_t *d_l2task = nullptr; size_t l2task_cap = 0;
-    void *d_l2tiles = nullptr; uint32_t *d_rowoff = nullptr; size_t l2tile_cap = 0;
-    uint32_t *d_l2totals = nullptr;
     // owner-partitioned exchange: the long clusters' update records of this rank; the owner's regrouped records
     uint64_t *d_bigrec = nullptr; uint32_t *d_bigrec_n = nullptr; uint32_t bigrec_cap = 0;
     uint32_t *d_xrecs = nullptr, *d_xrecs2 = nullptr; size_t xrecs_cap = 0;
@@ -162,7 +157,7 @@ extern "C" int lime_init(int device, lime_ctx **out)
     }
     if (const char *s = getenv("LIME_POOL_DENSITY")) { const double v = atof(s); if (v > 0) { c->pool_density = v; c->pool_density_fixed = true; } }   // tests: force a small pool
     if (const char *s = getenv("LIME_SCAN_STATIC_PCT")) { const long v = atol(s); if (v >= 0 && v <= 100) c->scan_static_pct = (uint32_t)v; }
-    if (const char *s = getenv("LIME_SECOND_LEVEL")) { c->by_tiles = strcmp(s, "sweeps") != 0; c->no_scatter = !strcmp(s, "noscatter"); }
+    if (const char *s = getenv("LIME_SECOND_LEVEL")) c->by_tiles = strcmp(s, "sweeps") != 0;
     if (const char *s = getenv("LIME_PART_SPLIT")) { const long v = atol(s); if (v >= 1 && v <= 16) c->part_split = (uint32_t)v; }
     if (const char *s = getenv("LIME_POOL_SLACK")) { const long v = atol(s); if (v >= 0) c->pool_slack = (uint32_t)v; }
     if (const char *s = getenv("LIME_MAX_BLOCKS")) { long v = atol(s); if (v > 0) c->max_blocks = (uint32_t)v; }
@@ -184,7 +179,6 @@ extern "C" void lime_shutdown(lime_ctx *c)
     (void)hipFree(c->d_totals); (void)hipFree(c->d_binbase); (void)hipFree(c->d_regbase); (void)hipFree(c->d_tbase); (void)hipFree(c->d_tidx);
     if (c->h_xoff) (void)hipHostFree(c->h_xoff);
     if (c->ev_xoff) (void)hipEventDestroy(c->ev_xoff);
-    (void)hipFree(c->d_idx1); (void)hipFree(c->d_l2task); (void)hipFree(c->d_l2tiles); (void)hipFree(c->d_rowoff); (void)hipFree(c->d_l2totals);
     (void)hipFree(c->d_bigrec); (void)hipFree(c->d_bigrec_n); (void)hipFree(c->d_xrecs); (void)hipFree(c->d_xrecs2); (void)hipFree(c->d_xoff); (void)hipFree(c->d_xreg);
     delete c;
 }
@@ -397,31 +391,6 @@ static int ensure_binned(lime_ctx *c, uint64_t n_own, uint32_t n_waves, uint32_t
     return LIME_OK;
 }
 
-// buffers of the no-scatter path (k_l1_sort .. k_l2_sort): grow-only like the rest of the scratch
-static int ensure_two_level(lime_ctx *c, const TwoLevel &g, uint32_t n_waves, uint32_t n_sub, uint32_t *tile_cap_out, hipStream_t st)
-{
-    int rc;
-    const size_t want_idx1 = two_level_idx1_entries(g, n_waves, n_sub);
-    if (want_idx1 > c->idx1_cap) { HIP_TRY(hipStreamSynchronize(st)); if ((rc = regrow(c->d_idx1, want_idx1))) return rc; c->idx1_cap = want_idx1; }
-    const size_t want_task = (size_t)g.n_bins * g.n_groups * 4u + 16u;
-    if (want_task > c->l2task_cap) { HIP_TRY(hipStreamSynchronize(st)); if ((rc = regrow(c->d_l2task, want_task))) return rc; c->l2task_cap = want_task; }
-    const uint32_t tile_cap = two_level_tile_cap(g, n_waves, c->pool_cap);
-    if (tile_cap > c->l2tile_cap) {
-        HIP_TRY(hipStreamSynchronize(st));
-        uint4 *t = reinterpret_cast<uint4 *>(c->d_l2tiles);
-        if ((rc = regrow(t, (size_t)tile_cap))) return rc;
-        c->d_l2tiles = t;
-        if ((rc = regrow(c->d_rowoff, (size_t)tile_cap))) return rc;
-        c->l2tile_cap = tile_cap;
-    }
-    const size_t want_idx2 = (size_t)c->l2tile_cap * (g.f2 + 1u);
-    if (want_idx2 > c->tidx_cap) { HIP_TRY(hipStreamSynchronize(st)); if ((rc = regrow(c->d_tidx, want_idx2))) return rc; c->tidx_cap = want_idx2; }
-    if (!c->d_l2totals) HIP_TRY(hipMalloc(&c->d_l2totals, 4 * sizeof(uint32_t)));
-    if (!c->d_tbase) HIP_TRY(hipMalloc(&c->d_tbase, (BIN_MAX + 2) * sizeof(uint32_t)));
-    *tile_cap_out = (uint32_t)c->l2tile_cap;
-    return LIME_OK;
-}
-
 // The table's bins for the binned update path: one bin per 64 KB region for small tables; else as few levels of fan-out
 // as fit: at most 2048 bins of 2^k regions (the bins' open output lines then merge in the L2), more bins only when k would
 // pass its limit.  A pure function of the table's size (and LIME_BIN_LEVELS): every rank of an exchange gets the same.
@@ -475,8 +444,7 @@ static int fused_dev_impl(lime_ctx *c, const uint32_t *d_lcp, const uint32_t *d_
         if (records_only) return fail(LIME_ERR_ARG, "lime_fused_records_dev: shard too long for 32-bit record positions (cut it in two)");
         binned = false;
     }
-    uint32_t grid = 0, cap_w = 0, n_bins = 0, bin_shift = REGION_SHIFT, n_sub = 1, prod_waves = 0, n_prod = 0, tile_cap = 0;
-    bool two_level = false; TwoLevel tl{};
+    uint32_t grid = 0, cap_w = 0, n_bins = 0, bin_shift = REGION_SHIFT, n_sub = 1, prod_waves = 0, n_prod = 0;
     if (binned) {
         grid = scan_grid(ebwt, 0, 1, n_tiles, c->max_blocks);
         bin_layout(c, sim_bytes, &n_bins, &bin_shift);
@@ -484,11 +452,6 @@ static int fused_dev_impl(lime_ctx *c, const uint32_t *d_lcp, const uint32_t *d_
         prod_waves = part_prod_waves(c, ebwt, n_bins);
         n_prod = grid * (scan_waves_per_wg(ebwt, 0) / prod_waves);
         if ((rc = ensure_binned(c, n_own, grid * scan_waves_per_wg(ebwt, 0), n_prod, n_bins, bin_shift, n_sub, &cap_w, st))) return rc;
-        // two partition levels: tile by tile without a bin-major scatter, unless the records themselves are the result (they
-        // are exchanged grouped by bin) or a comparison run asks for the round-3 kernels
-        two_level = !records_only && bin_shift > REGION_SHIFT && c->by_tiles && c->no_scatter &&
-                    two_level_geometry(sim_bytes, n_sub, grid * scan_waves_per_wg(ebwt, 0), cap_w, &tl);
-        if (two_level && (rc = ensure_two_level(c, tl, grid * scan_waves_per_wg(ebwt, 0), n_sub, &tile_cap, st))) return rc;
     }
     if ((rc = timing_mark(c, st))) return rc;
     if (keep_stats) {
@@ -521,12 +484,7 @@ static int fused_dev_impl(lime_ctx *c, const uint32_t *d_lcp, const uint32_t *d_
     launch_tile(ebwt, 0, a, c->max_blocks, st);
     if ((rc = timing_mark(c, st))) return rc;
     launch_resolve(0, a, st);
-    if (binned && !c->ablate && two_level) {
-        const size_t out_cap8 = c->pool_cap * 2u / 8u;    // 16-bit records the pool holds, in groups of 8
-        launch_two_level(a, grid * scan_waves_per_wg(ebwt, 0), tl, c->d_recs, c->d_idx1, c->d_l2task, c->d_l2tiles, c->d_rowoff, tile_cap,
-                         out_cap8 > 0xFFFFFFFFull ? 0xFFFFFFFFu : (uint32_t)out_cap8, c->d_l2totals, c->d_tbase, c->d_tidx,
-                         reinterpret_cast<uint16_t *>(c->d_pool), d_sim, sim_bytes, st);
-    } else if (binned && !c->ablate) {                   // (timing experiments cut the scan short: nothing to partition)
+    if (binned && !c->ablate) {                          // (timing experiments cut the scan short: nothing to partition)
         launch_bin_rowscan(c->d_counts, c->d_totals, n_bins, n_prod, st);
         launch_scan_tiles(c->d_totals, c->d_binbase, n_bins, reinterpret_cast<unsigned long long *>(c->d_binbase + n_bins), st);
         launch_part(a, n_prod, c->d_binbase, c->d_recs, st);

@@ -61,20 +61,6 @@ constexpr uint32_t BIN_SHIFT_MAX = 25;       // bin-relative cell offset + 7 bit
 constexpr uint32_t CELL_BITS = 40;           // a cell (byte index of the table) has at most this many bits
 constexpr uint32_t MAX_SUB = 8;              // binned updates: a pool record is the cell's low 32 bits, its high part the number of the wave's sub-region: tables up to 32 GB
 constexpr int APPLY_WG = 512;
-// two partition levels without a global scatter (k_l1_sort / k_l2_sort, lime_kernels.hip): coarse bins of 2^shift1 cells, sorted tile
-// by tile; a second-level task = (coarse bin, group of sg scan waves)
-constexpr uint32_t L1_BINS_MAX = 1024;       // coarse bins per sub-region (10 bits of the rank word)
-constexpr uint32_t L2_F2_MAX = 1024;         // 64 KB regions per coarse bin
-struct TwoLevel {
-    uint32_t shift1;                         // coarse bin of a cell = cell >> shift1
-    uint32_t nb_sub;                         // coarse bins per sub-region (one sub-region: all of them)
-    uint32_t n_bins;                         // coarse bins of the table
-    uint32_t f2;                             // regions per coarse bin = 1 << (shift1 - REGION_SHIFT)
-    uint32_t rps;                            // first-level tile rows a segment (wave, sub-region) can have
-    uint32_t tb;                             // tiles whose index entries k_l1_sort buffers in LDS before writing them bin-major
-    uint32_t sg, n_groups;                   // scan waves per second-level task; tasks per coarse bin
-};
-
 constexpr uint32_t BIG_GRID = 32;            // workgroups of k_score_big (each owns a scratch table)
 constexpr size_t BIG_SCRATCH_WORDS = (size_t)HT_SIZE + (size_t)HT_SIZE * 16u + 2u * LIME_MAX_CLUSTER;
 
@@ -132,13 +118,6 @@ void launch_resolve(int mode, const ScanArgs &a, hipStream_t st);
 void launch_apply_by_tiles(uint8_t *sim, size_t sim_bytes, const uint32_t *recs, const uint64_t *binbase, uint32_t n_bins, uint32_t bin_shift,
                            uint32_t *tbase, uint16_t *idx, uint16_t *out16, hipStream_t st);
 uint64_t tiles_bound(uint64_t n_records, uint32_t n_bins);
-// no-scatter path.  two_level_geometry: false when the table does not fit it.  Buffers: idx1 two_level_idx1_entries() 16-bit entries;
-// per task 4 words (tcount, trec8, tfirst, rfirst); tiles / rowoff: tile_cap entries; idx2: tile_cap * (f2 + 1) 16-bit entries; totals: 2 words
-bool two_level_geometry(size_t sim_bytes, uint32_t n_sub, uint32_t n_waves, uint32_t cap_w, TwoLevel *g);
-size_t two_level_idx1_entries(const TwoLevel &g, uint32_t n_waves, uint32_t n_sub);
-uint32_t two_level_tile_cap(const TwoLevel &g, uint32_t n_waves, uint64_t pool_records);
-void launch_two_level(const ScanArgs &a, uint32_t n_waves, const TwoLevel &g, uint32_t *recs, uint16_t *idx1, uint32_t *task_words, void *tiles, uint32_t *rowoff,
-                      uint32_t tile_cap, uint32_t out_cap8, uint32_t *totals, uint32_t *tbase, uint16_t *idx2, uint16_t *out16, uint8_t *sim, size_t sim_bytes, hipStream_t st);
 uint32_t part_tile();
 void launch_regroup(const uint32_t *rx, const uint64_t *srcoff, uint32_t n_src, uint32_t nb, const uint64_t *dstbase, uint32_t *dst, hipStream_t st);
 void launch_apply_bigrecs(const uint64_t *recs, uint64_t n, uint64_t cell_lo, uint64_t cell_hi, uint8_t *block, hipStream_t st);

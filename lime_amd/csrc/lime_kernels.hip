@@ -2199,7 +2199,7 @@ __global__ __launch_bounds__(PART_WG) void k_sort_tiles(const uint32_t *recs, co
 // the other, four 16-bit records per lane and step from 8-byte-aligned loads; the loads of the next four runs are in
 // flight while four are added.
 __global__ __launch_bounds__(APPLY_WG) void k_apply_tiles(uint8_t *sim, size_t sim_bytes, const uint16_t *recs16, const uint32_t *tbase,
-                                                          const uint16_t *idx, uint32_t bin_shift, uint32_t n_regions, const uint32_t *rowoff)
+                                                          const uint16_t *idx, uint32_t bin_shift, uint32_t n_regions)
 {
     constexpr uint32_t RW = (1u << REGION_SHIFT) / 4u;           // words per region
     constexpr uint32_t NWV = APPLY_WG / 64, UR = 4;
@@ -2263,8 +2263,7 @@ __global__ __launch_bounds__(APPLY_WG) void k_apply_tiles(uint8_t *sim, size_t s
                     const uint32_t l = l0 + u;
                     s.fa[u] = l < nl ? rl32(a, l) : 0u; s.fe[u] = l < nl ? rl32(e, l) : 0u;
                     s.q[u] = (s.fa[u] >> 2) + lane;               // this lane's group of four records
-                    // the tile's row of 16-bit records: fixed rows of k_sort_tiles, or rows packed one after the other (k_l2_sort: rowoff, in groups of 8 records)
-                    s.src[u] = rowoff ? recs16 + (l < nl ? (size_t)rowoff[row0 + outer + wave + NWV * l] * 8u : (size_t)0) : recs16 + (size_t)(row0 + outer + wave + NWV * l) * PART_TILE;
+                    s.src[u] = recs16 + (size_t)(row0 + outer + wave + NWV * l) * PART_TILE;
                     s.v[u] = make_uint2(0u, 0u);
                     if (s.q[u] * 4u < s.fe[u]) s.v[u] = *reinterpret_cast<const uint2 *>(s.src[u] + (size_t)s.q[u] * 4u);
                 }
@@ -2312,269 +2311,6 @@ __global__ __launch_bounds__(APPLY_WG) void k_apply_tiles(uint8_t *sim, size_t s
         if (!more) break;
         __syncthreads();                                          // (the region's LDS copy has been read: it may be cleared)
         region = next; row0 = nrow0; n_rows = nrow1 - nrow0; a = na; e = ne;
-    }
-}
-
-// =========================================================================================
-// Round 4: the two partition levels WITHOUT a global scatter.  k_part moves every record to a position of its own in a
-// bin-major array: runs of 7..17 records per bin and tile (partial 64-byte lines: WRITE_SIZE 2x the records' bytes,
-// 0.27..0.29 of the HBM roofline on its own bytes).  Here no record leaves its tile before the last kernel:
-//   k_l1_sort   a workgroup per producer segment (wave, sub-region): every tile of L1_TILE records is sorted by COARSE bin
-//               (cell >> shift1, about a hundred bins) in LDS and written back as a whole row, same place in `out` as in the
-//               pool; where the bins' runs start inside the row goes to idx1[segment][bin][tile];
-//   k_l2_count / k_l2_scan / k_l2_write   the plan of the second level: a task = (coarse bin, group of sg waves); its rows
-//               (the bin's run in every tile of those waves' segments) are cut into TILES of at most L2_SLOTS chunks of 64
-//               records and 512 rows; tiles are numbered bin-major (tbase[bin]) and their 16-bit rows packed (rowoff);
-//   k_l2_sort   a workgroup per tile gathers its rows' runs (a wave-uniform walk over (row, chunk) slots: 32 loads in flight
-//               per wave), sorts the records by 64 KB region in LDS and writes 16-bit offsets + the regions' starts -- the
-//               format k_apply_tiles reads.
-// Bytes per record: 4 read + 4 written, 4 read + 2 written, 2 read -- as before -- but every store is a whole row.
-// =========================================================================================
-constexpr int L1_WG = 1024;
-constexpr uint32_t L1_TILE = 16384, L1_PER = L1_TILE / L1_WG;
-constexpr uint32_t L2_SPW = 32, L2_SLOTS = (PART_WG / 64) * L2_SPW, L2_ROWS = 512, L2_TILE = L2_SLOTS * 64;   // 256 slots of <= 64 records
-static_assert(L1_TILE / 64 <= L2_SLOTS, "one row of the first level must fit a tile of the second");
-static_assert(L2_F2_MAX <= PART_WG * 8 && L1_BINS_MAX <= L1_WG * 8, "part_scan covers 8 counters per thread");
-
-__global__ __launch_bounds__(L1_WG) void k_l1_sort(const uint32_t *pool, const uint32_t *wave_cnt, uint32_t cap_w, TwoLevel g, uint32_t *out, uint16_t *idx1)
-{
-    __shared__ uint4 stage4[L1_TILE / 4];
-    extern __shared__ uint32_t l1_lds[];                                 // cnt[nb + 1], toff[nb + 1], then the buffered index [tb][nb + 1] (16-bit)
-    __shared__ uint32_t wsum[L1_WG / 64];
-    uint32_t *stage = reinterpret_cast<uint32_t *>(stage4);
-    const uint32_t nb = g.nb_sub, tid = threadIdx.x;
-    uint32_t *cnt = l1_lds, *toff = cnt + nb + 1u;
-    uint16_t *ib = reinterpret_cast<uint16_t *>(toff + nb + 1u);
-    const uint32_t seg = blockIdx.x;
-    const uint32_t n = wave_cnt[seg];
-    if (!n) return;
-    const uint32_t *src = pool + (size_t)seg * cap_w;
-    uint32_t *dst = out + (size_t)seg * cap_w;
-    uint16_t *iseg = idx1 + (size_t)seg * (nb + 1u) * g.rps;
-    const uint32_t n_tiles = (n + L1_TILE - 1u) / L1_TILE;
-    for (uint32_t b = tid; b <= nb; b += L1_WG) cnt[b] = 0u;
-    __syncthreads();
-    // (addresses past a partial tile's end are clamped, not predicated: one address form for all lanes)
-    auto load_tile = [&](uint32_t t, uint32_t (&rec)[L1_PER]) {
-        const uint32_t t0 = t * L1_TILE, tn = n - t0 < L1_TILE ? n - t0 : L1_TILE;
-#pragma unroll
-        for (uint32_t j = 0; j < L1_PER; ++j) {
-            const uint32_t i = j * L1_WG + tid;
-            rec[j] = __builtin_nontemporal_load(src + t0 + (i < tn ? i : tn - 1u));
-        }
-    };
-    uint32_t rec[L1_PER];
-    load_tile(0u, rec);
-    uint32_t tb0 = 0;                                                    // first tile of the buffered index block
-    for (uint32_t t = 0; t < n_tiles; ++t) {
-        const uint32_t t0 = t * L1_TILE, tn = n - t0 < L1_TILE ? n - t0 : L1_TILE;
-        // count per bin, prefix, then every record takes the next slot of its bin's cursor (the order inside a bin does not
-        // matter): nothing but the records themselves is held between the two passes
-        uint32_t val[L1_PER];
-#pragma unroll
-        for (uint32_t j = 0; j < L1_PER; ++j) {
-            val[j] = rec[j];
-            if (j * L1_WG + tid < tn) atomicAdd(&cnt[val[j] >> g.shift1], 1u);      // bin < nb: the records of a sub-region lie below nb << shift1
-        }
-        if (t + 1u < n_tiles) load_tile(t + 1u, rec);                    // the next tile's loads are in flight while this one goes through LDS
-        __syncthreads();
-        part_scan<L1_WG>(cnt, toff, nb, wsum);
-#pragma unroll
-        for (uint32_t j = 0; j < L1_PER; ++j)
-            if (j * L1_WG + tid < tn) stage[atomicAdd(&toff[val[j] >> g.shift1], 1u)] = val[j];
-        __syncthreads();
-        // (the cursors have moved to their bins' ends = the next bins' starts)
-        for (uint32_t b = tid; b <= nb; b += L1_WG) ib[(t - tb0) * (nb + 1u) + b] = (uint16_t)(b == 0u ? 0u : b < nb ? toff[b - 1u] : tn);
-        uint4 *d4 = reinterpret_cast<uint4 *>(dst + t0);                 // whole 16-byte groups: cap_w is a multiple of 16 records
-        for (uint32_t i = tid; i < (tn + 3u) / 4u; i += L1_WG) d4[i] = stage4[i];
-        for (uint32_t b = tid; b <= nb; b += L1_WG) cnt[b] = 0u;
-        __syncthreads();
-        const uint32_t nbuf = t + 1u - tb0;
-        if (nbuf == g.tb || t + 1u == n_tiles) {                         // the block's index entries leave bin-major: tile-consecutive per bin
-            for (uint32_t e = tid; e < (nb + 1u) * nbuf; e += L1_WG) {
-                const uint32_t b = e / nbuf, k = e - b * nbuf;
-                iseg[(size_t)b * g.rps + tb0 + k] = ib[k * (nb + 1u) + b];
-            }
-            tb0 = t + 1u;
-            __syncthreads();
-        }
-    }
-}
-
-// row i of task (bin b, group gq): tile i % rps of the segment of wave gq * sg + i / rps in the bin's sub-region
-struct L2Row { uint32_t src, len; };
-__device__ __forceinline__ L2Row l2_row(const TwoLevel &g, const uint32_t *wave_cnt, const uint16_t *idx1, uint32_t cap_w, uint32_t n_waves, uint32_t n_sub,
-                                        uint32_t b, uint32_t gq, uint32_t i)
-{
-    L2Row r; r.src = 0u; r.len = 0u;
-    const uint32_t wv = gq * g.sg + i / g.rps, t = i % g.rps;
-    if (i >= g.sg * g.rps || wv >= n_waves) return r;
-    const uint32_t sub = b / g.nb_sub, lb = b - sub * g.nb_sub, seg = wv * n_sub + sub;
-    const uint32_t n = wave_cnt[seg];
-    if ((uint64_t)t * L1_TILE >= n) return r;
-    const uint16_t *ie = idx1 + ((size_t)seg * (g.nb_sub + 1u) + lb) * g.rps + t;
-    const uint32_t a0 = ie[0], a1 = ie[g.rps];
-    r.src = seg * cap_w + t * L1_TILE + a0; r.len = a1 - a0;
-    return r;
-}
-
-// The cut of a task's rows into tiles (one wave, rows in order): a tile takes rows while it has fewer than L2_ROWS of them and
-// their chunks of 64 records fit L2_SLOTS; tiles without a record are not made.  emit(first row, rows, chunks, records).
-template <typename F>
-__device__ __forceinline__ void l2_cut(const TwoLevel &g, const uint32_t *wave_cnt, const uint16_t *idx1, uint32_t cap_w, uint32_t n_waves, uint32_t n_sub,
-                                       uint32_t b, uint32_t gq, F emit)
-{
-    const uint32_t lane = lane_id(), n_rows = g.sg * g.rps;
-    uint32_t i0 = 0, slots = 0, recs = 0;                                // the open tile: rows [i0, ..), its chunks and records so far
-    for (uint32_t base = 0; base < n_rows; base += 64u) {
-        const L2Row r = l2_row(g, wave_cnt, idx1, cap_w, n_waves, n_sub, b, gq, base + lane);
-        const uint32_t c = (r.len + 63u) >> 6;
-        const uint32_t ci = wave_incl_scan(c), li = wave_incl_scan(r.len);
-        uint32_t k0 = 0, csub = 0, lsub = 0;                             // rows [base + k0, ..) of this chunk are still to place
-        for (;;) {
-            const bool fits = lane >= k0 && slots + (ci - csub) <= L2_SLOTS && base + lane - i0 < L2_ROWS;
-            const uint64_t m = __ballot(fits) >> k0;
-            const uint32_t k = k0 + (m == ~0ull >> k0 ? 64u - k0 : (uint32_t)__builtin_ctzll(~m));     // rows [k0, k) join the open tile
-            if (k > k0) { slots += rl32(ci, k - 1u) - csub; recs += rl32(li, k - 1u) - lsub; csub = rl32(ci, k - 1u); lsub = rl32(li, k - 1u); }
-            if (k >= 64u) break;
-            if (recs) emit(i0, base + k - i0, slots, recs);              // row base + k does not fit: the tile closes in front of it
-            i0 = base + k; slots = 0; recs = 0; k0 = k;
-        }
-    }
-    if (recs) emit(i0, n_rows - i0, slots, recs);
-}
-
-struct L2Tile { uint32_t task, i0, n_rows, n_rec; };                    // 16 bytes; the tile's row of 16-bit records starts at rowoff[tile] * 8
-
-__global__ __launch_bounds__(256) void k_l2_count(const uint32_t *wave_cnt, const uint16_t *idx1, uint32_t cap_w, uint32_t n_waves, uint32_t n_sub, TwoLevel g,
-                                                  uint32_t *tcount, uint32_t *trec8)
-{
-    const uint32_t task = blockIdx.x * 4u + (threadIdx.x >> 6);
-    if (task >= g.n_bins * g.n_groups) return;
-    uint32_t k = 0, r8 = 0;
-    l2_cut(g, wave_cnt, idx1, cap_w, n_waves, n_sub, task / g.n_groups, task % g.n_groups,
-           [&](uint32_t, uint32_t, uint32_t, uint32_t nrec) { ++k; r8 += (nrec + 7u) >> 3; });
-    if (lane_id() == 0) { tcount[task] = k; trec8[task] = r8; }
-}
-
-// exclusive prefix sums of the tasks' tile counts and packed row lengths (one workgroup); the bins' first tiles
-__global__ __launch_bounds__(1024) void k_l2_scan(const uint32_t *tcount, const uint32_t *trec8, uint32_t n_tasks, uint32_t n_groups, uint32_t n_bins,
-                                                  uint32_t *tfirst, uint32_t *rfirst, uint32_t *tbase, uint32_t *totals)
-{
-    __shared__ uint32_t wa[16], wb[16], ca, cb;
-    const uint32_t tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
-    if (tid == 0) { ca = 0u; cb = 0u; }
-    __syncthreads();
-    for (uint32_t base = 0; base < n_tasks; base += 1024u) {
-        const uint32_t i = base + tid;
-        const uint32_t a = i < n_tasks ? tcount[i] : 0u, b = i < n_tasks ? trec8[i] : 0u;
-        const uint32_t ia = wave_incl_scan(a), ibb = wave_incl_scan(b);
-        if (lane == 63u) { wa[wave] = ia; wb[wave] = ibb; }
-        __syncthreads();
-        uint32_t pa = ca, pb = cb;
-        for (uint32_t k = 0; k < wave; ++k) { pa += wa[k]; pb += wb[k]; }
-        if (i < n_tasks) {
-            tfirst[i] = pa + ia - a; rfirst[i] = pb + ibb - b;
-            if (i % n_groups == 0u) tbase[i / n_groups] = pa + ia - a;
-        }
-        __syncthreads();
-        if (tid == 1023u) { ca = pa + ia; cb = pb + ibb; }
-        __syncthreads();
-    }
-    if (tid == 0) { tbase[n_bins] = ca; totals[0] = ca; totals[1] = cb; }
-}
-
-__global__ __launch_bounds__(256) void k_l2_write(const uint32_t *wave_cnt, const uint16_t *idx1, uint32_t cap_w, uint32_t n_waves, uint32_t n_sub, TwoLevel g,
-                                                  const uint32_t *tfirst, const uint32_t *rfirst, uint32_t tile_cap, uint32_t out_cap8, L2Tile *tiles, uint32_t *rowoff, uint32_t *flags)
-{
-    const uint32_t task = blockIdx.x * 4u + (threadIdx.x >> 6);
-    if (task >= g.n_bins * g.n_groups) return;
-    uint32_t tile = tfirst[task], off = rfirst[task];
-    l2_cut(g, wave_cnt, idx1, cap_w, n_waves, n_sub, task / g.n_groups, task % g.n_groups,
-           [&](uint32_t i0, uint32_t nrows, uint32_t, uint32_t nrec) {
-               if (lane_id() == 0) {
-                   // (more tiles or packed rows than the buffers hold -- out of reach with the sizes lime_api.cpp gives them -- fail the pass; a row that
-                   // would not fit is pointed at the buffer's start, so that nothing is read or written outside)
-                   const bool fits = off + ((nrec + 7u) >> 3) <= out_cap8;
-                   if (tile < tile_cap) { L2Tile t; t.task = task; t.i0 = i0; t.n_rows = nrows; t.n_rec = nrec; tiles[tile] = t; rowoff[tile] = fits ? off : 0u; }
-                   if (tile >= tile_cap || !fits) atomicOr(flags, LIME_FLAG_OVERFLOW);
-               }
-               ++tile; off += (nrec + 7u) >> 3;
-           });
-}
-
-__global__ __launch_bounds__(PART_WG) void k_l2_sort(const uint32_t *recs, const uint32_t *wave_cnt, const uint16_t *idx1, uint32_t cap_w, uint32_t n_waves, uint32_t n_sub,
-                                                     TwoLevel g, const L2Tile *tiles, const uint32_t *rowoff, const uint32_t *totals, uint32_t tile_cap,
-                                                     const uint32_t *tbase, uint16_t *idx2, uint16_t *out16)
-{
-    __shared__ uint4 stage4[L2_TILE / 8];                                // the tile's 16-bit offsets, sorted by region
-    __shared__ uint32_t cnt[L2_F2_MAX], toff[L2_F2_MAX];
-    __shared__ uint32_t rsrc[L2_ROWS], rlen[L2_ROWS], cpre[L2_ROWS + 1];
-    __shared__ uint32_t wsum[PART_WG / 64];
-    uint16_t *stage = reinterpret_cast<uint16_t *>(stage4);
-    const uint32_t tid = threadIdx.x, lane = tid & 63u, wave = (uint32_t)__builtin_amdgcn_readfirstlane((int)(tid >> 6));
-    const uint32_t f2 = g.f2, n_tiles = totals[0] < tile_cap ? totals[0] : tile_cap;
-    for (uint32_t tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
-        const L2Tile tl = tiles[tile];
-        const uint32_t b = tl.task / g.n_groups, gq = tl.task % g.n_groups;
-        for (uint32_t i = tid; i < f2; i += PART_WG) cnt[i] = 0u;
-        // ---- the tile's rows: where each run starts, its length, and the chunks of 64 before it
-        {
-            static_assert(L2_ROWS == PART_WG, "a row per thread");
-            L2Row r; r.src = 0u; r.len = 0u;
-            if (tid < tl.n_rows) r = l2_row(g, wave_cnt, idx1, cap_w, n_waves, n_sub, b, gq, tl.i0 + tid);
-            rsrc[tid] = r.src; rlen[tid] = r.len;
-            const uint32_t c = (r.len + 63u) >> 6, ci = wave_incl_scan(c);
-            if (lane == 63u) wsum[wave] = ci;
-            __syncthreads();
-            uint32_t pre = ci - c;
-            for (uint32_t k = 0; k < wave; ++k) pre += wsum[k];
-            cpre[tid] = pre;
-            if (tid == PART_WG - 1u) cpre[L2_ROWS] = pre + c;
-            __syncthreads();
-        }
-        // ---- this wave's chunks: slots wave * L2_SPW ..; the row of its first one by bisection (cpre ascends)
-        uint32_t v[L2_SPW], onm = 0;
-        {
-            const uint32_t s0 = wave * L2_SPW, total = cpre[L2_ROWS];
-            uint32_t lo = 0, hi = L2_ROWS;                               // last row with cpre[row] <= s0
-            while (hi - lo > 1u) { const uint32_t mid = (lo + hi) >> 1; if (cpre[mid] <= s0) lo = mid; else hi = mid; }
-            uint32_t r = (uint32_t)__builtin_amdgcn_readfirstlane((int)lo);
-            uint32_t o = (s0 - (uint32_t)__builtin_amdgcn_readfirstlane((int)cpre[r])) * 64u;
-            uint32_t len = (uint32_t)__builtin_amdgcn_readfirstlane((int)rlen[r]), src = rsrc[r];      // src stays a vector value: 32 scalar address pairs would not fit the SGPRs
-#pragma unroll
-            for (uint32_t k = 0; k < L2_SPW; ++k) {
-                v[k] = 0u;
-                if (s0 + k < total) {                                    // wave-uniform
-                    while (o >= len) {                                   // next row with records (there is one: slots remain)
-                        ++r; o = 0u;
-                        len = (uint32_t)__builtin_amdgcn_readfirstlane((int)rlen[r]); src = rsrc[r];
-                    }
-                    if (o + lane < len) { v[k] = __builtin_nontemporal_load(recs + src + o + lane); onm |= 1u << k; }
-                    o += 64u;
-                }
-            }
-        }
-#pragma unroll
-        for (uint32_t k = 0; k < L2_SPW; ++k)
-            if ((onm >> k) & 1u) atomicAdd(&cnt[(v[k] >> REGION_SHIFT) & (f2 - 1u)], 1u);
-        __syncthreads();
-        part_scan(cnt, toff, f2, wsum);
-#pragma unroll
-        for (uint32_t k = 0; k < L2_SPW; ++k)
-            if ((onm >> k) & 1u) stage[atomicAdd(&toff[(v[k] >> REGION_SHIFT) & (f2 - 1u)], 1u)] = (uint16_t)(v[k] & ((1u << REGION_SHIFT) - 1u));
-        __syncthreads();
-        // the regions' starts inside the tile (the cursors stand at their regions' ends = the next regions' starts): idx2 of the
-        // bin is region-major, tile-consecutive -- what k_apply_tiles reads
-        {
-            const uint32_t row0 = tbase[b], n_rows_bin = tbase[b + 1u] - row0;
-            uint16_t *bidx = idx2 + (size_t)row0 * (f2 + 1u);
-            for (uint32_t i = tid; i <= f2; i += PART_WG)
-                bidx[(size_t)i * n_rows_bin + (tile - row0)] = (uint16_t)(i == 0u ? 0u : i < f2 ? toff[i - 1u] : tl.n_rec);
-        }
-        uint4 *dst = reinterpret_cast<uint4 *>(out16 + (size_t)rowoff[tile] * 8u);
-        for (uint32_t i = tid; i < (tl.n_rec + 7u) / 8u; i += PART_WG) dst[i] = stage4[i];
-        __syncthreads();
     }
 }
 
@@ -3037,78 +2773,10 @@ void launch_apply_by_tiles(uint8_t *sim, size_t sim_bytes, const uint32_t *recs,
     uint32_t resident = slot.load(std::memory_order_relaxed);
     if (!resident) { resident = resident_blocks(k_apply_tiles, APPLY_WG); slot.store(resident, std::memory_order_relaxed); }
     const uint32_t grid = n_regions < resident ? n_regions : resident;
-    hipLaunchKernelGGL(k_apply_tiles, dim3(grid ? grid : 1u), dim3(APPLY_WG), 0, st, sim, sim_bytes, out16, tbase, idx, bin_shift, n_regions, (const uint32_t *)nullptr);
+    hipLaunchKernelGGL(k_apply_tiles, dim3(grid ? grid : 1u), dim3(APPLY_WG), 0, st, sim, sim_bytes, out16, tbase, idx, bin_shift, n_regions);
 }
 uint64_t tiles_bound(uint64_t n_records, uint32_t n_bins) { return n_records / PART_TILE + n_bins; }
 
-// ---- the no-scatter path (k_l1_sort .. k_l2_sort, then k_apply_tiles) ----
-bool two_level_geometry(size_t sim_bytes, uint32_t n_sub, uint32_t n_waves, uint32_t cap_w, TwoLevel *g)
-{
-    // coarse bins: about a hundred (runs of ~100+ records per bin in a first-level tile of 16384), at most L2_F2_MAX regions each
-    uint32_t sh = REGION_SHIFT + 1u;
-    auto bins_at = [&](uint32_t s) { return (uint64_t)((sim_bytes + ((size_t)1 << s) - 1) >> s); };
-    while (sh < REGION_SHIFT + 10u && bins_at(sh) > 160u) ++sh;          // f2 = 2^(sh - 16) <= 1024
-    if (n_sub > 1u && sh > 32u) return false;
-    const uint64_t nb = bins_at(sh);
-    const uint64_t nb_sub = n_sub > 1u ? (1ull << (32u - sh)) : nb;
-    if (nb_sub > L1_BINS_MAX || nb > BIN_MAX) return false;
-    g->shift1 = sh; g->n_bins = (uint32_t)nb; g->nb_sub = (uint32_t)nb_sub; g->f2 = 1u << (sh - REGION_SHIFT);
-    g->rps = (cap_w + L1_TILE - 1u) / L1_TILE;
-    g->rps = (g->rps + 3u) & ~3u;
-    uint32_t tb = 8192u / (g->nb_sub + 1u);
-    g->tb = tb > 32u ? 32u : (tb < 1u ? 1u : tb);
-    // rows per task: as many as give about 3/4 of a second-level tile's chunks -- a row (one bin's run of a first-level tile) has
-    // L1_TILE / nb_sub records when the tile is full -- and at most L2_ROWS
-    const uint32_t run = L1_TILE / g->nb_sub ? L1_TILE / g->nb_sub : 1u, chunks = (run + 63u) / 64u;
-    uint32_t rows = (L2_SLOTS * 3u / 4u) / chunks;
-    if (rows > L2_ROWS) rows = L2_ROWS;
-    uint32_t sg = rows / g->rps;
-    if (sg < 1u) sg = 1u;
-    g->sg = sg; g->n_groups = (n_waves + sg - 1u) / sg;
-    return true;
-}
-size_t two_level_idx1_entries(const TwoLevel &g, uint32_t n_waves, uint32_t n_sub) { return (size_t)n_waves * n_sub * (g.nb_sub + 1u) * g.rps + 64u; }
-uint32_t two_level_tile_cap(const TwoLevel &g, uint32_t n_waves, uint64_t pool_records)
-{
-    // a tile closed because the next row did not fit holds, with that row, more than L2_SLOTS chunks, and a row is counted twice at most;
-    // chunks <= records / 64 + non-empty rows; plus one open tile per task and the cuts at L2_ROWS rows
-    const uint64_t rows = (uint64_t)g.n_bins * n_waves * g.rps, tasks = (uint64_t)g.n_bins * g.n_groups;
-    const uint64_t cap = tasks * (1u + (uint64_t)g.sg * g.rps / L2_ROWS) + 2u * (pool_records / 64u + rows) / L2_SLOTS + 16u;
-    return cap > 0x7FFFFFFFull ? 0x7FFFFFFFu : (uint32_t)cap;
-}
-void launch_two_level(const ScanArgs &a, uint32_t n_waves, const TwoLevel &g, uint32_t *recs, uint16_t *idx1, uint32_t *task_words, void *tiles, uint32_t *rowoff,
-                      uint32_t tile_cap, uint32_t out_cap8, uint32_t *totals, uint32_t *tbase, uint16_t *idx2, uint16_t *out16, uint8_t *sim, size_t sim_bytes, hipStream_t st)
-{
-    static std::atomic<bool> attr_set[MAX_DEV];
-    std::atomic<bool> &set = attr_set[cur_device()];
-    if (!set.load(std::memory_order_relaxed)) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(k_l1_sort), hipFuncAttributeMaxDynamicSharedMemorySize, (int)(8u * (L1_BINS_MAX + 1u) + 2u * 8192u + 64u));
-        set.store(true, std::memory_order_relaxed);
-    }
-    const uint32_t n_segs = n_waves * a.n_sub, n_tasks = g.n_bins * g.n_groups;
-    const size_t l1_lds = 8u * ((size_t)g.nb_sub + 1u) + 2u * (size_t)g.tb * (g.nb_sub + 1u) + 16u;
-    hipLaunchKernelGGL(k_l1_sort, dim3(n_segs), dim3(L1_WG), l1_lds, st, a.pool, a.wave_cnt, a.cap_w, g, recs, idx1);
-    uint32_t *tcount = task_words, *trec8 = tcount + n_tasks, *tfirst = trec8 + n_tasks, *rfirst = tfirst + n_tasks;
-    hipLaunchKernelGGL(k_l2_count, dim3((n_tasks + 3u) / 4u), dim3(256), 0, st, a.wave_cnt, idx1, a.cap_w, n_waves, a.n_sub, g, tcount, trec8);
-    hipLaunchKernelGGL(k_l2_scan, dim3(1), dim3(1024), 0, st, tcount, trec8, n_tasks, g.n_groups, g.n_bins, tfirst, rfirst, tbase, totals);
-    hipLaunchKernelGGL(k_l2_write, dim3((n_tasks + 3u) / 4u), dim3(256), 0, st, a.wave_cnt, idx1, a.cap_w, n_waves, a.n_sub, g, tfirst, rfirst, tile_cap, out_cap8,
-                       reinterpret_cast<L2Tile *>(tiles), rowoff, &a.stats->flags);
-    static std::atomic<uint32_t> res_sort[MAX_DEV], res_apply[MAX_DEV];
-    auto resident_cached = [&](std::atomic<uint32_t> (&arr)[MAX_DEV], auto kernel, int wg) {
-        std::atomic<uint32_t> &slot = arr[cur_device()];
-        uint32_t r = slot.load(std::memory_order_relaxed);
-        if (!r) { r = resident_blocks(kernel, wg); slot.store(r, std::memory_order_relaxed); }
-        return r;
-    };
-    const uint32_t rs = resident_cached(res_sort, k_l2_sort, PART_WG);
-    const uint32_t sort_grid = tile_cap < 4u * rs ? tile_cap : 4u * rs;
-    hipLaunchKernelGGL(k_l2_sort, dim3(sort_grid ? sort_grid : 1u), dim3(PART_WG), 0, st, recs, a.wave_cnt, idx1, a.cap_w, n_waves, a.n_sub, g,
-                       reinterpret_cast<const L2Tile *>(tiles), rowoff, totals, tile_cap, tbase, idx2, out16);
-    const uint32_t n_regions = (uint32_t)((sim_bytes + ((size_t)1 << REGION_SHIFT) - 1) >> REGION_SHIFT);
-    const uint32_t ra = resident_cached(res_apply, k_apply_tiles, APPLY_WG);
-    const uint32_t grid = n_regions < ra ? n_regions : ra;
-    hipLaunchKernelGGL(k_apply_tiles, dim3(grid ? grid : 1u), dim3(APPLY_WG), 0, st, sim, sim_bytes, out16, tbase, idx2, g.shift1, n_regions, rowoff);
-}
 uint32_t part_tile() { return PART_TILE; }
 
 void launch_regroup(const uint32_t *rx, const uint64_t *srcoff, uint32_t n_src, uint32_t nb, const uint64_t *dstbase, uint32_t *dst, hipStream_t st)
