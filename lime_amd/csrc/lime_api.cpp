@@ -818,17 +818,54 @@ static int score_dev_impl(lime_ctx *c, const uint32_t *d_da, const uint8_t *d_eb
         c->big_cap = (uint32_t)(n_clusters + 16);
     }
     c->last.valid = false;
-    HIP_TRY(hipMemsetAsync(c->d_stats, 0, sizeof(DevStats), st));
-    if (zero_sim) HIP_TRY(hipMemsetAsync(d_sim, 0, lime_sim_bytes(n_reads, n_refs), st));
-    if (!n_clusters) return LIME_OK;
-    ScanArgs a = base_args(c, nullptr, d_da, d_ebwt, n, n, 1, n_reads, n_refs, 0, d_sim);
-    a.pos_base = pos_base;
     const int ebwt = d_ebwt != nullptr;
+    const size_t sim_bytes = lime_sim_bytes(n_reads, n_refs);
     uint64_t batches = (n_clusters + 255) / 256;          // 64 clusters per wave, 4 waves per workgroup
-    uint32_t blocks = (uint32_t)(batches < c->list_blocks ? batches : c->list_blocks);
-    launch_score_list(ebwt, a, d_clusters, n_clusters, blocks, st);
-    launch_score_big(ebwt, a, c->d_big_scratch, st);
-    HIP_TRY(hipGetLastError());
+    // Binned updates for the list flow too (round 4; ClusterBWT_DA.cpp:301-340 with the arrays resident): the table is built from
+    // scratch (zero_sim) and 16-byte aligned.  A pool that proves too small (the list says nothing about its update density) is found out right here --
+    // the call waits for the pass -- and the list is scored again by compare-and-swap.
+    bool binned = zero_sim && n_clusters && !pos_base && !misaligned(d_sim, 16) && sim_bytes >= (1u << 20) &&
+                  sim_bytes <= ((size_t)BIN_MAX << BIN_SHIFT_MAX) && sim_bytes < (1ull << CELL_BITS) && sim_bytes <= ((uint64_t)MAX_SUB << 32) &&
+                  c->upd_pref == 1;
+    // (only when asked for, LIME_UPDATE_PATH=bin: measured with the arrays resident -- tools/bench_list.py, clustered generator, 306 MB table -- the
+    // list flow is bound by its per-cluster gather of da / ebwt, not by its updates: 1e8 symbols, 1.7e7 updates 1.09 ms by compare-and-swap
+    // against 1.33 binned; 4e8 symbols, 6.6e7 updates 4.25 against 4.56)
+    for (int attempt = 0; attempt < 2; ++attempt) {
+        HIP_TRY(hipMemsetAsync(c->d_stats, 0, sizeof(DevStats), st));
+        if (zero_sim && !binned) HIP_TRY(hipMemsetAsync(d_sim, 0, sim_bytes, st));
+        if (!n_clusters) return LIME_OK;
+        ScanArgs a = base_args(c, nullptr, d_da, d_ebwt, n, n, 1, n_reads, n_refs, 0, d_sim);
+        a.pos_base = pos_base;
+        uint32_t blocks = (uint32_t)(batches < c->list_blocks ? batches : c->list_blocks);
+        uint32_t n_bins = 0, bin_shift = REGION_SHIFT, n_sub = 1, cap_w = 0;
+        if (binned) {
+            if (blocks > 1024u) blocks = 1024u;           // fewer, longer producers: a partition workgroup per scoring workgroup
+            bin_layout(c, sim_bytes, &n_bins, &bin_shift);
+            n_sub = (uint32_t)((sim_bytes + 0xFFFFFFFFull) >> 32);
+            if (((double)n * sizing_density(c) * 1.35 + 512.0 * 4096.0) * n_sub > 3.9e9) { binned = false; --attempt; continue; }   // 32-bit record positions
+            if ((rc = ensure_binned(c, n, blocks * (SCAN_WG / 64), blocks, n_bins, bin_shift, n_sub, &cap_w, st))) return rc;
+            a.upd_mode = 1; a.pool = c->d_pool; a.cap_w = cap_w; a.n_sub = n_sub; a.wave_cnt = c->d_wave_cnt; a.counts = c->d_counts;
+            a.n_bins = n_bins; a.bin_shift = bin_shift; a.prod_waves = SCAN_WG / 64;
+            a.sub_rb = 0xFFFFFFFFu; a.sub_gb = 0u;
+            if (n_sub == 2) { a.sub_rb = (uint32_t)((1ull << 32) / n_refs); a.sub_gb = (uint32_t)((1ull << 32) - (uint64_t)a.sub_rb * n_refs); }
+        }
+        launch_score_list(ebwt, a, d_clusters, n_clusters, blocks, st);
+        if (binned) {
+            launch_bin_rowscan(c->d_counts, c->d_totals, n_bins, blocks, st);
+            launch_scan_tiles(c->d_totals, c->d_binbase, n_bins, reinterpret_cast<unsigned long long *>(c->d_binbase + n_bins), st);
+            launch_part(a, blocks, c->d_binbase, c->d_recs, st);
+            if (bin_shift > REGION_SHIFT) launch_apply_by_tiles(d_sim, sim_bytes, c->d_recs, c->d_binbase, n_bins, bin_shift, c->d_tbase, c->d_tidx,
+                                                                reinterpret_cast<uint16_t *>(c->d_pool), st);
+            else launch_apply(d_sim, sim_bytes, c->d_recs, c->d_binbase, bin_shift, st);
+        }
+        launch_score_big(ebwt, a, c->d_big_scratch, st);  // (after the table is built: its compare-and-swaps add to it)
+        HIP_TRY(hipGetLastError());
+        if (!binned) break;
+        lime_stats_t s;
+        if ((rc = read_stats(c, &s, st))) return rc;      // waits for the pass
+        if (!(s.flags & LIME_FLAG_POOL_FULL)) break;
+        binned = false;                                   // the table is incomplete: again, by compare-and-swap
+    }
     return LIME_OK;
 }
 

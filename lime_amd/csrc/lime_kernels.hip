@@ -691,9 +691,8 @@ __device__ __forceinline__ uint32_t cluster_general(const uint32_t *da, const ui
 
 // all clusters filed in the wave's list; returns the number of table cells incremented (per lane)
 template <int EBWT, typename LDS>
-__device__ __forceinline__ uint32_t score_lists(LDS &L, const ScanArgs &a, uint32_t nA)
+__device__ __forceinline__ uint32_t score_lists(LDS &L, UpdQueue &qu, const ScanArgs &a, uint32_t nA)
 {
-    UpdQueue qu; qu.qr = L.q_read; qu.qg = L.q_gen; qu.n = 0; qu.cap = QCAP;
     uint32_t nupd = 0, nD = 0;
     for (uint32_t k0 = 0; k0 < nA; k0 += 64u) nupd += cluster_pairs<EBWT>(L, qu, a, L.listA, nA, k0, nD);
     for (uint32_t k0 = 0; k0 < nD; k0 += 64u) {
@@ -2365,17 +2364,33 @@ __global__ __launch_bounds__(APPLY_WG) void k_apply(uint8_t *sim, size_t sim_byt
 // (each <= SMALL_MAX long) side by side into its LDS, files them under their length class and
 // runs the same scoring routines as the scan; longer clusters are pushed to the big list.
 // =========================================================================================
-template <int EBWT>
+// BIN (round 4; device-resident arrays, the table to be built from scratch): the updates leave as 4-byte records through the
+// same drains, line buffers and per-bin counts as the scan's (a workgroup = one producer of k_part), instead of
+// compare-and-swaps at the memory-side atomic rate -- the two-program flow on text-like density: 4.3 ms per 1e8 symbols.
+template <int EBWT, int BIN>
 __global__ __launch_bounds__(SCAN_WG) void k_score_list(ScanArgs a, const lime_cluster_t *list, uint64_t n_list)
 {
     __shared__ WaveLds<64 * SMALL_MAX> lds[SCAN_WG / 64];
     __shared__ uint32_t c_off[SCAN_WG / 64][65];
+    __shared__ uint32_t hist[BIN ? BIN_MAX : 1], bq_sub_n[SCAN_WG / 64][MAX_SUB + 1], bq_lfill[SCAN_WG / 64][2], bq_lbuf[SCAN_WG / 64][BIN ? 2 * LBUF : 2], wg_done_s;
     const uint32_t lane = lane_id(), wave = (uint32_t)__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));   // wave-uniform: LDS bases stay scalar
     WaveLds<64 * SMALL_MAX> &L = lds[wave];
     uint32_t *off = c_off[wave];
     const uint64_t n_batches = (n_list + 63u) / 64u, stride = (uint64_t)gridDim.x * (SCAN_WG / 64);
     const uint64_t lt = (1ull << lane) - 1ull;
     uint32_t acc_upd = 0;
+    UpdQueue qu; qu.qr = L.q_read; qu.qg = L.q_gen; qu.n = 0; qu.cap = QCAP;
+    if (BIN) {
+        for (uint32_t i = threadIdx.x; i < BIN_MAX; i += SCAN_WG) hist[i] = 0u;
+        if (threadIdx.x == 0) wg_done_s = 0u;
+        const uint32_t wave_gid = blockIdx.x * (SCAN_WG / 64) + wave;
+        qu.async = true; qu.binned = true;
+        qu.out = cold(a).pool + (size_t)wave_gid * cold(a).n_sub * cold(a).cap_w; qu.hist = hist;
+        qu.sub_n = (lds_vu32 *)bq_sub_n[wave]; qu.lbuf = bq_lbuf[wave]; qu.lfill = (lds_vu32 *)bq_lfill[wave];
+        if (lane <= MAX_SUB) bq_sub_n[wave][lane] = 0u;               // ([MAX_SUB]: the producer group's offset in the histogram: one group)
+        if (lane < 2u) bq_lfill[wave][lane] = 0u;
+        __syncthreads();
+    }
     for (uint64_t b = (uint64_t)blockIdx.x * (SCAN_WG / 64) + wave; b < n_batches; b += stride) {
         const uint64_t c = b * 64u + lane;
         uint64_t ps = 0, len = 0;
@@ -2411,7 +2426,25 @@ __global__ __launch_bounds__(SCAN_WG) void k_score_list(ScanArgs a, const lime_c
         const uint16_t item = (uint16_t)(my_off | ((len32 - 1u) << 12));
         const uint64_t mA = __ballot(cA);
         if (cA) L.listA[(uint32_t)__popcll(mA & lt)] = item;
-        acc_upd += score_lists<EBWT>(L, a, (uint32_t)__popcll(mA));
+        acc_upd += score_lists<EBWT>(L, qu, a, (uint32_t)__popcll(mA));
+    }
+    if (BIN) {                                                        // the records still waiting for their line; this wave's counts; the workgroup's histogram
+        const uint32_t n_sub = cold(a).n_sub, cap_w = cold(a).cap_w;
+        if (n_sub <= 2u) drain_lines(qu, a, true);
+        if (lane < n_sub) {
+            const uint32_t n = qu.sub_n[lane];
+            cold(a).wave_cnt[(size_t)(blockIdx.x * (SCAN_WG / 64) + wave) * n_sub + lane] = n < cap_w ? n : cap_w;
+            atomicMax(&cold(a).stats->wave_records_max, n);
+            if (n > cap_w) atomicOr(&cold(a).stats->flags, LIME_FLAG_POOL_FULL);
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+        uint32_t old = 0;
+        if (lane == 0) old = atomicAdd(&wg_done_s, 1u);
+        old = (uint32_t)__builtin_amdgcn_readfirstlane((int)old);
+        if (old == SCAN_WG / 64 - 1) {
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+            for (uint32_t bb = lane; bb < cold(a).n_bins; bb += 64u) cold(a).counts[(size_t)bb * gridDim.x + blockIdx.x] = hist[bb];
+        }
     }
     const uint32_t tu = wave_sum(acc_upd);
     if (lane == 0 && tu) atomicAdd(&a.stats->n_updates, (unsigned long long)tu);
@@ -2822,8 +2855,13 @@ void launch_scan_tiles(const uint32_t *cnt, uint64_t *off, uint32_t n, unsigned 
 
 void launch_score_list(int ebwt, const ScanArgs &a, const lime_cluster_t *list, uint64_t count, uint32_t blocks, hipStream_t st)
 {
-    if (ebwt) hipLaunchKernelGGL((k_score_list<1>), dim3(blocks), dim3(SCAN_WG), 0, st, a, list, count);
-    else      hipLaunchKernelGGL((k_score_list<0>), dim3(blocks), dim3(SCAN_WG), 0, st, a, list, count);
+    if (a.upd_mode) {
+        if (ebwt) hipLaunchKernelGGL((k_score_list<1, 1>), dim3(blocks), dim3(SCAN_WG), 0, st, a, list, count);
+        else      hipLaunchKernelGGL((k_score_list<0, 1>), dim3(blocks), dim3(SCAN_WG), 0, st, a, list, count);
+    } else {
+        if (ebwt) hipLaunchKernelGGL((k_score_list<1, 0>), dim3(blocks), dim3(SCAN_WG), 0, st, a, list, count);
+        else      hipLaunchKernelGGL((k_score_list<0, 0>), dim3(blocks), dim3(SCAN_WG), 0, st, a, list, count);
+    }
 }
 
 void launch_score_big(int ebwt, const ScanArgs &a, uint32_t *scratch, hipStream_t st)

@@ -259,3 +259,67 @@ def test_stream_chunks_stay_off_the_binned_path(monkeypatch):
             assert (gnc, gml) == (nc, ml) and np.array_equal(sim, exp)
     finally:
         c.close()
+
+
+# ---- the list flow (lime_score_dev: clusters from a .clrs list, arrays resident) on the binned path (round 4) -------------
+def _score_dev(ctx, da, eb, cl, nr, ng, poison=0xA5):
+    import torch
+    import lime_amd
+    dev = torch.device("cuda", 0)
+    td = torch.from_numpy(da.view(np.int32)).to(dev)
+    te = None if eb is None else torch.from_numpy(eb).to(dev)
+    tc = torch.from_numpy(np.ascontiguousarray(cl).view(np.int64).reshape(-1)).to(dev) if len(cl) else torch.zeros(2, dtype=torch.int64, device=dev)
+    sim = torch.full((lime_amd.sim_bytes(nr, ng),), poison, dtype=torch.uint8, device=dev)     # every byte must be written
+    ctx.score_dev(td, te, len(da), tc.data_ptr(), len(cl), nr, ng, sim, True)
+    s, rc = ctx.stats()
+    torch.cuda.synchronize()
+    return sim[:nr * ng].cpu().numpy().reshape(nr, ng), s, rc
+
+
+@pytest.mark.parametrize("n,nr,ng,mode", [
+    (300001, 200, 9, 1),
+    (2000003, 5000, 120, 0),          # 600 KB table (below the 1 MB limit of the binned path: compare-and-swap, same result)
+    (2500000, 30000, 90, 1),          # 2.7 MB table, one level
+    (3000000, 40000, 700, 1),         # 28 MB table, 214 regions
+])
+def test_list_scoring_on_the_binned_path_vs_oracle(bctx, n, nr, ng, mode):
+    """ClusterBWT_DA.cpp:301-340 with the arrays on the device: k_score_list emits records, k_part -> k_apply build the table,
+    k_score_big adds the long clusters; the clusters in the list's (shuffled) order"""
+    lcp, da, eb = O.synth(4000 + n, 0, n, nr, ng, 16, mode)
+    lcp[n // 2:n // 2 + 900] = 40                              # a long cluster for k_score_big
+    cl, nc, ml = O.detect(lcp, da, nr, 16)
+    rng = np.random.default_rng(5)
+    cls = cl[rng.permutation(len(cl))]
+    for e in (eb, None):
+        exp = O.score(da, e, cl, nr, ng, threads=4)
+        got, s, rc = _score_dev(bctx, da, e, cls, nr, ng)
+        assert rc == 0
+        assert np.array_equal(got, exp)
+        assert (s.wave_records_max > 0) == (nr * ng >= (1 << 20)), "the binned path is taken from 1 MB of table on"
+
+
+
+def test_list_scoring_binned_with_second_level_and_small_pool(monkeypatch):
+    """forced second level (bins of several regions) and a pool far too small: the pass is found incomplete inside the call and the list
+    scored again by compare-and-swap -- same table"""
+    import lime_amd
+    n, nr, ng = 1500000, 40000, 700
+    lcp, da, eb = O.synth(77, 0, n, nr, ng, 16, 1)
+    cl, nc, ml = O.detect(lcp, da, nr, 16)
+    exp = O.score(da, eb, cl, nr, ng, threads=4)
+    monkeypatch.setenv("LIME_UPDATE_PATH", "bin")
+    monkeypatch.setenv("LIME_BIN_LEVELS", "4,7")
+    c = lime_amd.Context()
+    try:
+        got, s, rc = _score_dev(c, da, eb, cl, nr, ng)
+        assert rc == 0 and np.array_equal(got, exp)
+    finally:
+        c.close()
+    monkeypatch.delenv("LIME_BIN_LEVELS")
+    monkeypatch.setenv("LIME_POOL_DENSITY", "0.0005"); monkeypatch.setenv("LIME_POOL_SLACK", "0")
+    c = lime_amd.Context()
+    try:
+        got, s, rc = _score_dev(c, da, eb, cl, nr, ng)
+        assert rc == 0 and np.array_equal(got, exp)
+    finally:
+        c.close()
