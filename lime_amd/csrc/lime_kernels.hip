@@ -1812,7 +1812,7 @@ __global__ __launch_bounds__(WGS) void k_part(ScanArgs a, const uint64_t *binbas
             for (uint32_t j = 0; j < PART_PER / 4; ++j) v4[j] = rv[j];
             count_tile(tnext, v4);
             tn_ = next_tile(tnext);
-            if (tn_.any) load_tile(tn_, rv);                             // ... and the one after it is on its way
+            if (tn_.any) load_tile(tn_, rv);                             // ... and the one after it is on its way (in front of this tile's stores: behind them -- what helps k_part_lines -- configs[2] 468 -> 497 us: here the stores are many requests, and the loads queue behind them)
         }
         PP(5)
         // ---- ... while this one leaves LDS, four slots a lane: consecutive positions as one 16-byte store
@@ -1970,6 +1970,16 @@ __global__ __launch_bounds__(PART_WG) void k_part_lines(ScanArgs a, const uint64
         PP(3)
         __syncthreads();
         PP(4)
+        // ---- the next tile is counted now (only the counters are touched; its records were loaded a tile ago) -- BEFORE this tile's lines are
+        // stored: the wait for loaded registers is a wait for every older memory operation of the wave, and right behind the stores it was a wait
+        // for their round trip (23 % of the kernel's cycles, tools/r04_part_phases.sh)
+        const Tile tnext = tn_;
+        if (tnext.any) {
+#pragma unroll
+            for (uint32_t j = 0; j < PART_PER / 4; ++j) v4[j] = rv[j];
+            count_tile(tnext, v4);
+        }
+        PP(5)
         // ---- a line per 16-lane group: element e of the bin's stream (its carried records, then the tile's) goes to g + e
         {
             // (four lines a turn: each is a chain of dependent LDS reads -- task -> bin -> its descriptors -> the record -- and one at a
@@ -1995,13 +2005,9 @@ __global__ __launch_bounds__(PART_WG) void k_part_lines(ScanArgs a, const uint64
                 for (uint32_t u = 0; u < UT; ++u) if (on[u]) out[pp[u]] = val[u];
             }
         }
-        PP(5)
-        // ---- the next tile is counted now (only the counters are touched) ...
-        const Tile tnext = tn_;
+
+        // ---- ... and the tile after it is on its way (behind the stores: by the time its registers are waited for, both are long done)
         if (tnext.any) {
-#pragma unroll
-            for (uint32_t j = 0; j < PART_PER / 4; ++j) v4[j] = rv[j];
-            count_tile(tnext, v4);
             tn_ = next_tile(tnext);
             if (tn_.any) load_tile(tn_, rv);
         }
