@@ -135,3 +135,14 @@ def test_combine_edges_host_logic():
     assert rc(HEAD | OPEN | OR, LR) == 0
     assert rc(HEAD | LR | LG, HEAD | LR | LG) == 0                    # leading content without an open run: nothing
     assert rc(HEAD | OPEN | OG, HEAD | LG | OPEN | OR, HEAD | LR) == 0  # two separate long runs
+
+
+def test_scan_resources():
+    """the scan kernels' register / LDS budget (tools/kres.py --gate through `make resources`): planned waves per SIMD, no VGPR spills or
+    scratch, the LDS of one workgroup fits a CU.  A performance property: gated here, not in the build."""
+    import shutil
+    import subprocess
+    if not shutil.which("hipcc") and not os.path.exists("/opt/rocm/bin/hipcc"):
+        pytest.skip("no hipcc")
+    r = subprocess.run(["make", "-C", os.path.join(ROOT, "lime_amd", "csrc"), "-s", "resources"], capture_output=True, timeout=600)
+    assert r.returncode == 0, r.stdout.decode()[-2000:]

@@ -20,11 +20,11 @@ if "--gate" in sys.argv:
     for name, r in out.items():
         if "k_scanI" not in name: continue
         ebwt = "k_scanILi1" in name
-        want_waves = 3 if ebwt else 4
+        want_waves = 4 if (not ebwt or "k_scanILi1ELi0ELi1" in name) else 3     # EBWT=1: the record-emitting scan runs 16 waves per CU, the compare-and-swap one 12
         if r["vgpr_spill"] or r["scratch"]: bad.append(f"{name}: VGPR spills / scratch")
         if r["waves_by_vgpr"] < want_waves: bad.append(f"{name}: {r['vgpr']} VGPRs allow {r['waves_by_vgpr']} waves per SIMD, planned {want_waves}")
         if r["lds"] > 160 * 1024: bad.append(f"{name}: {r['lds']} B of LDS do not fit a CU (one workgroup per CU)")
-        if r["sgpr_spill"] > (12 if ebwt else 0): bad.append(f"{name}: {r['sgpr_spill']} SGPR spills")
+        if r["sgpr_spill"] > (12 if ebwt else 2): bad.append(f"{name}: {r['sgpr_spill']} SGPR spills")     # (SGPR spills go to VGPR lanes: harmless; EBWT=0: one since the producer groups of round 4)
     if bad:
         print("RESOURCE GATE FAILED:\n  " + "\n  ".join(bad)); sys.exit(1)
     print("resource gate ok")
