@@ -323,3 +323,28 @@ def test_list_scoring_binned_with_second_level_and_small_pool(monkeypatch):
         assert rc == 0 and np.array_equal(got, exp)
     finally:
         c.close()
+
+
+def test_whole_line_partition_on_a_table_of_two_sub_regions(monkeypatch):
+    """k_part_lines (bins few enough for their line buffers: forced here, 298 bins of 256 regions) on a 5 GB table: the cells beyond 4 GB
+    come from the waves' second sub-regions (bin = record >> shift + the sub-region's offset); binned table == compare-and-swap table"""
+    import torch
+    import lime_amd
+    n, nr, ng = 30_000_000, 1_000_000, 5000
+    dev = torch.device("cuda", 0)
+    lcp = torch.empty(n, dtype=torch.int32, device=dev); da = torch.empty_like(lcp)
+    tabs = []
+    for path, levels in (("cas", None), ("bin", "1024,512")):
+        monkeypatch.setenv("LIME_UPDATE_PATH", path)
+        if levels: monkeypatch.setenv("LIME_BIN_LEVELS", levels)
+        c = lime_amd.Context()
+        try:
+            c.synth_dev(9, 0, n, nr, ng, 16, 0, lcp, da, None)
+            sim = torch.empty(lime_amd.sim_bytes(nr, ng), dtype=torch.uint8, device=dev)
+            c.fused_dev(lcp, da, None, n, n, True, nr, ng, 16, sim, True)
+            s, rc = c.stats()
+            assert rc == 0 and (s.wave_records_max > 0) == (path == "bin")
+            tabs.append((sim, int(s.n_updates)))
+        finally:
+            c.close()
+    assert tabs[0][1] == tabs[1][1] and torch.equal(tabs[0][0], tabs[1][0])
