@@ -2779,7 +2779,7 @@ void launch_part(const ScanArgs &a, uint32_t n_prod, const uint64_t *binbase, ui
             return;
         }
     }
-    if (a.n_bins <= 512u && !(getenv("LIME_PART_WG") && atoi(getenv("LIME_PART_WG")) == 512))
+    if (a.n_bins <= 512u && getenv("LIME_PART_WG") && atoi(getenv("LIME_PART_WG")) == 256)      // comparison runs only: measured no faster on small inputs, 1.5 x slower on large ones
         hipLaunchKernelGGL((k_part<256, 512>), dim3(n_prod), dim3(256), (size_t)a.n_bins * 12u, st, a, binbase, out);
     else
         hipLaunchKernelGGL((k_part<PART_WG, BIN_MAX>), dim3(n_prod), dim3(PART_WG), (size_t)a.n_bins * 12u, st, a, binbase, out);
