@@ -25,6 +25,23 @@ if "--gate" in sys.argv:
         if r["waves_by_vgpr"] < want_waves: bad.append(f"{name}: {r['vgpr']} VGPRs allow {r['waves_by_vgpr']} waves per SIMD, planned {want_waves}")
         if r["lds"] > 160 * 1024: bad.append(f"{name}: {r['lds']} B of LDS do not fit a CU (one workgroup per CU)")
         if r["sgpr_spill"] > (12 if ebwt else 2): bad.append(f"{name}: {r['sgpr_spill']} SGPR spills")     # (SGPR spills go to VGPR lanes: harmless; EBWT=0: one since the producer groups of round 4)
+    # the v_writelane of the scan's mask words sits in inline assembly with its own wait states (a VALU write of an SGPR / VCC
+    # followed at once by a v_writelane reading it took the PREVIOUS value; the compiler's hazard recognizer does not see into the assembly):
+    # every v_writelane_b32 must follow an s_nop or another v_writelane directly, and no DPP operation or v_readlane may follow one at once
+    # (only the hand-written ones, between the compiler's ;;#ASMSTART / ;;#ASMEND marks: its own v_writelanes -- SGPR spills -- get their wait states from it)
+    in_asm, prev, chk_next = False, "", False
+    for l in txt.split("\n"):
+        t = l.strip()
+        if "#ASMSTART" in t: in_asm = True; continue
+        if "#ASMEND" in t: in_asm = False; continue
+        if not t or t.startswith((";", ".", "#")) or t.endswith(":"): continue
+        if chk_next:
+            if "_dpp" in t or t.startswith("v_readlane"): bad.append(f"`{t.split()[0]}` directly behind a hand-written v_writelane_b32")
+            chk_next = False
+        if in_asm and t.startswith("v_writelane_b32"):
+            if not prev.startswith(("s_nop", "v_writelane_b32")): bad.append(f"hand-written v_writelane_b32 directly behind `{prev.split()[0] if prev else '?'}` (no wait states)")
+            chk_next = True
+        prev = t
     if bad:
-        print("RESOURCE GATE FAILED:\n  " + "\n  ".join(bad)); sys.exit(1)
+        print("RESOURCE GATE FAILED:\n  " + "\n  ".join(sorted(set(bad)))); sys.exit(1)
     print("resource gate ok")
