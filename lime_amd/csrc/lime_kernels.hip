@@ -2171,6 +2171,8 @@ __global__ __launch_bounds__(PART_WG) void k_sort_tiles(const uint32_t *recs, co
     uint32_t nxt[PART_PER];
     if (first < hi) load_tile(first, nxt);
     uint32_t row = kq;
+    __shared__ uint32_t nv_s;
+    const uint32_t lane = tid & 63u, wave = tid >> 6;
     for (uint64_t t0 = first; t0 < hi; t0 += step, row += nq) {
         uint32_t val[PART_PER], dr[PART_PER];
 #pragma unroll
@@ -2183,19 +2185,28 @@ __global__ __launch_bounds__(PART_WG) void k_sort_tiles(const uint32_t *recs, co
         }
         if (t0 + step < hi) load_tile(t0 + step, nxt);
         __syncthreads();
-        part_scan(cnt, toff, f2, wsum);
+        // the regions' starts inside the tile: f2 <= 512 counters, one per thread; the counters go back to zero right here (round 3 cleared them in
+        // a pass of their own behind two more barriers: four barriers a tile now instead of six)
+        {
+            static_assert(F2MAX <= PART_WG, "a region's counter per thread");
+            const uint32_t c = tid < f2 ? cnt[tid] : 0u;
+            const uint32_t incl = wave_incl_scan(c);
+            if (lane == 63u) wsum[wave] = incl;
+            __syncthreads();
+            uint32_t run = incl - c;
+            for (uint32_t k = 0; k < wave; ++k) run += wsum[k];
+            if (tid < f2) { toff[tid] = run; cnt[tid] = 0u; bidx[(size_t)tid * n_rows + row] = (uint16_t)run; }
+            if (tid == f2 - 1u) { nv_s = run + c; bidx[(size_t)f2 * n_rows + row] = (uint16_t)(run + c); }
+            __syncthreads();
+        }
 #pragma unroll
         for (uint32_t j = 0; j < PART_PER; ++j)
             if (dr[j] != ~0u) stage[toff[dr[j] & 0xFFFu] + (dr[j] >> 12)] = (uint16_t)(val[j] & ((1u << REGION_SHIFT) - 1u));
-        for (uint32_t i = tid; i <= f2; i += PART_WG)
-            bidx[(size_t)i * n_rows + row] = (uint16_t)(i < f2 ? toff[i] : toff[f2 - 1u] + cnt[f2 - 1u]);
         __syncthreads();
-        const uint32_t nv = toff[f2 - 1u] + cnt[f2 - 1u];               // records of the tile
+        const uint32_t nv = nv_s;                                        // records of the tile
         uint4 *dst = reinterpret_cast<uint4 *>(out16 + (size_t)(row0 + row) * PART_TILE);
         for (uint32_t i = tid; i < (nv + 7u) / 8u; i += PART_WG) dst[i] = stage4[i];       // whole 16-byte groups: the row is the tile's alone
-        __syncthreads();
-        for (uint32_t i = tid; i < f2; i += PART_WG) cnt[i] = 0u;
-        __syncthreads();
+        // (no barrier here: the next tile's ranks touch the counters only -- cleared above -- and its staging comes behind two barriers)
     }
 }
 
