@@ -364,7 +364,10 @@ static int ensure_binned(lime_ctx *c, uint64_t n_own, uint32_t n_waves, uint32_t
     if (c->pool_cap / segs > cw) cw = (c->pool_cap / segs) & ~15ull;      // grow-only: use all of what is there
     if (cw * segs > 0xF0000000ull) return fail(LIME_ERR_ARG, "update record pool too large for one shard");   // record positions are 32-bit
     size_t want = (size_t)cw * segs;
-    if (want < (size_t)n_bins * part_tile()) want = (size_t)n_bins * part_tile();      // the second level's 16-bit rows (one per tile, a bin's last one partly used) fit the pool
+    {   // the second level's 16-bit rows (one per tile, a bin's last one partly used) fit the pool
+        const size_t rows_words = ((size_t)tiles_bound(want, n_bins) * row_stride() + 1) / 2;
+        if (want < rows_words) want = rows_words;
+    }
     if (want > c->pool_cap) {
         HIP_TRY(hipStreamSynchronize(st));
         if ((rc = regrow(c->d_pool, want + 16))) return rc;      // slack: k_part2 / k_apply read aligned groups of four 4-byte records
@@ -611,7 +614,10 @@ extern "C" int lime_apply_records_dev(lime_ctx *c, uint32_t n_src, const uint32_
     if (total && !d_rx) return fail(LIME_ERR_ARG, "lime_apply_records_dev: d_rx is NULL");
     const size_t f2 = (size_t)1 << (bin_shift - REGION_SHIFT), n_reg = (size_t)nb * f2;
     size_t xwant = (size_t)total + 16;
-    if (xwant < (size_t)nb * part_tile() + 16) xwant = (size_t)nb * part_tile() + 16;      // (the second level's 16-bit tile rows)
+    {   // (the second level's 16-bit tile rows)
+        const size_t rows_words = ((size_t)tiles_bound(total, nb) * row_stride() + 1) / 2 + 16;
+        if (xwant < rows_words) xwant = rows_words;
+    }
     if (xwant > c->xrecs_cap) {
         HIP_TRY(hipStreamSynchronize(st));
         if ((rc = regrow(c->d_xrecs, xwant + total / 8))) return rc;

@@ -119,6 +119,7 @@ void launch_apply_by_tiles(uint8_t *sim, size_t sim_bytes, const uint32_t *recs,
                            uint32_t *tbase, uint16_t *idx, uint16_t *out16, hipStream_t st);
 uint64_t tiles_bound(uint64_t n_records, uint32_t n_bins);
 uint32_t part_tile();
+uint32_t row_stride();
 void launch_regroup(const uint32_t *rx, const uint64_t *srcoff, uint32_t n_src, uint32_t nb, const uint64_t *dstbase, uint32_t *dst, hipStream_t st);
 void launch_apply_bigrecs(const uint64_t *recs, uint64_t n, uint64_t cell_lo, uint64_t cell_hi, uint8_t *block, hipStream_t st);
 void launch_emit(const ScanArgs &a, hipStream_t st);

@@ -1646,6 +1646,7 @@ __global__ __launch_bounds__(256) void k_bin_rowscan(uint32_t *counts, uint32_t 
 #endif
 constexpr int PART_WG = 512;
 constexpr uint32_t PART_PER = LIME_PART_PER, PART_TILE = PART_WG * PART_PER;   // 8192 records per tile, 64 KB of (position, record)
+constexpr uint32_t ROW_STRIDE = PART_TILE;                              // 16-bit records from one second-level tile row to the next (padding it -- 256 B, 4.25 KB -- changed nothing)
 
 // exclusive prefix of cnt[0 .. nb) into toff[0 .. nb), nb <= PART_WG * 8; all threads of the workgroup call it
 // (barriers inside: cnt is complete on entry, toff on exit)
@@ -1677,7 +1678,7 @@ __device__ __forceinline__ void part_scan(const uint32_t *cnt, uint32_t *toff, u
 // the threads that scan them; the counters are cleared by the scan, and the NEXT tile is counted while this one is written
 // out: three barriers a tile.
 typedef uint32_t u32x4u __attribute__((ext_vector_type(4), aligned(4)));   // four words at any 4-byte alignment
-#ifdef LIME_PART_TIMING      // debug build: cycles of k_part's phases, summed over the first wave of every workgroup (tools/r04_part_phases.sh)
+#if defined(LIME_PART_TIMING) || defined(LIME_APPLY_TIMING)      // debug builds: cycles of k_part's (k_apply_tiles') phases, summed over the first wave of every workgroup (tools/r04_part_phases.sh, tools/r04_apply_phases.sh)
 __device__ unsigned long long g_part_pt[8];
 extern "C" int lime_debug_part_times(unsigned long long *out)
 {
@@ -1685,13 +1686,29 @@ extern "C" int lime_debug_part_times(unsigned long long *out)
     void *p = nullptr; (void)hipGetSymbolAddress(&p, HIP_SYMBOL(g_part_pt)); (void)hipMemset(p, 0, sizeof(g_part_pt));
     return rc;
 }
-#define PP_DECL uint64_t pp_t = __builtin_readcyclecounter(), pp_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-#define PP(i) { const uint64_t n_ = __builtin_readcyclecounter(); pp_acc[i] += n_ - pp_t; pp_t = n_; }
-#define PP_END if (threadIdx.x == 0) { for (int i_ = 0; i_ < 8; ++i_) atomicAdd(&g_part_pt[i_], (unsigned long long)pp_acc[i_]); }
+#define PT_DECL_ uint64_t pp_t = __builtin_readcyclecounter(), pp_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+#define PT_(i) { const uint64_t n_ = __builtin_readcyclecounter(); pp_acc[i] += n_ - pp_t; pp_t = n_; }
+#define PT_END_ if (threadIdx.x == 0) { for (int i_ = 0; i_ < 8; ++i_) atomicAdd(&g_part_pt[i_], (unsigned long long)pp_acc[i_]); }
+#endif
+#ifdef LIME_PART_TIMING
+#define PP_DECL PT_DECL_
+#define PP(i) PT_(i)
+#define PP_END PT_END_
 #else
 #define PP_DECL
 #define PP(i)
 #define PP_END
+#endif
+#ifdef LIME_APPLY_TIMING
+#define AP_DECL PT_DECL_
+#define AP(i) PT_(i)
+#define AP_END PT_END_
+#define AP_WAITVM asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#else
+#define AP_DECL
+#define AP(i)
+#define AP_END
+#define AP_WAITVM
 #endif
 
 // WGS threads and tiles of 16 WGS records: 512 / 8192, or -- few bins: the runs stay long enough -- 256 / 4096 with twice as many
@@ -2204,7 +2221,7 @@ __global__ __launch_bounds__(PART_WG) void k_sort_tiles(const uint32_t *recs, co
             if (dr[j] != ~0u) stage[toff[dr[j] & 0xFFFu] + (dr[j] >> 12)] = (uint16_t)(val[j] & ((1u << REGION_SHIFT) - 1u));
         __syncthreads();
         const uint32_t nv = nv_s;                                        // records of the tile
-        uint4 *dst = reinterpret_cast<uint4 *>(out16 + (size_t)(row0 + row) * PART_TILE);
+        uint4 *dst = reinterpret_cast<uint4 *>(out16 + (size_t)(row0 + row) * ROW_STRIDE);
         for (uint32_t i = tid; i < (nv + 7u) / 8u; i += PART_WG) dst[i] = stage4[i];       // whole 16-byte groups: the row is the tile's alone
         // (no barrier here: the next tile's ranks touch the counters only -- cleared above -- and its staging comes behind two barriers)
     }
@@ -2212,8 +2229,8 @@ __global__ __launch_bounds__(PART_WG) void k_sort_tiles(const uint32_t *recs, co
 
 // k_apply_tiles: k_apply on the output of k_sort_tiles: the region's records are its run in every tile of its bin.
 // Wave w takes the tiles w, w + 8, ... of the bin (a lane reads one tile's two index entries), then their runs one after
-// the other, four 16-bit records per lane and step from 8-byte-aligned loads; the loads of the next four runs are in
-// flight while four are added.
+// the other, four 16-bit records per lane and step from 8-byte-aligned loads (and the 65th group of a run with them); the
+// loads of the next four runs are in flight while four are added.
 __global__ __launch_bounds__(APPLY_WG) void k_apply_tiles(uint8_t *sim, size_t sim_bytes, const uint16_t *recs16, const uint32_t *tbase,
                                                           const uint16_t *idx, uint32_t bin_shift, uint32_t n_regions)
 {
@@ -2221,7 +2238,7 @@ __global__ __launch_bounds__(APPLY_WG) void k_apply_tiles(uint8_t *sim, size_t s
     constexpr uint32_t NWV = APPLY_WG / 64, UR = 4;
     __shared__ uint4 reg4[RW / 4];
     uint32_t *reg = reinterpret_cast<uint32_t *>(reg4);
-    const uint32_t lane = lane_id(), wave = threadIdx.x >> 6;
+    const uint32_t lane = lane_id(), wave = (uint32_t)__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));   // wave-uniform: the runs' borders and sources stay scalar
     const uint32_t f2 = 1u << (bin_shift - REGION_SHIFT);
     // one record: + 1 modulo 256 on byte o of the region.  Fast form: ONE returning LDS add of 1 << (8 x byte) on the word -- exact as long
     // as no cell of the word passes 255 (a carry would run into its neighbour); an add that finds its cell at 255 raises the region's
@@ -2229,14 +2246,9 @@ __global__ __launch_bounds__(APPLY_WG) void k_apply_tiles(uint8_t *sim, size_t s
     // there: a cell's sum is bounded by the read length; the wrap-around fixtures and the iid generator at few reads do).
     __shared__ uint32_t ovf_s;
     bool exact = false;
-    auto add = [&](uint32_t o) {
+    auto add_exact = [&](uint32_t o) {
         const uint32_t sh = (o & 3u) * 8u;
         uint32_t *w = &reg[o >> 2];
-        if (!exact) {
-            const uint32_t old = atomicAdd(w, 1u << sh);
-            if (((old >> sh) & 255u) == 255u) ovf_s = 1u;
-            return;
-        }
         uint32_t seen = *w;
         for (;;) {
             const uint32_t b = ((seen >> sh) + 1u) & 255u;
@@ -2245,89 +2257,137 @@ __global__ __launch_bounds__(APPLY_WG) void k_apply_tiles(uint8_t *sim, size_t s
             seen = old;
         }
     };
-    struct Step { uint2 v[UR]; uint32_t fa[UR], fe[UR], q[UR]; const uint16_t *src[UR]; };
+    // the four records of a lane's group [p, p + 4), those inside [fa, fe) only.  The four adds leave together and are looked at together: a
+    // record outside the run adds 0 to whatever word its bits name (one add at a time behind its own branch, each waiting for its answer,
+    // the adds were 77 % of the kernel's cycles at N = 1e10 and 19 .. 34 % elsewhere: tools/r04_apply_phases.sh)
+    auto add4 = [&](uint32_t p, uint2 w, uint32_t fa, uint32_t fe) {
+        const uint32_t o[4] = {w.x & 0xFFFFu, w.x >> 16, w.y & 0xFFFFu, w.y >> 16};
+        if (exact) {
+#pragma unroll
+            for (uint32_t i = 0; i < 4; ++i) if (p + i >= fa && p + i < fe) add_exact(o[i]);
+            return;
+        }
+        // (the valid slots as a 4-bit mask: lo .. hi of the group; p + 4 > fa and p < fe hold for every group that gets here.  The flag is
+        // also raised by an add of 0 that meets a cell at 255 -- harmless: the exact pass follows)
+        const uint32_t lo = fa > p ? fa - p : 0u, hi = fe - p < 4u ? fe - p : 4u;
+        const uint32_t m = ((1u << hi) - 1u) & (~0u << lo);
+        uint32_t old[4], sh[4];
+#pragma unroll
+        for (uint32_t i = 0; i < 4; ++i) {
+            sh[i] = (o[i] << 3) & 24u;
+            old[i] = atomicAdd(&reg[o[i] >> 2], ((m >> i) & 1u) << sh[i]);
+        }
+        bool over = false;
+#pragma unroll
+        for (uint32_t i = 0; i < 4; ++i) over |= __builtin_amdgcn_ubfe(old[i], sh[i], 8u) == 255u;
+        if (over) ovf_s = 1u;
+    };
+    struct Step { uint2 v[UR], v2[UR]; uint32_t fa[UR], fe[UR], q[UR]; const uint16_t *src[UR]; };
     if (threadIdx.x == 0) ovf_s = 0u;
     // A workgroup walks regions blockIdx.x, + gridDim.x, ... (two workgroups per CU).  What a region needs before its records
     // can be read -- its bin's tile range, then its index entries -- is fetched while the region before it is worked on: a
     // workgroup per region paid that chain of dependent loads per region (configs[2]: 76 k regions of 1.6 k records each).
+    const uint32_t bsh = bin_shift - REGION_SHIFT;
+    auto index_of = [&](uint32_t r, uint32_t r0, uint32_t nr, uint32_t outer, uint32_t &a_, uint32_t &e_) {   // lane l: the index entries of tile outer + wave + NWV * l of the region's bin
+        const uint16_t *ia = idx + (size_t)r0 * (f2 + 1u) + (size_t)(r & (f2 - 1u)) * nr;
+        const uint32_t t = outer + wave + NWV * lane;
+        a_ = 0u; e_ = 0u;
+        if (t < nr) { a_ = ia[t]; e_ = ia[nr + t]; }
+    };
+    auto runs_of = [&](uint32_t nr, uint32_t outer) {             // tiles of this round: the wave's are wave, wave + NWV, ... < left
+        const uint32_t left = nr - outer;
+        return left > wave ? ((left - wave + NWV - 1u) / NWV < 64u ? (left - wave + NWV - 1u) / NWV : 64u) : 0u;
+    };
+    auto load_step = [&](uint32_t l0, Step &s, uint32_t a_, uint32_t e_, uint32_t nl_, uint32_t row_w) {   // the first 256 records of the runs l0 .. l0 + UR of this wave (row_w: the wave's first tile row)
+#pragma unroll
+        for (uint32_t u = 0; u < UR; ++u) {
+            const uint32_t l = l0 + u;
+            s.fa[u] = l < nl_ ? rl32(a_, l) : 0u; s.fe[u] = l < nl_ ? rl32(e_, l) : 0u;
+            s.q[u] = (s.fa[u] >> 2) + lane;                       // this lane's group of four records
+            s.src[u] = recs16 + (size_t)(row_w + NWV * l) * ROW_STRIDE;
+            s.v[u] = make_uint2(0u, 0u); s.v2[u] = make_uint2(0u, 0u);
+            if (s.q[u] * 4u < s.fe[u]) s.v[u] = *reinterpret_cast<const uint2 *>(s.src[u] + (size_t)s.q[u] * 4u);
+            // (the 65th group of a run -- 256 records on average at 32 regions per bin, and few start on a group border -- comes with the
+            // step: fetched when its turn came, it was a memory round trip for one lane's four records in every second run, N = 1e10)
+            if ((s.q[u] + 64u) * 4u < s.fe[u]) s.v2[u] = *reinterpret_cast<const uint2 *>(s.src[u] + (size_t)(s.q[u] + 64u) * 4u);
+        }
+    };
     uint32_t region = blockIdx.x;
     if (region >= n_regions) return;
-    uint32_t row0 = tbase[region >> (bin_shift - REGION_SHIFT)], n_rows = tbase[(region >> (bin_shift - REGION_SHIFT)) + 1u] - row0;
-    uint32_t a = 0, e = 0;                                        // lane l: the index entries of tile wave + NWV * l of the region's bin
-    {
-        const uint16_t *ia = idx + (size_t)row0 * (f2 + 1u) + (size_t)(region & (f2 - 1u)) * n_rows;
-        const uint32_t t = wave + NWV * lane;
-        if (t < n_rows) { a = ia[t]; e = ia[n_rows + t]; }
-    }
+    uint32_t row0 = tbase[region >> bsh], n_rows = tbase[(region >> bsh) + 1u] - row0;
+    uint32_t a, e;
+    index_of(region, row0, n_rows, 0u, a, e);
+    __syncthreads();                                              // (everybody sees the cleared flag)
+    AP_DECL
     for (;;) {
         const uint32_t next = region + gridDim.x;
         const bool more = next < n_regions;
         uint32_t nrow0 = 0, nrow1 = 0;                            // the next region's tile range: needed only after this one's records
-        if (more) { nrow0 = tbase[next >> (bin_shift - REGION_SHIFT)]; nrow1 = tbase[(next >> (bin_shift - REGION_SHIFT)) + 1u]; }
-        const uint32_t sub = region & (f2 - 1u);
-        const uint16_t *ia = idx + (size_t)row0 * (f2 + 1u) + (size_t)sub * n_rows, *ie = ia + n_rows;
+        if (more) { nrow0 = tbase[next >> bsh]; nrow1 = tbase[(next >> bsh) + 1u]; }
         for (exact = false;; exact = true) {                      // once; twice if a cell passed 255 under the fast adds
         for (uint32_t i = threadIdx.x; i < RW / 4; i += APPLY_WG) reg4[i] = make_uint4(0u, 0u, 0u, 0u);
         __syncthreads();
+        AP(0)
         for (uint32_t outer = 0; outer < n_rows; outer += NWV * 64u) {
-            if (outer || exact) { a = 0u; e = 0u; const uint32_t t = outer + wave + NWV * lane; if (t < n_rows) { a = ia[t]; e = ie[t]; } }
-            const uint32_t left = n_rows - outer;                  // tiles of this round: the wave's are wave, wave + NWV, ... < left
-            const uint32_t nl = left > wave ? ((left - wave + NWV - 1u) / NWV < 64u ? (left - wave + NWV - 1u) / NWV : 64u) : 0u;
-            auto load_step = [&](uint32_t l0, Step &s) {          // the first 256 records of the runs l0 .. l0 + UR of this wave
-#pragma unroll
-                for (uint32_t u = 0; u < UR; ++u) {
-                    const uint32_t l = l0 + u;
-                    s.fa[u] = l < nl ? rl32(a, l) : 0u; s.fe[u] = l < nl ? rl32(e, l) : 0u;
-                    s.q[u] = (s.fa[u] >> 2) + lane;               // this lane's group of four records
-                    s.src[u] = recs16 + (size_t)(row0 + outer + wave + NWV * l) * PART_TILE;
-                    s.v[u] = make_uint2(0u, 0u);
-                    if (s.q[u] * 4u < s.fe[u]) s.v[u] = *reinterpret_cast<const uint2 *>(s.src[u] + (size_t)s.q[u] * 4u);
-                }
-            };
+            const uint32_t nl = runs_of(n_rows, outer);
+            if (outer || exact) index_of(region, row0, n_rows, outer, a, e);
             Step nxt;
-            if (nl) load_step(0u, nxt);
+            if (nl) load_step(0u, nxt, a, e, nl, row0 + outer + wave);
+            AP(1)
             for (uint32_t l0 = 0; l0 < nl; l0 += UR) {
+                AP_WAITVM AP(2)
                 Step cur = nxt;
-                if (l0 + UR < nl) load_step(l0 + UR, nxt);        // the next runs' loads go out before these are added
+                if (l0 + UR < nl) load_step(l0 + UR, nxt, a, e, nl, row0 + outer + wave);     // the next runs' loads go out before these are added
+                AP(3)
 #pragma unroll
                 for (uint32_t u = 0; u < UR; ++u) {
                     uint32_t q = cur.q[u];
-                    uint2 w = cur.v[u];
+                    uint2 w = cur.v[u], w2 = cur.v2[u];
                     const uint32_t fa = cur.fa[u], fe = cur.fe[u];
                     while (__ballot(q * 4u < fe)) {
-                        if (q * 4u < fe) {
-                            const uint32_t p = q * 4u;
-                            if (p >= fa) add(w.x & 0xFFFFu);
-                            if (p + 1u >= fa && p + 1u < fe) add(w.x >> 16);
-                            if (p + 2u >= fa && p + 2u < fe) add(w.y & 0xFFFFu);
-                            if (p + 3u >= fa && p + 3u < fe) add(w.y >> 16);
-                        }
-                        q += 64u;                                 // (runs beyond 256 records: further steps, loaded here)
-                        if (q * 4u < fe) w = *reinterpret_cast<const uint2 *>(cur.src[u] + (size_t)q * 4u);
+                        if (q * 4u < fe) add4(q * 4u, w, fa, fe);
+                        q += 64u;
+                        w = w2;
+                        if ((q + 64u) * 4u < fe) w2 = *reinterpret_cast<const uint2 *>(cur.src[u] + (size_t)(q + 64u) * 4u);   // (runs beyond 512 records: further groups, loaded here)
                     }
                 }
+                AP(4)
             }
         }
         __syncthreads();
+        AP(5)
         if (exact || !ovf_s) break;
         __syncthreads();                                          // (everybody has seen the flag)
         if (threadIdx.x == 0) ovf_s = 0u;
         }
         // the next region's index entries go out now and land while this region is written
         uint32_t na = 0, ne = 0;
-        if (more) {
-            const uint32_t nn = nrow1 - nrow0, t = wave + NWV * lane;
-            const uint16_t *nia = idx + (size_t)nrow0 * (f2 + 1u) + (size_t)(next & (f2 - 1u)) * nn;
-            if (t < nn) { na = nia[t]; ne = nia[nn + t]; }
-        }
+        if (more) index_of(next, nrow0, nrow1 - nrow0, 0u, na, ne);
         const size_t reg_base = (size_t)region << REGION_SHIFT;  // regions start inside the table
         uint4 *dst = reinterpret_cast<uint4 *>(sim + reg_base);
         const size_t left16 = (sim_bytes - reg_base) / 16u;      // sim_bytes is a multiple of 16
-        for (uint32_t i = threadIdx.x; i < RW / 4 && i < left16; i += APPLY_WG) dst[i] = reg4[i];
+        constexpr uint32_t NST = RW / 4 / APPLY_WG;
+        static_assert(RW / 4 % APPLY_WG == 0, "whole rounds of 16-byte stores");
+        if (left16 >= RW / 4) {
+            // the thread's eight 16-byte pieces: read together, then stored together (one after the other every piece waited for its LDS
+            // read; named registers, not an array: the array went to scratch memory)
+            static_assert(NST == 8, "eight 16-byte stores per thread below");
+            uint4 *rp = reg4 + threadIdx.x, *dp = dst + threadIdx.x;
+#define LIME_RD(J) const uint4 o##J = rp[J * APPLY_WG];
+            LIME_RD(0) LIME_RD(1) LIME_RD(2) LIME_RD(3) LIME_RD(4) LIME_RD(5) LIME_RD(6) LIME_RD(7)
+#undef LIME_RD
+            dp[0 * APPLY_WG] = o0; dp[1 * APPLY_WG] = o1; dp[2 * APPLY_WG] = o2; dp[3 * APPLY_WG] = o3;
+            dp[4 * APPLY_WG] = o4; dp[5 * APPLY_WG] = o5; dp[6 * APPLY_WG] = o6; dp[7 * APPLY_WG] = o7;
+        } else {                                                  // the table's last region, cut short (it is its workgroup's last one)
+            for (uint32_t i = threadIdx.x; i < left16; i += APPLY_WG) dst[i] = reg4[i];
+        }
+        AP(6)
         if (!more) break;
         __syncthreads();                                          // (the region's LDS copy has been read: it may be cleared)
+        AP(7)
         region = next; row0 = nrow0; n_rows = nrow1 - nrow0; a = na; e = ne;
     }
+    AP_END
 }
 
 // k_apply: one workgroup builds one 64 KB region of the table in LDS -- zero, add the region's records (exact
@@ -2828,6 +2888,7 @@ void launch_apply_by_tiles(uint8_t *sim, size_t sim_bytes, const uint32_t *recs,
 uint64_t tiles_bound(uint64_t n_records, uint32_t n_bins) { return n_records / PART_TILE + n_bins; }
 
 uint32_t part_tile() { return PART_TILE; }
+uint32_t row_stride() { return ROW_STRIDE; }
 
 void launch_regroup(const uint32_t *rx, const uint64_t *srcoff, uint32_t n_src, uint32_t nb, const uint64_t *dstbase, uint32_t *dst, hipStream_t st)
 {
