@@ -1678,7 +1678,7 @@ __device__ __forceinline__ void part_scan(const uint32_t *cnt, uint32_t *toff, u
 // the threads that scan them; the counters are cleared by the scan, and the NEXT tile is counted while this one is written
 // out: three barriers a tile.
 typedef uint32_t u32x4u __attribute__((ext_vector_type(4), aligned(4)));   // four words at any 4-byte alignment
-#if defined(LIME_PART_TIMING) || defined(LIME_APPLY_TIMING)      // debug builds: cycles of k_part's (k_apply_tiles') phases, summed over the first wave of every workgroup (tools/r04_part_phases.sh, tools/r04_apply_phases.sh)
+#if defined(LIME_PART_TIMING) || defined(LIME_APPLY_TIMING) || defined(LIME_SORT_TIMING)      // debug builds: cycles of k_part's (k_apply_tiles') phases, summed over the first wave of every workgroup (tools/r04_part_phases.sh, tools/r04_apply_phases.sh)
 __device__ unsigned long long g_part_pt[8];
 extern "C" int lime_debug_part_times(unsigned long long *out)
 {
@@ -1698,6 +1698,17 @@ extern "C" int lime_debug_part_times(unsigned long long *out)
 #define PP_DECL
 #define PP(i)
 #define PP_END
+#endif
+#ifdef LIME_SORT_TIMING
+#define ST_DECL PT_DECL_
+#define ST(i) PT_(i)
+#define ST_END PT_END_
+#define ST_WAITVM asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#else
+#define ST_DECL
+#define ST(i)
+#define ST_END
+#define ST_WAITVM
 #endif
 #ifdef LIME_APPLY_TIMING
 #define AP_DECL PT_DECL_
@@ -2168,13 +2179,18 @@ __global__ __launch_bounds__(PART_WG) void k_sort_tiles(const uint32_t *recs, co
     uint16_t *stage = reinterpret_cast<uint16_t *>(stage4);
     const uint32_t tid = threadIdx.x;
     const uint32_t f2 = 1u << (bin_shift - REGION_SHIFT), omask = (1u << bin_shift) - 1u;
+    // every region's counter comes in R copies, a lane uses copy lane % R: 64 lanes on 32 counters is what an LDS add is slowest at (10 cycles
+    // an instruction against 6.5 on 128 and more, tools/lds_bench.hip), and the ranks were a third of the kernel's cycles (tools/r04_sort_phases.sh).
+    // The copies of a region lie next to each other, so the scan hands each its own piece of the region's run.
+    const uint32_t rsh = f2 <= 32u ? 4u : f2 <= 64u ? 3u : f2 <= 128u ? 2u : f2 <= 256u ? 1u : 0u, nc = f2 << rsh;      // nc <= F2MAX counters
+    const uint32_t mycopy = (threadIdx.x & 63u) & ((1u << rsh) - 1u);
     // workgroup (bin, k) of gridDim.y takes the bin's tiles k, k + gridDim.y, ...: tiles are independent of each other, and a
     // workgroup per BIN left the CUs unevenly loaded (477 or 1193 workgroups of 8 waves over 256 CUs, 292 on the text workload)
     const uint32_t bin = blockIdx.x, kq = blockIdx.y, nq = gridDim.y;
     const uint64_t lo = binbase[bin], hi = binbase[bin + 1];
     const uint32_t row0 = tbase[bin], n_rows = tbase[bin + 1] - row0;
     uint16_t *bidx = idx + (size_t)row0 * (f2 + 1u);
-    for (uint32_t i = tid; i < f2; i += PART_WG) cnt[i] = 0u;
+    for (uint32_t i = tid; i < nc; i += PART_WG) cnt[i] = 0u;
     __syncthreads();
     const uint64_t step = (uint64_t)PART_TILE * nq, first = lo + (uint64_t)PART_TILE * kq;
     auto load_tile = [&](uint64_t t0, uint32_t (&v)[PART_PER]) {
@@ -2190,41 +2206,51 @@ __global__ __launch_bounds__(PART_WG) void k_sort_tiles(const uint32_t *recs, co
     uint32_t row = kq;
     __shared__ uint32_t nv_s;
     const uint32_t lane = tid & 63u, wave = tid >> 6;
+    ST_DECL
     for (uint64_t t0 = first; t0 < hi; t0 += step, row += nq) {
+        ST_WAITVM ST(0)
         uint32_t val[PART_PER], dr[PART_PER];
 #pragma unroll
         for (uint32_t j = 0; j < PART_PER; ++j) {
             val[j] = nxt[j]; dr[j] = ~0u;
             if (val[j] >> bin_shift) {                                   // (0: no record)
-                const uint32_t d = (val[j] & omask) >> REGION_SHIFT;
+                const uint32_t d = (((val[j] & omask) >> REGION_SHIFT) << rsh) | mycopy;
                 dr[j] = d | (atomicAdd(&cnt[d], 1u) << 12);
             }
         }
+        ST(1)
         if (t0 + step < hi) load_tile(t0 + step, nxt);
+        ST(2)
         __syncthreads();
+        ST(3)
         // the regions' starts inside the tile: f2 <= 512 counters, one per thread; the counters go back to zero right here (round 3 cleared them in
         // a pass of their own behind two more barriers: four barriers a tile now instead of six)
         {
             static_assert(F2MAX <= PART_WG, "a region's counter per thread");
-            const uint32_t c = tid < f2 ? cnt[tid] : 0u;
+            const uint32_t c = tid < nc ? cnt[tid] : 0u;
             const uint32_t incl = wave_incl_scan(c);
             if (lane == 63u) wsum[wave] = incl;
             __syncthreads();
             uint32_t run = incl - c;
             for (uint32_t k = 0; k < wave; ++k) run += wsum[k];
-            if (tid < f2) { toff[tid] = run; cnt[tid] = 0u; bidx[(size_t)tid * n_rows + row] = (uint16_t)run; }
-            if (tid == f2 - 1u) { nv_s = run + c; bidx[(size_t)f2 * n_rows + row] = (uint16_t)(run + c); }
+            if (tid < nc) { toff[tid] = run; cnt[tid] = 0u; if (!(tid & ((1u << rsh) - 1u))) bidx[(size_t)(tid >> rsh) * n_rows + row] = (uint16_t)run; }
+            if (tid == nc - 1u) { nv_s = run + c; bidx[(size_t)f2 * n_rows + row] = (uint16_t)(run + c); }
             __syncthreads();
         }
+        ST(4)
 #pragma unroll
         for (uint32_t j = 0; j < PART_PER; ++j)
             if (dr[j] != ~0u) stage[toff[dr[j] & 0xFFFu] + (dr[j] >> 12)] = (uint16_t)(val[j] & ((1u << REGION_SHIFT) - 1u));
+        ST(5)
         __syncthreads();
+        ST(6)
         const uint32_t nv = nv_s;                                        // records of the tile
         uint4 *dst = reinterpret_cast<uint4 *>(out16 + (size_t)(row0 + row) * ROW_STRIDE);
         for (uint32_t i = tid; i < (nv + 7u) / 8u; i += PART_WG) dst[i] = stage4[i];       // whole 16-byte groups: the row is the tile's alone
         // (no barrier here: the next tile's ranks touch the counters only -- cleared above -- and its staging comes behind two barriers)
+        ST(7)
     }
+    ST_END
 }
 
 // k_apply_tiles: k_apply on the output of k_sort_tiles: the region's records are its run in every tile of its bin.
