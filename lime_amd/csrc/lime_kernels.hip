@@ -1876,19 +1876,22 @@ __global__ __launch_bounds__(WGS) void k_part(ScanArgs a, const uint64_t *binbas
 constexpr uint32_t PL_TASKS = PART_TILE / 16u + 16u;                     // + one task per bin (a first, aligning piece)
 // (tasks of a tile: its lines -- at most (PART_TILE + 15 nb) / 16 -- plus one per bin whose first piece is not aligned)
 constexpr uint32_t PL_CS = 17;                                          // words per bin's carry row: 16 records on a stride that spreads the bins over the LDS banks (a stride of 16 put every bin's record i on two banks: 77 % of the LDS cycles were bank conflicts)
-__host__ __device__ inline size_t part_lines_lds(uint32_t nb) { return (size_t)nb * (16u + 4u * PL_CS) + ((size_t)nb + 1u) / 2u * 4u + ((size_t)PL_TASKS + 2u * nb + 1u) / 2u * 4u; }
+__host__ __device__ inline size_t part_lines_lds(uint32_t nb) { return (size_t)nb * (16u + 4u * PL_CS) + ((size_t)PL_TASKS + 2u * nb) * 4u; }
 
 __global__ __launch_bounds__(PART_WG) void k_part_lines(ScanArgs a, const uint64_t *binbase, uint32_t *out)
 {
     __shared__ uint4 stage4[PART_TILE / 4];                              // the tile's records, grouped by bin
-    extern __shared__ uint32_t part_lds[];
+    extern __shared__ __attribute__((aligned(16))) uint32_t part_lds_al[];
+    uint32_t *part_lds = part_lds_al;
     __shared__ uint32_t wsum[PART_WG / 64], n_tasks_s;
     uint32_t *stage = reinterpret_cast<uint32_t *>(stage4);
     const uint32_t nb = a.n_bins, tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
-    uint32_t *cnt = part_lds, *cur = cnt + nb, *desc = cur + nb, *gpos = desc + nb;      // desc: stage start | carried records << 14 | records to emit << 18
-    uint32_t *cb = gpos + nb;                                            // [nb][PL_CS]: the bins' carried records
-    uint16_t *tfirst = reinterpret_cast<uint16_t *>(cb + (size_t)nb * PL_CS);
-    uint16_t *taskbin = tfirst + ((nb + 1u) & ~1u);
+    // dg[b]: (stage start | carried records << 14 | records to emit << 18, position of the bin's next record in out) -- what a line's lanes need
+    // of its bin, one 8-byte read; task[j]: bin | line of the bin << 11
+    uint32_t *cnt = part_lds, *cur = cnt + nb;
+    uint2 *dg = reinterpret_cast<uint2 *>(cur + nb);                     // (8-byte aligned: part_lds is, and cnt + cur are 2 nb words)
+    uint32_t *cb = reinterpret_cast<uint32_t *>(dg + nb);                // [nb][PL_CS]: the bins' carried records
+    uint32_t *task = cb + (size_t)nb * PL_CS;
     const uint32_t per = (nb + PART_WG - 1u) / PART_WG, b0 = tid * per;
     constexpr uint32_t BPT = 3;                                          // bins a thread owns at most (launch_part: nb <= 3 * PART_WG)
     uint32_t G[BPT], C[BPT];                                             // per owned bin: position of its next record in out; records carried
@@ -1948,6 +1951,7 @@ __global__ __launch_bounds__(PART_WG) void k_part_lines(ScanArgs a, const uint64
     count_tile(tc, v4);
     Tile tn_ = next_tile(tc);
     if (tn_.any) load_tile(tn_, rv);
+    __syncthreads();                                                     // the first tile's counts are complete
     PP_DECL
     for (;;) {
         uint32_t N[BPT], S[BPT], E[BPT], Cold[BPT];
@@ -1956,7 +1960,8 @@ __global__ __launch_bounds__(PART_WG) void k_part_lines(ScanArgs a, const uint64
         {
             uint32_t L[BPT], mine = 0;
             PP(0)
-            __syncthreads();                                             // the counts are complete, the carries up to date
+            // (no barrier here: the tile was counted in front of the barrier that ended the last write-out, and the carries the owner threads
+            // have just moved are read by nobody before three more barriers)
             PP(1)
 #pragma unroll
             for (uint32_t k = 0; k < BPT; ++k) {
@@ -1977,8 +1982,8 @@ __global__ __launch_bounds__(PART_WG) void k_part_lines(ScanArgs a, const uint64
             for (uint32_t k = 0; k < BPT; ++k)
                 if (k < per && b0 + k < nb) {
                     const uint32_t b = b0 + k, s0 = run & 0xFFFFu, t0_ = run >> 16;
-                    S[k] = s0; cur[b] = s0; desc[b] = s0 | (C[k] << 14) | (E[k] << 18); gpos[b] = G[k]; tfirst[b] = (uint16_t)t0_;
-                    for (uint32_t i = 0; i < L[k]; ++i) taskbin[t0_ + i] = (uint16_t)b;
+                    S[k] = s0; cur[b] = s0; dg[b] = make_uint2(s0 | (C[k] << 14) | (E[k] << 18), G[k]);
+                    for (uint32_t i = 0; i < L[k]; ++i) task[t0_ + i] = b | (i << 11);
                     G[k] += E[k]; C[k] = C[k] + N[k] - E[k];
                     run += N[k] | (L[k] << 16);
                 }
@@ -2015,18 +2020,21 @@ __global__ __launch_bounds__(PART_WG) void k_part_lines(ScanArgs a, const uint64
             constexpr uint32_t GRPS = PART_WG / 16u, UT = 4;
             const uint32_t grp = tid >> 4, l16 = tid & 15u, n_tasks = n_tasks_s;
             for (uint32_t j0 = grp; j0 < n_tasks; j0 += GRPS * UT) {
-                uint32_t bb[UT], dd[UT], gg[UT], tf[UT], pp[UT], ee[UT], val[UT];
+                uint32_t tt[UT], pp[UT], val[UT];
+                uint2 dd[UT];
                 bool on[UT];
 #pragma unroll
-                for (uint32_t u = 0; u < UT; ++u) { const uint32_t j = j0 + u * GRPS; on[u] = j < n_tasks; bb[u] = taskbin[on[u] ? j : 0u]; }
+                for (uint32_t u = 0; u < UT; ++u) { const uint32_t j = j0 + u * GRPS; on[u] = j < n_tasks; tt[u] = task[on[u] ? j : 0u]; }
 #pragma unroll
-                for (uint32_t u = 0; u < UT; ++u) { dd[u] = desc[bb[u]]; gg[u] = gpos[bb[u]]; tf[u] = tfirst[bb[u]]; }
+                for (uint32_t u = 0; u < UT; ++u) dd[u] = dg[tt[u] & 0x7FFu];
 #pragma unroll
                 for (uint32_t u = 0; u < UT; ++u) {
-                    const uint32_t j = j0 + u * GRPS, s0 = dd[u] & 0x3FFFu, c = (dd[u] >> 14) & 15u, e_n = dd[u] >> 18;
-                    pp[u] = (((gg[u] >> 4) + (j - tf[u])) << 4) + l16; ee[u] = pp[u] - gg[u];
-                    on[u] = on[u] && ee[u] < e_n;
-                    const uint32_t *srcp = ee[u] < c ? cb + (bb[u] * PL_CS + ee[u]) : stage + (s0 + ee[u] - c);
+                    const uint32_t bq = tt[u] & 0x7FFu, d = dd[u].x, g = dd[u].y;
+                    const uint32_t s0 = d & 0x3FFFu, c = (d >> 14) & 15u, e_n = d >> 18;
+                    const uint32_t e = ((tt[u] >> 11) << 4) + l16 - (g & 15u);      // the lane's element of the bin's stream (before the first one: wraps)
+                    pp[u] = g + e;
+                    on[u] = on[u] && e < e_n;
+                    const uint32_t *srcp = e < c ? cb + (bq * PL_CS + e) : stage + (s0 + e - c);
                     val[u] = on[u] ? *srcp : 0u;
                 }
 #pragma unroll
