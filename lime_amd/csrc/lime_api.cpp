@@ -460,10 +460,14 @@ static int fused_dev_impl(lime_ctx *c, const uint32_t *d_lcp, const uint32_t *d_
     if (keep_stats) {
         HIP_TRY(hipMemsetAsync(&c->d_stats->n_cross, 0, 2 * sizeof(uint32_t), st));      // n_cross, n_big
         HIP_TRY(hipMemsetAsync(&c->d_stats->n_open, 0, sizeof(uint32_t), st));
+        if (zero_sim && !binned) HIP_TRY(hipMemsetAsync(d_sim, 0, sim_bytes, st));
     } else {
-        HIP_TRY(hipMemsetAsync(c->d_stats, 0, sizeof(DevStats), st));
+        // the counters and (compare-and-swap path: the binned path writes every byte of the table itself) the table, one launch
+        static_assert(sizeof(DevStats) % 4 == 0, "whole words");
+        const bool zt = zero_sim && !binned && d_sim;
+        launch_zero2(c->d_stats, sizeof(DevStats), zt ? d_sim : nullptr, zt ? (sim_bytes & ~(size_t)15) : 0, st);
+        if (zt && (sim_bytes & 15)) HIP_TRY(hipMemsetAsync(d_sim + (sim_bytes & ~(size_t)15), 0, sim_bytes & 15, st));
     }
-    if (zero_sim && !binned) HIP_TRY(hipMemsetAsync(d_sim, 0, sim_bytes, st));           // the binned path writes every byte itself
     if (records_only) {                                   // the long clusters' updates leave as records too
         if (!c->d_bigrec) {
             c->bigrec_cap = 16u << 20;
@@ -837,8 +841,11 @@ static int score_dev_impl(lime_ctx *c, const uint32_t *d_da, const uint8_t *d_eb
     // list flow is bound by its per-cluster gather of da / ebwt, not by its updates: 1e8 symbols, 1.7e7 updates 1.09 ms by compare-and-swap
     // against 1.33 binned; 4e8 symbols, 6.6e7 updates 4.25 against 4.56)
     for (int attempt = 0; attempt < 2; ++attempt) {
-        HIP_TRY(hipMemsetAsync(c->d_stats, 0, sizeof(DevStats), st));
-        if (zero_sim && !binned) HIP_TRY(hipMemsetAsync(d_sim, 0, sim_bytes, st));
+        {
+            const bool zt = zero_sim && !binned && d_sim;
+            launch_zero2(c->d_stats, sizeof(DevStats), zt ? d_sim : nullptr, zt ? (sim_bytes & ~(size_t)15) : 0, st);
+            if (zt && (sim_bytes & 15)) HIP_TRY(hipMemsetAsync(d_sim + (sim_bytes & ~(size_t)15), 0, sim_bytes & 15, st));
+        }
         if (!n_clusters) return LIME_OK;
         ScanArgs a = base_args(c, nullptr, d_da, d_ebwt, n, n, 1, n_reads, n_refs, 0, d_sim);
         a.pos_base = pos_base;
