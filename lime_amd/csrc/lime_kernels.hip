@@ -2265,7 +2265,7 @@ __global__ __launch_bounds__(PART_WG) void k_sort_tiles(const uint32_t *recs, co
 // Wave w takes the tiles w, w + 8, ... of the bin (a lane reads one tile's two index entries), then their runs one after
 // the other, four 16-bit records per lane and step from 8-byte-aligned loads (and the 65th group of a run with them); the
 // loads of the next four runs are in flight while four are added.
-__global__ __launch_bounds__(APPLY_WG) void k_apply_tiles(uint8_t *sim, size_t sim_bytes, const uint16_t *recs16, const uint32_t *tbase,
+template <bool WIDE> __global__ __launch_bounds__(APPLY_WG) void k_apply_tiles(uint8_t *sim, size_t sim_bytes, const uint16_t *recs16, const uint32_t *tbase,
                                                           const uint16_t *idx, uint32_t bin_shift, uint32_t n_regions)
 {
     constexpr uint32_t RW = (1u << REGION_SHIFT) / 4u;           // words per region
@@ -2316,7 +2316,8 @@ __global__ __launch_bounds__(APPLY_WG) void k_apply_tiles(uint8_t *sim, size_t s
         for (uint32_t i = 0; i < 4; ++i) over |= __builtin_amdgcn_ubfe(old[i], sh[i], 8u) == 255u;
         if (over) ovf_s = 1u;
     };
-    struct Step { uint2 v[UR], v2[UR]; uint32_t fa[UR], fe[UR], q[UR]; const uint16_t *src[UR]; };
+    static_assert(UR == 4, "a step's four runs share one pass over their groups 64 .. 79: sixteen lanes each");
+    struct Step { uint2 v[UR], v2[UR], vx; uint32_t fa[UR], fe[UR], q[UR], fax, fex, qx; const uint16_t *src[UR]; };
     if (threadIdx.x == 0) ovf_s = 0u;
     // A workgroup walks regions blockIdx.x, + gridDim.x, ... (two workgroups per CU).  What a region needs before its records
     // can be read -- its bin's tile range, then its index entries -- is fetched while the region before it is worked on: a
@@ -2339,11 +2340,22 @@ __global__ __launch_bounds__(APPLY_WG) void k_apply_tiles(uint8_t *sim, size_t s
             s.fa[u] = l < nl_ ? rl32(a_, l) : 0u; s.fe[u] = l < nl_ ? rl32(e_, l) : 0u;
             s.q[u] = (s.fa[u] >> 2) + lane;                       // this lane's group of four records
             s.src[u] = recs16 + (size_t)(row_w + NWV * l) * ROW_STRIDE;
-            s.v[u] = make_uint2(0u, 0u); s.v2[u] = make_uint2(0u, 0u);
+            s.v[u] = make_uint2(0u, 0u);
             if (s.q[u] * 4u < s.fe[u]) s.v[u] = *reinterpret_cast<const uint2 *>(s.src[u] + (size_t)s.q[u] * 4u);
-            // (the 65th group of a run -- 256 records on average at 32 regions per bin, and few start on a group border -- comes with the
-            // step: fetched when its turn came, it was a memory round trip for one lane's four records in every second run, N = 1e10)
-            if ((s.q[u] + 64u) * 4u < s.fe[u]) s.v2[u] = *reinterpret_cast<const uint2 *>(s.src[u] + (size_t)(s.q[u] + 64u) * 4u);
+            if (!WIDE) {                                          // the run's 65th group, fetched with the step
+                s.v2[u] = make_uint2(0u, 0u);
+                if ((s.q[u] + 64u) * 4u < s.fe[u]) s.v2[u] = *reinterpret_cast<const uint2 *>(s.src[u] + (size_t)(s.q[u] + 64u) * 4u);
+            }
+        }
+        // WIDE (many records: chosen at the launch).  The groups 64 .. 79 of the step's four runs, sixteen lanes a run, come with the step and are added in ONE pass: a run is 256 records on
+        // average at 32 regions per bin and few start on a group border, so every second run has a 65th group -- fetched when its turn came it
+        // was a memory round trip, and added in a pass of its own it cost the instructions of a full pass for one or two lanes.
+        if (WIDE) {
+            const uint32_t ux = lane >> 4, lx = l0 + ux;
+            s.fax = lx < nl_ ? (uint32_t)__shfl((int)a_, (int)lx) : 0u; s.fex = lx < nl_ ? (uint32_t)__shfl((int)e_, (int)lx) : 0u;
+            s.qx = (s.fax >> 2) + 64u + (lane & 15u);
+            s.vx = make_uint2(0u, 0u);
+            if (s.qx * 4u < s.fex) s.vx = *reinterpret_cast<const uint2 *>(recs16 + (size_t)(row_w + NWV * lx) * ROW_STRIDE + (size_t)s.qx * 4u);
         }
     };
     uint32_t region = blockIdx.x;
@@ -2373,16 +2385,31 @@ __global__ __launch_bounds__(APPLY_WG) void k_apply_tiles(uint8_t *sim, size_t s
                 Step cur = nxt;
                 if (l0 + UR < nl) load_step(l0 + UR, nxt, a, e, nl, row0 + outer + wave);     // the next runs' loads go out before these are added
                 AP(3)
+                if (WIDE) {
 #pragma unroll
-                for (uint32_t u = 0; u < UR; ++u) {
-                    uint32_t q = cur.q[u];
-                    uint2 w = cur.v[u], w2 = cur.v2[u];
-                    const uint32_t fa = cur.fa[u], fe = cur.fe[u];
-                    while (__ballot(q * 4u < fe)) {
-                        if (q * 4u < fe) add4(q * 4u, w, fa, fe);
-                        q += 64u;
-                        w = w2;
-                        if ((q + 64u) * 4u < fe) w2 = *reinterpret_cast<const uint2 *>(cur.src[u] + (size_t)(q + 64u) * 4u);   // (runs beyond 512 records: further groups, loaded here)
+                    for (uint32_t u = 0; u < UR; ++u)
+                        if (cur.q[u] * 4u < cur.fe[u]) add4(cur.q[u] * 4u, cur.v[u], cur.fa[u], cur.fe[u]);
+                    if (__ballot(cur.qx * 4u < cur.fex)) {
+                        if (cur.qx * 4u < cur.fex) add4(cur.qx * 4u, cur.vx, cur.fax, cur.fex);
+#pragma unroll
+                        for (uint32_t u = 0; u < UR; ++u) {        // runs beyond 320 records (groups from 80 on): loaded here, rare
+                            const uint32_t fa = cur.fa[u], fe = cur.fe[u];
+                            for (uint32_t q = cur.q[u] + 80u; __ballot(q * 4u < fe); q += 64u)
+                                if (q * 4u < fe) add4(q * 4u, *reinterpret_cast<const uint2 *>(cur.src[u] + (size_t)q * 4u), fa, fe);
+                        }
+                    }
+                } else {
+#pragma unroll
+                    for (uint32_t u = 0; u < UR; ++u) {
+                        uint32_t q = cur.q[u];
+                        uint2 w = cur.v[u], w2 = cur.v2[u];
+                        const uint32_t fa = cur.fa[u], fe = cur.fe[u];
+                        while (__ballot(q * 4u < fe)) {
+                            if (q * 4u < fe) add4(q * 4u, w, fa, fe);
+                            q += 64u;
+                            w = w2;
+                            if ((q + 64u) * 4u < fe) w2 = *reinterpret_cast<const uint2 *>(cur.src[u] + (size_t)(q + 64u) * 4u);   // (runs beyond 512 records: further groups, loaded here)
+                        }
                     }
                 }
                 AP(4)
@@ -2905,7 +2932,7 @@ void launch_apply(uint8_t *sim, size_t sim_bytes, const uint32_t *recs, const ui
 // second level by tiles (k_sort_tiles + k_apply_tiles).  tbase: n_bins + 1 words; idx: (tiles + n_bins) * (f2 + 1) 16-bit entries;
 // out16: PART_TILE 16-bit records per tile row (tiles_bound() rows at most)
 void launch_apply_by_tiles(uint8_t *sim, size_t sim_bytes, const uint32_t *recs, const uint64_t *binbase, uint32_t n_bins, uint32_t bin_shift,
-                           uint32_t *tbase, uint16_t *idx, uint16_t *out16, hipStream_t st)
+                           uint32_t *tbase, uint16_t *idx, uint16_t *out16, bool many_records, hipStream_t st)
 {
     hipLaunchKernelGGL(k_tile_bases, dim3(1), dim3(PART_WG), 0, st, binbase, n_bins, tbase);
     // enough workgroups to fill the device evenly: about 8 per CU (two are resident at a time)
@@ -2915,9 +2942,13 @@ void launch_apply_by_tiles(uint8_t *sim, size_t sim_bytes, const uint32_t *recs,
     static std::atomic<uint32_t> resident_of[MAX_DEV];           // workgroups that fit the device at once (two per CU: 64 KB of LDS each)
     std::atomic<uint32_t> &slot = resident_of[cur_device()];
     uint32_t resident = slot.load(std::memory_order_relaxed);
-    if (!resident) { resident = resident_blocks(k_apply_tiles, APPLY_WG); slot.store(resident, std::memory_order_relaxed); }
+    if (!resident) { resident = resident_blocks(k_apply_tiles<false>, APPLY_WG); slot.store(resident, std::memory_order_relaxed); }
     const uint32_t grid = n_regions < resident ? n_regions : resident;
-    hipLaunchKernelGGL(k_apply_tiles, dim3(grid ? grid : 1u), dim3(APPLY_WG), 0, st, sim, sim_bytes, out16, tbase, idx, bin_shift, n_regions);
+    // the variant for many records (a step's groups 64 .. 79 in one pass): N = 1e10 (1.2e9 records) 1.09 -> 0.84 ms, configs[4]'s shape (3.2e8)
+    // 2.43 -> 2.08; the other one where there are fewer: configs[2] (1.2e8) +3 %, configs[3]'s shape +3 %, text +7 % with the first
+    if (const char *e = getenv("LIME_APPLY_WIDE")) many_records = atoi(e) != 0;            // tests: either variant on any input
+    if (many_records) hipLaunchKernelGGL(k_apply_tiles<true>, dim3(grid ? grid : 1u), dim3(APPLY_WG), 0, st, sim, sim_bytes, out16, tbase, idx, bin_shift, n_regions);
+    else hipLaunchKernelGGL(k_apply_tiles<false>, dim3(grid ? grid : 1u), dim3(APPLY_WG), 0, st, sim, sim_bytes, out16, tbase, idx, bin_shift, n_regions);
 }
 uint64_t tiles_bound(uint64_t n_records, uint32_t n_bins) { return n_records / PART_TILE + n_bins; }
 

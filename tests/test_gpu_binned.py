@@ -348,3 +348,27 @@ def test_whole_line_partition_on_a_table_of_two_sub_regions(monkeypatch):
         finally:
             c.close()
     assert tabs[0][1] == tabs[1][1] and torch.equal(tabs[0][0], tabs[1][0])
+
+
+@pytest.mark.parametrize("levels,nr,ng,mode", [("1,1", 3000, 300, 1), ("2,3", 5000, 1200, 0), ("4,7", 40000, 700, 1), ("1,2", 1, 1, 0), (None, 150000, 3000, 0)])
+def test_apply_variant_for_many_records_on_small_inputs(monkeypatch, levels, nr, ng, mode):
+    """k_apply_tiles<true> (chosen at the launch from about 2e8 records on: a step's groups 64 .. 79 of four runs added in one
+    pass, longer runs in a loop) forced on small inputs with LIME_APPLY_WIDE=1: one bin for the whole table (runs of
+    thousands of records per tile and region: the loop), bins of a few regions (runs around 256: the shared pass), the
+    default layout; wrap-around cells (few reads) take the exact second pass"""
+    import lime_amd
+    monkeypatch.setenv("LIME_UPDATE_PATH", "bin")
+    monkeypatch.setenv("LIME_APPLY_WIDE", "1")
+    if levels:
+        monkeypatch.setenv("LIME_BIN_LEVELS", levels)
+    c = lime_amd.Context()
+    try:
+        n = 1500000
+        lcp, da, eb = O.synth(900 + nr, 0, n, nr, ng, 16, mode)
+        cl, nc, ml = O.detect(lcp, da, nr, 16)
+        for e in (eb, None):
+            exp = O.score(da, e, cl, nr, ng, threads=4)
+            sim, gnc, gml = c.fused(lcp, da, e, nr, ng, 16)
+            assert (gnc, gml) == (nc, ml) and np.array_equal(sim, exp), (levels, nr, ng, int((sim != exp).sum()))
+    finally:
+        c.close()
