@@ -1688,7 +1688,10 @@ extern "C" int lime_debug_part_times(unsigned long long *out)
 }
 #define PT_DECL_ uint64_t pp_t = __builtin_readcyclecounter(), pp_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
 #define PT_(i) { const uint64_t n_ = __builtin_readcyclecounter(); pp_acc[i] += n_ - pp_t; pp_t = n_; }
-#define PT_END_ if (threadIdx.x == 0) { for (int i_ = 0; i_ < 8; ++i_) atomicAdd(&g_part_pt[i_], (unsigned long long)pp_acc[i_]); }
+#ifndef LIME_PT_WAVE
+#define LIME_PT_WAVE 0               // the wave of every workgroup whose cycles are summed (tools/r04_part_phases_waves.sh)
+#endif
+#define PT_END_ if (threadIdx.x == 64 * LIME_PT_WAVE) { for (int i_ = 0; i_ < 8; ++i_) atomicAdd(&g_part_pt[i_], (unsigned long long)pp_acc[i_]); }
 #endif
 #ifdef LIME_PART_TIMING
 #define PP_DECL PT_DECL_
