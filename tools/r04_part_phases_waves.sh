@@ -1,6 +1,7 @@
 #!/bin/bash
 # tools/r04_part_phases_waves.sh -- k_part_lines' phases as seen by the workgroup's first, fourth and last wave (variants/lib_ppt{0,3,7}.so:
 # -DLIME_PART_TIMING -DLIME_PT_WAVE=w): do the waves reach the barriers together?
+# build them first:  for w in 0 3 7; do make -C lime_amd/csrc -s EXTRA="-DLIME_PART_TIMING -DLIME_PT_WAVE=$w" -B ../liblime_hip.so && cp lime_amd/liblime_hip.so variants/lib_ppt$w.so; done; make -C lime_amd/csrc -s -B ../liblime_hip.so
 cp lime_amd/liblime_hip.so /tmp/lib_keep.so
 for w in 0 3 7; do
 cp variants/lib_ppt$w.so lime_amd/liblime_hip.so
