@@ -2,7 +2,7 @@
 # tools/r04_part_phases.sh -- where k_part's cycles go (variants/lib_ppt.so: -DLIME_PART_TIMING): per phase, summed over wave 0 of every workgroup
 # build the instrumented library first:  make -C lime_amd/csrc -s EXTRA=-DLIME_PART_TIMING -B ../liblime_hip.so && mkdir -p variants && cp lime_amd/liblime_hip.so variants/lib_ppt.so && make -C lime_amd/csrc -s -B ../liblime_hip.so
 cp lime_amd/liblime_hip.so /tmp/lib_keep.so; cp variants/lib_ppt.so lime_amd/liblime_hip.so
-for shape in "1000000000 1000000 5000" "10000000000 1000000 1000"; do
+for shape in ${SHAPES:-"1000000000 1000000 5000" "10000000000 1000000 1000"}; do
 set -- $shape
 LIME_PART_LINES=${LINES:-0} LIME_PART_SPLIT=${SPLIT:-4} C3_PATHS=bin C3_N=$1 C3_NR=$2 C3_NG=$3 python3 - <<'PY'
 import os, sys, ctypes, json, subprocess
