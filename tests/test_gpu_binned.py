@@ -372,3 +372,25 @@ def test_apply_variant_for_many_records_on_small_inputs(monkeypatch, levels, nr,
             assert (gnc, gml) == (nc, ml) and np.array_equal(sim, exp), (levels, nr, ng, int((sim != exp).sum()))
     finally:
         c.close()
+
+
+@pytest.mark.parametrize("wide", ["0", "1"])
+def test_one_bin_of_more_than_512_tiles(monkeypatch, wide):
+    """the whole table one bin (LIME_BIN_LEVELS=1,1) with more records than 512 second-level tiles hold: k_apply_tiles walks the
+    bin's tiles in rounds of 512 (a lane per tile and wave), reloading its index entries per round -- both variants of the kernel"""
+    import lime_amd
+    monkeypatch.setenv("LIME_UPDATE_PATH", "bin")
+    monkeypatch.setenv("LIME_BIN_LEVELS", "1,1")
+    monkeypatch.setenv("LIME_APPLY_WIDE", wide)
+    c = lime_amd.Context()
+    try:
+        n, nr, ng = 40_000_000, 3000, 300
+        lcp, da, _ = O.synth(4242, 0, n, nr, ng, 16, 0)
+        cl, nc, ml = O.detect(lcp, da, nr, 16)
+        exp = O.score(da, None, cl, nr, ng, threads=8)
+        sim, gnc, gml = c.fused(lcp, da, None, nr, ng, 16)
+        s, rc = c.stats()
+        assert rc == 0 and s.n_updates > 512 * 8192, int(s.n_updates)      # more than 512 tiles in the one bin
+        assert (gnc, gml) == (nc, ml) and np.array_equal(sim, exp), int((sim != exp).sum())
+    finally:
+        c.close()
