@@ -499,9 +499,9 @@ static int fused_dev_impl(lime_ctx *c, const uint32_t *d_lcp, const uint32_t *d_
             // the records grouped by bin are the result: the owners of the bins build the table (lime_apply_records_dev)
         } else if (bin_shift > REGION_SHIFT && c->by_tiles) {      // second level tile by tile into the (by now free) pool, regions from the tiles' runs
             // (how many records: what the last pass counted per symbol, once one has been read back)
-            const bool many = c->density_known && c->density * (double)n_own >= 2e8;
+            const double expect = c->density_known ? c->density * (double)n_own : 0.0;
             launch_apply_by_tiles(d_sim, sim_bytes, c->d_recs, c->d_binbase, n_bins, bin_shift, c->d_tbase, c->d_tidx,
-                                  reinterpret_cast<uint16_t *>(c->d_pool), many, st);
+                                  reinterpret_cast<uint16_t *>(c->d_pool), expect >= 2e8, st, expect >= 1e8);
         } else if (bin_shift > REGION_SHIFT) {            // second level into the (by now free) pool, then regions from there
             uint32_t *recs2 = c->d_pool;
             launch_part2(c->d_recs, c->d_binbase, n_bins, bin_shift, c->d_regbase, recs2, st);
@@ -656,7 +656,7 @@ extern "C" int lime_apply_records_dev(lime_ctx *c, uint32_t n_src, const uint32_
     launch_regroup(d_rx, d_srcoff, n_src, nb, d_dstbase, c->d_xrecs, st);
     if (bin_shift > REGION_SHIFT && c->by_tiles) {
         launch_apply_by_tiles(d_block, (size_t)block_bytes, c->d_xrecs, d_dstbase, nb, bin_shift, c->d_tbase, c->d_tidx,
-                              reinterpret_cast<uint16_t *>(c->d_xrecs2), total >= 200000000ull, st);
+                              reinterpret_cast<uint16_t *>(c->d_xrecs2), total >= 200000000ull, st, total >= 100000000ull);
     } else if (bin_shift > REGION_SHIFT) {
         launch_part2(c->d_xrecs, d_dstbase, nb, bin_shift, c->d_xreg, c->d_xrecs2, st);
         HIP_TRY(hipMemcpyAsync(c->d_xreg + n_reg, d_dstbase + nb, sizeof(uint64_t), hipMemcpyDeviceToDevice, st));

@@ -116,7 +116,7 @@ void launch_part2(const uint32_t *recs, const uint64_t *binbase, uint32_t n_bins
 void launch_apply(uint8_t *sim, size_t sim_bytes, const uint32_t *recs, const uint64_t *regbase, uint32_t bin_shift, hipStream_t st);
 void launch_resolve(int mode, const ScanArgs &a, hipStream_t st);
 void launch_apply_by_tiles(uint8_t *sim, size_t sim_bytes, const uint32_t *recs, const uint64_t *binbase, uint32_t n_bins, uint32_t bin_shift,
-                           uint32_t *tbase, uint16_t *idx, uint16_t *out16, bool many_records, hipStream_t st);   // many_records: about 2e8 and more (a variant of k_apply_tiles)
+                           uint32_t *tbase, uint16_t *idx, uint16_t *out16, bool many_records, hipStream_t st, bool big_rows = false);   // many_records: about 2e8 and more (a variant of k_apply_tiles); big_rows: about 1e8 records and more (the 16-bit rows written non-temporally)
 uint64_t tiles_bound(uint64_t n_records, uint32_t n_bins);
 uint32_t part_tile();
 uint32_t row_stride();

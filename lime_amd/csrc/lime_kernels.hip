@@ -2181,7 +2181,7 @@ __global__ __launch_bounds__(PART_WG) void k_tile_bases(const uint64_t *binbase,
 }
 
 __global__ __launch_bounds__(PART_WG) void k_sort_tiles(const uint32_t *recs, const uint64_t *binbase, uint32_t bin_shift,
-                                                        const uint32_t *tbase, uint16_t *idx, uint16_t *out16)
+                                                        const uint32_t *tbase, uint16_t *idx, uint16_t *out16, uint32_t nt_rows)
 {
     constexpr uint32_t F2MAX = 1u << (BIN_SHIFT_MAX - REGION_SHIFT);
     __shared__ uint4 stage4[PART_TILE / 8];                              // the tile's 16-bit offsets, sorted by region
@@ -2257,7 +2257,14 @@ __global__ __launch_bounds__(PART_WG) void k_sort_tiles(const uint32_t *recs, co
         ST(6)
         const uint32_t nv = nv_s;                                        // records of the tile
         uint4 *dst = reinterpret_cast<uint4 *>(out16 + (size_t)(row0 + row) * ROW_STRIDE);
-        for (uint32_t i = tid; i < (nv + 7u) / 8u; i += PART_WG) dst[i] = stage4[i];       // whole 16-byte groups: the row is the tile's alone
+        // (whole 16-byte groups: the row is the tile's alone.  Non-temporal where the rows of the pass do not fit the Infinity Cache anyway -- N = 1e10
+        // 1.56 -> 1.50 ms and 3 % in k_apply_tiles, configs[4]'s shape 433 -> 391 us --; where they do, plain stores leave them there for
+        // k_apply_tiles: the text workload's 48 MB of rows 65 against 101 us in that kernel)
+        if (nt_rows) {
+            typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+            for (uint32_t i = tid; i < (nv + 7u) / 8u; i += PART_WG) { const uint4 v = stage4[i]; const u32x4 x = {v.x, v.y, v.z, v.w}; __builtin_nontemporal_store(x, reinterpret_cast<u32x4 *>(dst + i)); }
+        } else
+            for (uint32_t i = tid; i < (nv + 7u) / 8u; i += PART_WG) dst[i] = stage4[i];
         // (no barrier here: the next tile's ranks touch the counters only -- cleared above -- and its staging comes behind two barriers)
         ST(7)
     }
@@ -2440,8 +2447,12 @@ template <bool WIDE> __global__ __launch_bounds__(APPLY_WG) void k_apply_tiles(u
 #define LIME_RD(J) const uint4 o##J = rp[J * APPLY_WG];
             LIME_RD(0) LIME_RD(1) LIME_RD(2) LIME_RD(3) LIME_RD(4) LIME_RD(5) LIME_RD(6) LIME_RD(7)
 #undef LIME_RD
-            dp[0 * APPLY_WG] = o0; dp[1 * APPLY_WG] = o1; dp[2 * APPLY_WG] = o2; dp[3 * APPLY_WG] = o3;
-            dp[4 * APPLY_WG] = o4; dp[5 * APPLY_WG] = o5; dp[6 * APPLY_WG] = o6; dp[7 * APPLY_WG] = o7;
+            // (non-temporal: the table is written once and not read again by the pass -- configs[2] 0.98 -> 0.91 ms, the text workload 83 -> 64 us,
+            // configs[4]'s shape 2.06 -> 1.93 ms against plain stores, ABAB in one run)
+            typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+#define LIME_ST(J) { const u32x4 x = {o##J.x, o##J.y, o##J.z, o##J.w}; __builtin_nontemporal_store(x, reinterpret_cast<u32x4 *>(dp + J * APPLY_WG)); }
+            LIME_ST(0) LIME_ST(1) LIME_ST(2) LIME_ST(3) LIME_ST(4) LIME_ST(5) LIME_ST(6) LIME_ST(7)
+#undef LIME_ST
         } else {                                                  // the table's last region, cut short (it is its workgroup's last one)
             for (uint32_t i = threadIdx.x; i < left16; i += APPLY_WG) dst[i] = reg4[i];
         }
@@ -2935,12 +2946,14 @@ void launch_apply(uint8_t *sim, size_t sim_bytes, const uint32_t *recs, const ui
 // second level by tiles (k_sort_tiles + k_apply_tiles).  tbase: n_bins + 1 words; idx: (tiles + n_bins) * (f2 + 1) 16-bit entries;
 // out16: PART_TILE 16-bit records per tile row (tiles_bound() rows at most)
 void launch_apply_by_tiles(uint8_t *sim, size_t sim_bytes, const uint32_t *recs, const uint64_t *binbase, uint32_t n_bins, uint32_t bin_shift,
-                           uint32_t *tbase, uint16_t *idx, uint16_t *out16, bool many_records, hipStream_t st)
+                           uint32_t *tbase, uint16_t *idx, uint16_t *out16, bool many_records, hipStream_t st, bool big_rows)
 {
+    if (const char *e = getenv("LIME_SORT_NT")) big_rows = atoi(e) != 0;                     // tests: either kind of row stores on any input
+
     hipLaunchKernelGGL(k_tile_bases, dim3(1), dim3(PART_WG), 0, st, binbase, n_bins, tbase);
     // enough workgroups to fill the device evenly: about 8 per CU (two are resident at a time)
     const uint32_t per_bin = n_bins >= 2048u ? 1u : (2048u + n_bins - 1u) / n_bins;
-    hipLaunchKernelGGL(k_sort_tiles, dim3(n_bins, per_bin), dim3(PART_WG), 0, st, recs, binbase, bin_shift, tbase, idx, out16);
+    hipLaunchKernelGGL(k_sort_tiles, dim3(n_bins, per_bin), dim3(PART_WG), 0, st, recs, binbase, bin_shift, tbase, idx, out16, big_rows ? 1u : 0u);
     const uint32_t n_regions = (uint32_t)((sim_bytes + ((size_t)1 << REGION_SHIFT) - 1) >> REGION_SHIFT);
     static std::atomic<uint32_t> resident_of[MAX_DEV];           // workgroups that fit the device at once (two per CU: 64 KB of LDS each)
     std::atomic<uint32_t> &slot = resident_of[cur_device()];
