@@ -2041,7 +2041,7 @@ __global__ __launch_bounds__(PART_WG) void k_part_lines(ScanArgs a, const uint64
                     val[u] = on[u] ? *srcp : 0u;
                 }
 #pragma unroll
-                for (uint32_t u = 0; u < UT; ++u) if (on[u]) out[pp[u]] = val[u];
+                for (uint32_t u = 0; u < UT; ++u) if (on[u]) __builtin_nontemporal_store(val[u], out + pp[u]);      // (whole lines, read once by the next kernel: -1.5 % against plain stores)
             }
         }
 
