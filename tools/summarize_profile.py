@@ -34,14 +34,20 @@ def main():
     stats = glob.glob(os.path.join(src, "trace", "**", "*kernel_stats.csv"), recursive=True)
     if not stats:
         sys.exit("no kernel_stats.csv under " + src)
-    shutil.copy(stats[0], os.path.join(dst, tag + "_kernel_stats.csv"))
+    # (gpurun merges a run's files into gpurun_out/ without removing older ones: the newest file of every pass counts)
+    shutil.copy(max(stats, key=os.path.getmtime), os.path.join(dst, tag + "_kernel_stats.csv"))
     bl = os.path.join(src, "bench_line.json")
     bench = None
     if os.path.exists(bl) and os.path.getsize(bl):
         bench = json.load(open(bl))
         json.dump(bench, open(os.path.join(dst, tag + "_bench.json"), "w"), indent=1)
     acc = defaultdict(lambda: defaultdict(list))
+    newest = {}
     for path in glob.glob(os.path.join(src, "pmc*", "**", "*counter_collection.csv"), recursive=True):
+        d = os.path.relpath(path, src).split(os.sep)[0]
+        if d not in newest or os.path.getmtime(path) > os.path.getmtime(newest[d]):
+            newest[d] = path
+    for path in sorted(newest.values()):
         per_dispatch = defaultdict(float)
         names = {}
         with open(path) as f:
