@@ -83,7 +83,7 @@ struct lime_ctx {
     double pool_density = 0.20;             // records per owned symbol the pool is sized for before a pass has been measured (grows on LIME_FLAG_POOL_FULL)
     bool pool_density_fixed = false;        // set by LIME_POOL_DENSITY or by a repeated pass: sizing_density() then leaves it alone
     uint32_t scan_static_pct = 75;          // share of the scan's rounds of window chunks that go round-robin; the rest is handed out as workgroups get there (LIME_SCAN_STATIC_PCT: tests)
-    uint32_t part_split = 4;                // producers (of k_part) per scan workgroup at most (LIME_PART_SPLIT: comparison runs)
+    uint32_t part_split = 2;                // producers (of k_part) per scan workgroup at most (LIME_PART_SPLIT: comparison runs): two = one partition workgroup per resident slot of the device; four -- round 4's first choice -- cut the streams into more, less filled tiles: k_part_lines +4 % at N = 1e10 and on the text workload
     uint32_t pool_slack = 512;              // + this many records per wave and sub-region (LIME_POOL_SLACK: tests make pools overflow)
     struct Last {                           // the last lime_fused_dev call, so that lime_get_stats can repeat it with a larger pool
         bool valid = false, binned = false;
