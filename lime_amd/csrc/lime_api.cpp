@@ -82,7 +82,7 @@ struct lime_ctx {
     uint32_t bin_one_level = BIN_ONE_LEVEL, bin_two_level = BIN_TWO_LEVEL;   // LIME_BIN_LEVELS="a,b" (tests: force the second level on small tables)
     double pool_density = 0.20;             // records per owned symbol the pool is sized for before a pass has been measured (grows on LIME_FLAG_POOL_FULL)
     bool pool_density_fixed = false;        // set by LIME_POOL_DENSITY or by a repeated pass: sizing_density() then leaves it alone
-    uint32_t scan_static_pct = 75;          // share of the scan's rounds of window chunks that go round-robin; the rest is handed out as workgroups get there (LIME_SCAN_STATIC_PCT: tests)
+    int scan_static_pct = -1;               // share (%) of the scan's rounds of window chunks that go round-robin, the rest is handed out as workgroups get there; -1: by the input's length (base_args); LIME_SCAN_STATIC_PCT: tests, comparison runs
     uint32_t part_split = 2;                // producers (of k_part) per scan workgroup at most (LIME_PART_SPLIT: comparison runs): two = one partition workgroup per resident slot of the device; four -- round 4's first choice -- cut the streams into more, less filled tiles: k_part_lines +4 % at N = 1e10 and on the text workload
     uint32_t pool_slack = 512;              // + this many records per wave and sub-region (LIME_POOL_SLACK: tests make pools overflow)
     struct Last {                           // the last lime_fused_dev call, so that lime_get_stats can repeat it with a larger pool
@@ -156,7 +156,7 @@ extern "C" int lime_init(int device, lime_ctx **out)
         if (sscanf(s, "%u,%u", &a1, &a2) == 2 && a1 >= 1 && a2 >= 1 && a1 <= BIN_MAX && a2 <= BIN_MAX) { c->bin_one_level = a1; c->bin_two_level = a2; c->bin_levels_forced = true; }
     }
     if (const char *s = getenv("LIME_POOL_DENSITY")) { const double v = atof(s); if (v > 0) { c->pool_density = v; c->pool_density_fixed = true; } }   // tests: force a small pool
-    if (const char *s = getenv("LIME_SCAN_STATIC_PCT")) { const long v = atol(s); if (v >= 0 && v <= 100) c->scan_static_pct = (uint32_t)v; }
+    if (const char *s = getenv("LIME_SCAN_STATIC_PCT")) { const long v = atol(s); if (v >= 0 && v <= 100) c->scan_static_pct = (int)v; }
     if (const char *s = getenv("LIME_SECOND_LEVEL")) c->by_tiles = strcmp(s, "sweeps") != 0;
     if (const char *s = getenv("LIME_PART_SPLIT")) { const long v = atol(s); if (v >= 1 && v <= 16) c->part_split = (uint32_t)v; }
     if (const char *s = getenv("LIME_POOL_SLACK")) { const long v = atol(s); if (v >= 0) c->pool_slack = (uint32_t)v; }
@@ -251,7 +251,11 @@ static ScanArgs base_args(lime_ctx *c, const uint32_t *lcp, const uint32_t *da, 
     a.tile_cnt = c->d_tile_cnt; a.tile_off = c->d_tile_off; a.cross = c->d_cross; a.out = c->d_out;
     a.wmask = c->d_wmask;
     a.edge = &c->d_stats->edge;
-    a.sticky = c->d_sticky; a.dyn = c->d_sticky + 1; a.static_pct = c->scan_static_pct;
+    a.sticky = c->d_sticky; a.dyn = c->d_sticky + 1;
+    // Measured with the final round-4 kernels (LIME_SCAN_STATIC_PCT = 0 / 25 / 50 / 75, ABAB): long inputs run faster with every chunk but a
+    // workgroup's first handed out as the workgroups get there (configs[2] 1.66 -> 1.60 ms, N = 1e10 14.6 -> 14.4, configs[4]'s shape 17.1 -> 15.9),
+    // 1e8 symbols 1 .. 2 % faster with three quarters of the rounds round-robin (fewer trips to the device-wide counter in a 0.2 ms kernel)
+    a.static_pct = c->scan_static_pct >= 0 ? (uint32_t)c->scan_static_pct : (n_avail >= 500000000ull ? 0u : 75u);
     a.ablate = c->ablate;
     return a;
 }
