@@ -47,6 +47,10 @@ WORKLOADS = {
     # the reference's default build (EBWT=1) at the shapes of configs[3] and configs[4], on one GPU (synthetic generator: the real collections are not in the image)
     "c4_shape": dict(n=2_000_000_000, nr=20_249_373, ng=930, ebwt=1, mode=0, what="shape of BASELINE.json configs[3] (setB2: 20 249 373 reads x 930 genomes), 2*10^9 symbols on one GPU"),
     "c5_shape": dict(n=10_000_000_000, nr=3_000_000, ng=3423, ebwt=1, mode=0, what="shape of BASELINE.json configs[4] (3*10^6 reads x 3423 genomes), 10^10 symbols on one GPU"),
+    # the same two N = 10^10 shapes with the "clustered" generator (more and longer clusters, 25 % reads): several times the update
+    # density of the iid generator -- the regime of real collections, where rounds 1-4 fell back to compare-and-swap (32-bit record positions)
+    "c5_clustered": dict(n=10_000_000_000, nr=3_000_000, ng=3423, ebwt=1, mode=1, what="shape of BASELINE.json configs[4], clustered generator, 10^10 symbols on one GPU"),
+    "n1e10_clustered": dict(n=10_000_000_000, nr=1_000_000, ng=1000, ebwt=0, mode=1, what="north_star scaling series N = 10^10, clustered generator"),
     # text-derived statistics: tests/golden/text_example.npz (2000 example reads x 3 surrogate genomes, 442 003 symbols, 49.5 % of
     # them in clusters, 0.24 table updates per symbol) laid side by side 226 times, every copy with its own reads and genomes
     "text_tiled": dict(n=226 * 442_003, nr=226 * 2000, ng=226 * 3, ebwt=1, mode=-1, tiled=226,
@@ -61,9 +65,12 @@ def describe(wl, n_total, world):
             + (f"; cut into {world} position ranges" if world > 1 else ""))
 
 
-def cpu_baseline(wl, lcp_t, da_t, eb_t, n, sample_n):
-    """The reference's programs on the first `sample_n` symbols (bounded: about 10-30 s of CPU work), all cores the
-    box gives this process and one thread; wall time of the two processes and the reference's own timer lines."""
+def cpu_baseline(wl, lcp_t, da_t, eb_t, n, sample_n, full=True):
+    """The reference's own programs (oracle/_ref) beside the GPU number.  README.md:145 runs them with 4 threads: that point is timed on the
+    WHOLE workload when it has at most 10^9 symbols (about 20 s; round 4 timed every point on the first 2*10^8 symbols against the full
+    10^6 x 5000 table, which charged the table's allocation and the single-threaded clusterChoose -- about 4.4 s -- to a fifth of the
+    symbols); one thread and all cores the box gives this process run on the first `sample_n` symbols (bounded), and for those the
+    fixed part (the reference's own `Time:` lines of the table set-up / clusterChoose) is reported separately."""
     import numpy as np
     try:
         aff = sorted(os.sched_getaffinity(0))
@@ -73,44 +80,62 @@ def cpu_baseline(wl, lcp_t, da_t, eb_t, n, sample_n):
     sample_n = min(sample_n, n)
     ref = os.path.join(ROOT, "oracle", "_ref")
     bwt = "ClusterBWT_DA" if wl["ebwt"] else "ClusterBWT_DA_e0"
-    sample = (f"first {sample_n} symbols of the bench workload (seed {SEED}, mode {wl['mode']}), {wl['nr']}x{wl['ng']}, "
-              f"alpha {ALPHA}, EBWT={wl['ebwt']}")
-    lcp = lcp_t[:sample_n].cpu().numpy().view(np.uint32)
-    da = da_t[:sample_n].cpu().numpy().view(np.uint32)
-    eb = eb_t[:sample_n].cpu().numpy() if eb_t is not None else None
+    what = f"bench workload (seed {SEED}, mode {wl['mode']}), {wl['nr']}x{wl['ng']}, alpha {ALPHA}, EBWT={wl['ebwt']}"
     if not (os.path.exists(f"{ref}/ClusterLCP") and os.path.exists(f"{ref}/{bwt}")):
         from oracle import oracle_py as O
+        lcp = lcp_t[:sample_n].cpu().numpy().view(np.uint32); da = da_t[:sample_n].cpu().numpy().view(np.uint32)
+        eb = eb_t[:sample_n].cpu().numpy() if eb_t is not None else None
         t0 = time.perf_counter()
         cl, nc, ml = O.detect(lcp, da, wl["nr"], ALPHA)
         O.score(da, eb, cl, wl["nr"], wl["ng"], threads=cores)
         t1 = time.perf_counter()
-        return {"value": sample_n / (t1 - t0), "unit": "symbols/s", "cores": cores, "kind": "port", "sample": sample}
+        return {"value": sample_n / (t1 - t0), "unit": "symbols/s", "cores": cores, "kind": "port", "sample": f"first {sample_n} symbols of the {what}"}
 
     def timers(text):
         return [ln.strip() for ln in text.splitlines() if re.match(r"\s*(TIME (clusterAnalyze|clusterChoose)|Time:)", ln)]
 
+    def to_files(base, count):                 # the arrays' first `count` elements as the reference's input files, in pieces (no second copy of 8 GB on the host)
+        for t, ext in ((lcp_t, ".lcp"), (da_t, ".da"), (eb_t, ".ebwt")):
+            if t is None:
+                continue
+            with open(base + ext, "wb") as f:
+                for lo in range(0, count, 1 << 27):
+                    f.write(t[lo:min(count, lo + (1 << 27))].cpu().numpy().tobytes())
+
+    def run(td, base, count, thr):
+        t0 = time.perf_counter()
+        p1 = subprocess.run([f"{ref}/ClusterLCP", base, str(wl["nr"]), str(wl["ng"]), str(ALPHA), str(thr)], check=True, capture_output=True, cwd=td, timeout=1500)
+        t1 = time.perf_counter()
+        p2 = subprocess.run([f"{ref}/{bwt}", base, "100", "0.25", str(thr)], check=True, capture_output=True, cwd=td, timeout=1500)
+        t2 = time.perf_counter()
+        tm = timers(p2.stdout.decode(errors="replace") + p2.stderr.decode(errors="replace"))
+        ana = [float(m.group(1)) for ln in tm for m in [re.search(r"TIME clusterAnalyze[^0-9]*([0-9.]+)", ln)] if m]
+        out = {"threads": thr, "symbols": count, "symbols_per_s": count / (t2 - t0), "wall_s": {"ClusterLCP": t1 - t0, "ClusterBWT_DA": t2 - t1},
+               "reference_timers": {"ClusterLCP": timers(p1.stdout.decode(errors="replace")), "ClusterBWT_DA": tm}}
+        if ana:                                # the scan + the per-cluster analysis alone (what the GPU pass replaces), without the table set-up and clusterChoose
+            out["symbols_per_s_scan_and_analyze"] = count / ((t1 - t0) + max(ana))
+        return out
+
     runs = {}
     with tempfile.TemporaryDirectory(dir="/tmp") as td:
         base = os.path.join(td, "S.fasta")
-        lcp.tofile(base + ".lcp"); da.tofile(base + ".da")
-        if eb is not None:
-            eb.tofile(base + ".ebwt")
-        for label, thr in (("all_cores", cores), ("four_threads", min(4, cores)), ("one_thread", 1)):   # README.md:145 uses 4
-            t0 = time.perf_counter()
-            p1 = subprocess.run([f"{ref}/ClusterLCP", base, str(wl["nr"]), str(wl["ng"]), str(ALPHA), str(thr)],
-                                check=True, capture_output=True, cwd=td, timeout=1500)
-            t1 = time.perf_counter()
-            p2 = subprocess.run([f"{ref}/{bwt}", base, "100", "0.25", str(thr)],
-                                check=True, capture_output=True, cwd=td, timeout=1500)
-            t2 = time.perf_counter()
-            runs[label] = {"threads": thr, "symbols_per_s": sample_n / (t2 - t0),
-                           "wall_s": {"ClusterLCP": t1 - t0, "ClusterBWT_DA": t2 - t1},
-                           "reference_timers": {"ClusterLCP": timers(p1.stdout.decode(errors="replace")),
-                                                "ClusterBWT_DA": timers(p2.stdout.decode(errors="replace") + p2.stderr.decode(errors="replace"))}}
-    best = max(runs.values(), key=lambda x: x["symbols_per_s"])      # the reference's best thread count on this box is the baseline
-    return {"value": best["symbols_per_s"], "unit": "symbols/s", "cores": best["threads"], "kind": "reference",
-            "sample": sample + "; wall time of the reference's ClusterLCP + ClusterBWT_DA processes (files in page cache; "
-                               "ClusterBWT_DA's wall includes allocating/zeroing the table and the single-threaded clusterChoose)",
+        do_full = full and n <= 1_000_000_000 and n > sample_n
+        to_files(base, n if do_full else sample_n)
+        if do_full:
+            runs["four_threads_whole_workload"] = run(td, base, n, min(4, cores))
+            for ext in (".lcp", ".da", ".ebwt"):       # cut the files down to the sample for the other two points
+                if os.path.exists(base + ext):
+                    os.truncate(base + ext, sample_n * (1 if ext == ".ebwt" else 4))
+        else:
+            runs["four_threads"] = run(td, base, sample_n, min(4, cores))
+        runs["all_cores"] = run(td, base, sample_n, cores)
+        runs["one_thread"] = run(td, base, sample_n, 1)
+    main_run = runs.get("four_threads_whole_workload") or max(runs.values(), key=lambda x: x["symbols_per_s"])
+    return {"value": main_run["symbols_per_s"], "unit": "symbols/s", "cores": main_run["threads"], "kind": "reference",
+            "sample": (f"the whole {what}: {main_run['symbols']} symbols" if "four_threads_whole_workload" in runs else f"first {sample_n} symbols of the {what}") +
+                      "; wall time of the reference's ClusterLCP + ClusterBWT_DA processes (files in page cache; ClusterBWT_DA's wall includes "
+                      "allocating/zeroing the table and the single-threaded clusterChoose); the other thread counts ran on the first "
+                      f"{sample_n} symbols (runs.*; their fixed table set-up weighs more there: see symbols_per_s_scan_and_analyze)",
             "nproc": os.cpu_count(), "affinity_cpus": len(aff), "runs": runs}
 
 
@@ -201,6 +226,22 @@ def run_pass_series(torch, lime_amd, ldist, wl, n_total, steps, warmup, world, r
             comm.barrier()
         torch.cuda.synchronize()
 
+    # ---- the COLD pass: the first one on a fresh context, as LiME_paired.sh:62-68 runs every collection -- once.  It pays the sampled
+    # density probe, the scratch / record-pool allocations, and (if the probe misled it) a repeated pass; wall clock around pass + statistics
+    cold = None
+    if world == 1:
+        torch.cuda.synchronize()
+        tc0 = time.perf_counter()
+        step()
+        s, rc = ctx.stats(stream)
+        torch.cuda.synchronize()
+        cold_ms = (time.perf_counter() - tc0) * 1e3
+        if rc:
+            sys.exit(f"scan failed: rc={rc}")
+        ht = ctx.host_times()
+        cold = {"cold_ms": cold_ms, "alloc_ms": ht["alloc_ms"], "probe_ms": ht["probe_ms"], "probes": ht["probes"], "repeated_passes": ht["repeats"],
+                "cas_fallbacks": ht["cas_fallbacks"], "records_per_symbol_probed": ht["records_per_symbol"],
+                "update_path": "binned" if s.wave_records_max > 0 else "compare-and-swap", "flags": int(s.flags)}
     for _ in range(warmup):
         step()
         s, rc = ctx.stats(stream)              # settles the pass: update path, pool size (a pass that overflowed its record pool is repeated here)
@@ -217,11 +258,23 @@ def run_pass_series(torch, lime_amd, ldist, wl, n_total, steps, warmup, world, r
     barrier()
     dt = time.perf_counter() - t0
     parts, launches = ctx.get_timing_ex()
+    # the same passes once more, one at a time (HIP events around each): median and minimum next to the mean of the timed region
+    each = []
+    if world == 1:
+        for _ in range(max(10, steps) if n_total <= 2_000_000_000 else max(5, steps)):
+            step()
+            p1, _n = ctx.get_timing_ex()
+            each.append(p1["pass"])
     ctx.set_timing(False)
     s, rc = ctx.stats(stream)
     if rc:
         sys.exit(f"scan failed: rc={rc}")
-    res = {"exchange": exchange, "dt": dt, "parts": parts, "launches": launches, "n_own": n_own, "n_clusters": int(s.n_clusters), "max_len": int(s.max_len),
+    if cold is not None:
+        ht = ctx.host_times()
+        cold["repeated_passes_after_cold"] = ht["repeats"] - cold["repeated_passes"]
+    each.sort()
+    res = {"exchange": exchange, "dt": dt, "parts": parts, "cold": cold, "flags": int(s.flags),
+           "pass_ms_each": {"n": len(each), "median": each[len(each) // 2], "min": each[0], "max": each[-1]} if each else None, "launches": launches, "n_own": n_own, "n_clusters": int(s.n_clusters), "max_len": int(s.max_len),
            "updates": int(s.n_updates), "binned": bool(s.wave_records_max > 0), "lcp": lcp, "da": da, "eb": eb}
     ctx.close()
     return res
@@ -230,7 +283,13 @@ def run_pass_series(torch, lime_amd, ldist, wl, n_total, steps, warmup, world, r
 def summarize(wl, r, n_total, steps):
     bps = 8 + wl["ebwt"]
     scan_ms, pass_ms = r["parts"]["scan"], r["parts"]["pass"]
+    cold = dict(r["cold"]) if r.get("cold") else None
+    if cold:
+        steady = r["dt"] / steps * 1e3
+        cold["minus_alloc_over_steady"] = (cold["cold_ms"] - cold["alloc_ms"]) / steady if steady else None
     return {"workload": describe(wl, n_total, 1), "ms_per_step": r["dt"] / steps * 1e3, "symbols_per_s": n_total * steps / r["dt"],
+            "pass_ms_each": r.get("pass_ms_each"), "cold": cold,
+            "pass_frac_median": bps * r["n_own"] / r["pass_ms_each"]["median"] / 1e6 / HBM_PEAK_GBS if r.get("pass_ms_each") else None,
             "update_path": "binned (records -> bins -> table regions built in LDS)" if r["binned"] else "compare-and-swap on the table",
             "kernel_ms_avg": scan_ms, "kernel_GBps": bps * r["n_own"] / scan_ms / 1e6 if scan_ms else None,
             "frac_of_hbm_peak": bps * r["n_own"] / scan_ms / 1e6 / HBM_PEAK_GBS if scan_ms else None,
@@ -306,7 +365,9 @@ def main():
     if rank == 0:
         bps = 8 + wl["ebwt"]
         scan_ms, pass_ms = r["parts"]["scan"], r["parts"]["pass"]
-        achieved = bps * r["n_own"] / (scan_ms * 1e-3) / 1e9 if scan_ms > 0 else 0.0
+        k_achieved = bps * r["n_own"] / (scan_ms * 1e-3) / 1e9 if scan_ms > 0 else 0.0
+        step_ms = dt / args.steps * 1e3
+        achieved = bps * r["n_own"] / (step_ms * 1e-3) / 1e9       # the WHOLE step (every kernel of a pass, N > 1: + the exchange): what `value` implies per GPU
         traffic, tsrc, pass_traffic = None, None, None
         tfile = os.path.join(ROOT, "profiles", "traffic.json")        # rocprofv3 --pmc results, see DESIGN.md
         if os.path.exists(tfile) and world == 1:
@@ -329,12 +390,16 @@ def main():
                                      f"send/receive), every rank builds its block of the table")) if world > 1 else "one GPU",
                        "update_path": "binned (records -> bins -> table regions built in LDS)" if r["binned"] else "compare-and-swap on the table",
                        "n_clusters": int(n_clusters), "max_cluster_len": int(max_len), "table_updates_rank0": r["updates"]},
+            # achieved / frac describe the STEP (= what `value` implies: algorithmic bytes of a pass / ms_per_step); the dominant kernel alone
+            # (k_scan, HIP events on its stream) is under kernel_*.  traffic = HBM bytes of ALL kernels of a pass, kernel_traffic of k_scan alone.
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
-                         "traffic": traffic, "traffic_source": tsrc, "kernel": kname, "kernel_ms_avg": scan_ms,
-                         "launches_timed": r["launches"], "algorithmic_bytes_per_launch": bps * r["n_own"],
+                         "frac_of": "the whole step (all kernels of a pass; N > 1: + the exchange) -- value x bytes per symbol / peak per GPU",
+                         "traffic": pass_traffic, "traffic_source": tsrc, "algorithmic_bytes_per_launch": bps * r["n_own"],
+                         "kernel": kname, "kernel_ms_avg": scan_ms, "kernel_achieved": k_achieved, "kernel_frac": k_achieved / HBM_PEAK_GBS,
+                         "kernel_traffic": traffic, "launches_timed": r["launches"],
                          "pass_ms_avg": pass_ms, "pass_achieved": bps * r["n_own"] / (pass_ms * 1e-3) / 1e9 if pass_ms else None,
                          "pass_frac": bps * r["n_own"] / (pass_ms * 1e-3) / 1e9 / HBM_PEAK_GBS if pass_ms else None,
-                         "pass_traffic": pass_traffic,          # HBM bytes of ALL kernels of a pass (same source as `traffic`, which covers the scan kernel alone)
+                         "pass_ms_each": r.get("pass_ms_each"), "cold": r.get("cold"),
                          "pass_parts_ms": r["parts"]},
         }
     if world == 1 and rank == 0 and not args.no_cpu:
@@ -349,12 +414,12 @@ def main():
     if not args.no_also:
         also = {}
         if world == 1:
-            for name in ("c2", "c2_clustered", "text_tiled", "n1e10", "c5_shape", "c4_shape"):
+            for name in ("c2", "c2_clustered", "text_tiled", "n1e10", "c5_shape", "c4_shape", "c5_clustered", "n1e10_clustered"):
                 if name == wname:
                     continue
                 w2 = WORKLOADS[name]
                 try:
-                    k = max(3, args.steps // 2) if name == "n1e10" else 3 if name in ("c5_shape", "c4_shape") else max(10, args.steps)
+                    k = max(5, args.steps // 2) if w2["n"] >= 10_000_000_000 else 3 if name == "c4_shape" else max(10, args.steps)
                     r2 = run_pass_series(torch, lime_amd, ldist, w2, w2["n"], k, 2, 1, 0, dev, None, overlap=False)
                     also[name] = summarize(w2, r2, w2["n"], k)
                     del r2

@@ -67,6 +67,7 @@ typedef struct {
 #define LIME_FLAG_BADCLUSTER 8u
 #define LIME_FLAG_OVERFLOW 16u   /* an internal cluster list was too small (cannot happen with the default sizing) */
 #define LIME_FLAG_POOL_FULL 32u  /* binned table updates: the record pool was too small; lime_get_stats repeats the pass */
+#define LIME_FLAG_CAS_FALLBACK 128u /* the pass wanted the binned update path and found no device memory for its records: it ran by compare-and-swap on the table instead (same result, several times slower); the reason is in lime_last_error().  Set by lime_get_stats; not an error */
 #define LIME_FLAG_INTERNAL 64u   /* a device-side invariant did not hold (the scan's window hand-out): the pass is invalid, LIME_ERR_HIP */
 
 /* Edge word of a shard (lime_stats_t.edge): what the host needs to decide about a run that crosses shard borders
@@ -149,7 +150,10 @@ size_t lime_sim_bytes(uint32_t n_reads, uint32_t n_refs);  /* n_reads*n_refs rou
  * is the read-ahead halo (the reference's straddle loop, ClusterLCP.cpp:246-264).  A cluster
  * belongs to the shard that owns its first position.  eof != 0: the arrays end at the true
  * end of the collection, so an open run closes at n_avail (ClusterLCP.cpp:244-245).
- * zero_sim != 0: clear d_sim first.  Counters: lime_get_stats. */
+ * zero_sim != 0: clear d_sim first.  Counters: lime_get_stats.
+ * Asynchronous on `stream`, except the FIRST pass on a ctx over 2^24 symbols or more: it is preceded by a sampled
+ * density probe (1/64 .. 1/256 of the windows, counted only) that synchronises the stream once -- the update path and the
+ * record pool are chosen from what it finds, so that the one pass LiME_paired.sh:62-68 runs lands right. */
 int lime_fused_dev(lime_ctx *ctx, const uint32_t *d_lcp, const uint32_t *d_da,
                    const uint8_t *d_ebwt, uint64_t n_own, uint64_t n_avail, int eof,
                    uint32_t n_reads, uint32_t n_refs, uint32_t alpha,
@@ -235,6 +239,11 @@ int lime_get_timing(lime_ctx *ctx, double *scan_ms_avg, uint64_t *launches);
 /* the same with the parts of a lime_fused_dev pass: ms_avg[0] the scan kernel, [1] the whole pass (table clear or
  * table build included), [2] everything after the scan kernel, [3] everything before it */
 int lime_get_timing_ex(lime_ctx *ctx, double ms_avg[4], uint64_t *launches);
+/* What the passes on this ctx have cost on the host side so far (LiME_paired.sh:62-68 runs every collection once: a cold pass pays all of it):
+ * out[0] ms inside device allocations, [1] ms inside the sampled density probe in front of the ctx's first pass (synchronisation included),
+ * [2] probes run, [3] passes repeated by lime_get_stats (record pool too small), [4] passes that fell back to compare-and-swap
+ * (LIME_FLAG_CAS_FALLBACK), [5] update records per owned symbol as last measured (-1: nothing measured yet). */
+int lime_get_host_times(lime_ctx *ctx, double out[6]);
 
 /* ---- multi-GPU: the one exchange step of the path (RCCL over xGMI; librccl is loaded on first use) ---- *
  * The reference partitions positions over OpenMP threads (ClusterLCP.cpp:150-161, skip :196-202, straddle

@@ -63,6 +63,7 @@ SYMBOLS = {
     "lime_set_timing": (_i, [_vp, _i]),
     "lime_get_timing": (_i, [_vp, C.POINTER(C.c_double), _pu64]),
     "lime_get_timing_ex": (_i, [_vp, C.POINTER(C.c_double), _pu64]),
+    "lime_get_host_times": (_i, [_vp, C.POINTER(C.c_double)]),
     "lime_sym_index": (C.c_uint8, [C.c_uint8]),
     "lime_pair_score": (C.c_uint8, [_vp, _vp]),
     "lime_write_clrs": (_i, [C.c_char_p, _vp, _u64]),

@@ -204,6 +204,14 @@ class Context:
         return {"scan": ms[0], "pass": ms[1], "after_scan": ms[2], "before_scan": ms[3]}, int(n.value)
 
 
+    def host_times(self):
+        """what the passes on this context cost on the host so far (lime_get_host_times)"""
+        v = (C.c_double * 6)()
+        check(self.lib.lime_get_host_times(self.h, v))
+        return {"alloc_ms": v[0], "probe_ms": v[1], "probes": int(v[2]), "repeats": int(v[3]), "cas_fallbacks": int(v[4]),
+                "records_per_symbol": None if v[5] < 0 else v[5]}
+
+
 def _ptr(t):
     if t is None:
         return None

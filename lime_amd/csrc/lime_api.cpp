@@ -9,6 +9,7 @@
 #include <stdlib.h>
 #include <string.h>
 #include <atomic>
+#include <chrono>
 #include <condition_variable>
 #include <functional>
 #include <mutex>
@@ -85,12 +86,19 @@ struct lime_ctx {
     int scan_static_pct = -1;               // share (%) of the scan's rounds of window chunks that go round-robin, the rest is handed out as workgroups get there; -1: by the input's length (base_args); LIME_SCAN_STATIC_PCT: tests, comparison runs
     uint32_t part_split = 2;                // producers (of k_part) per scan workgroup at most (LIME_PART_SPLIT: comparison runs): two = one partition workgroup per resident slot of the device; four -- round 4's first choice -- cut the streams into more, less filled tiles: k_part_lines +4 % at N = 1e10 and on the text workload
     uint32_t pool_slack = 512;              // + this many records per wave and sub-region (LIME_POOL_SLACK: tests make pools overflow)
+    bool probe = true;                      // LIME_NO_PROBE: no sampled density probe in front of a ctx's first pass (tests, comparison runs)
+    bool force_p64 = false;                 // LIME_FORCE_P64: the partition kernels' 64-bit-position variants on any pass (tests)
+    uint64_t p64_test_base = 0;             // LIME_P64_TEST_BASE (tests): the binned records' positions start at this number instead of 0 -- the bin bases are
+                                            // shifted by it and the kernels get the records' array address minus it --, so that a small pass crosses a multiple of 2^32
+    double alloc_ms = 0.0, probe_ms = 0.0; uint32_t n_probes = 0, n_repeats = 0, n_fallbacks = 0;   // host-side costs a cold pass pays (lime_get_host_times)
     struct Last {                           // the last lime_fused_dev call, so that lime_get_stats can repeat it with a larger pool
         bool valid = false, binned = false;
         const uint32_t *lcp = nullptr, *da = nullptr; const uint8_t *ebwt = nullptr;
         uint64_t n_own = 0, n_avail = 0; int eof = 0; uint32_t n_reads = 0, n_refs = 0, alpha = 0;
         uint8_t *sim = nullptr; int zero_sim = 0; hipStream_t st = nullptr; uint32_t n_waves = 0; bool records_only = false;
         uint64_t own_total = 0;             // owned symbols the counters in d_stats stand for (chunks of a stream accumulate)
+        double share = 1.0;                 // binned: the part of a wave's records one sub-region was sized for (sub_share)
+        bool fell_back = false;             // the binned path was wanted and could not be had (memory): LIME_FLAG_CAS_FALLBACK
     } last;
     // timing with HIP events on the launch stream: per pass {pass start, scan start, scan end, pass end}
     bool timing = false;
@@ -160,6 +168,9 @@ extern "C" int lime_init(int device, lime_ctx **out)
     if (const char *s = getenv("LIME_SECOND_LEVEL")) c->by_tiles = strcmp(s, "sweeps") != 0;
     if (const char *s = getenv("LIME_PART_SPLIT")) { const long v = atol(s); if (v >= 1 && v <= 16) c->part_split = (uint32_t)v; }
     if (const char *s = getenv("LIME_POOL_SLACK")) { const long v = atol(s); if (v >= 0) c->pool_slack = (uint32_t)v; }
+    if (const char *s = getenv("LIME_NO_PROBE")) c->probe = atoi(s) == 0;
+    if (const char *s = getenv("LIME_FORCE_P64")) c->force_p64 = atoi(s) != 0;
+    if (const char *s = getenv("LIME_P64_TEST_BASE")) { c->p64_test_base = strtoull(s, nullptr, 0) & ~15ull; if (c->p64_test_base) c->force_p64 = true; }
     if (const char *s = getenv("LIME_MAX_BLOCKS")) { long v = atol(s); if (v > 0) c->max_blocks = (uint32_t)v; }
     *out = c;
     return LIME_OK;
@@ -183,10 +194,14 @@ extern "C" void lime_shutdown(lime_ctx *c)
     delete c;
 }
 
+static thread_local double g_alloc_ms = 0.0;             // (host time spent in hipFree / hipMalloc by regrow: moved into the ctx's account by its callers)
 template <typename T> static int regrow(T *&p, size_t count)
 {
+    const auto t0 = std::chrono::steady_clock::now();
     if (p) { (void)hipFree(p); p = nullptr; }
-    HIP_TRY(hipMalloc(&p, count * sizeof(T)));
+    const hipError_t e = hipMalloc(&p, count * sizeof(T));
+    g_alloc_ms += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+    if (e != hipSuccess) { p = nullptr; HIP_TRY(e); }
     return LIME_OK;
 }
 
@@ -306,6 +321,15 @@ extern "C" int lime_get_timing_ex(lime_ctx *c, double ms_avg[4], uint64_t *launc
     return LIME_OK;
 }
 
+extern "C" int lime_get_host_times(lime_ctx *c, double out[6])
+{
+    int rc = check_ctx(c, "lime_get_host_times"); if (rc) return rc;
+    if (!out) return fail(LIME_ERR_ARG, "lime_get_host_times: out is NULL");
+    out[0] = c->alloc_ms; out[1] = c->probe_ms; out[2] = (double)c->n_probes; out[3] = (double)c->n_repeats; out[4] = (double)c->n_fallbacks;
+    out[5] = c->density_known ? c->density : -1.0;
+    return LIME_OK;
+}
+
 extern "C" int lime_get_timing(lime_ctx *c, double *scan_ms_avg, uint64_t *launches)
 {
     double ms[4];
@@ -358,41 +382,65 @@ static double sizing_density(const lime_ctx *c)
     return d < c->pool_density ? d : c->pool_density;
 }
 
+// the largest part of a wave's records that one of its sub-regions (4 GB of table each, the last one what is left) has to take when the
+// cells spread evenly over the table: the sub-regions are sized for THAT share of the wave's records (round 5; rounds 3-4 gave every one of
+// the n_sub sub-regions room for the wave's whole share, n_sub times the memory and -- with 32-bit positions -- a third of the reach)
+static double sub_share(size_t sim_bytes)
+{
+    return sim_bytes > (1ull << 32) ? (double)(1ull << 32) / (double)sim_bytes : 1.0;
+}
+
+// the scan's per-(wave, sub-region) record counts, its per-(bin, producer) counts and the bins' totals / bases (also what the density probe needs)
+static int ensure_bin_counters(lime_ctx *c, size_t segs, size_t want_counts, hipStream_t st)
+{
+    int rc;
+    if (segs > c->wave_cap) { HIP_TRY(hipStreamSynchronize(st)); c->wave_cap = 0; if ((rc = regrow(c->d_wave_cnt, segs))) return rc; c->wave_cap = segs; }
+    if (want_counts > c->counts_cap) { HIP_TRY(hipStreamSynchronize(st)); c->counts_cap = 0; if ((rc = regrow(c->d_counts, want_counts))) return rc; c->counts_cap = want_counts; }
+    if (!c->d_totals) {
+        HIP_TRY(hipMalloc(&c->d_totals, (BIN_MAX + 1) * sizeof(uint32_t)));
+        HIP_TRY(hipMalloc(&c->d_binbase, (BIN_MAX + 2) * sizeof(uint64_t)));
+    }
+    return LIME_OK;
+}
+
+// *p64: the pool holds 2^32 records or more -- the partition kernels then run with 64-bit positions (launch_part)
 static int ensure_binned(lime_ctx *c, uint64_t n_own, uint32_t n_waves, uint32_t n_prod, uint32_t n_bins, uint32_t bin_shift,
-                         uint32_t n_sub, uint32_t *cap_w, hipStream_t st)
+                         uint32_t n_sub, double share, uint32_t *cap_w, bool *p64, hipStream_t st)
 {
     int rc;
     const double per_wave = (double)n_own * sizing_density(c) / (double)n_waves;
-    uint64_t cw = (((uint64_t)(per_wave * 1.35) + c->pool_slack) & ~15ull) + 16u;   // a multiple of 16 records: sub-regions start on a 64-byte line
-    const size_t segs = (size_t)n_waves * n_sub;                          // every sub-region can take a wave's whole share (no assumption on how the cells spread)
-    if (c->pool_cap / segs > cw) cw = (c->pool_cap / segs) & ~15ull;      // grow-only: use all of what is there
-    if (cw * segs > 0xF0000000ull) return fail(LIME_ERR_ARG, "update record pool too large for one shard");   // record positions are 32-bit
+    // (the waves draw their windows from counters: their record counts differ by a few % -- x 1.35; a sub-region's part of them by a little more)
+    const double per_sub = per_wave * share * (n_sub > 1u ? 1.5 : 1.35);
+    if (per_sub > 4.0e9) return fail(LIME_ERR_ARG, "update record pool: more than 2^32 records per scan wave and sub-region");
+    uint64_t cw = (((uint64_t)per_sub + c->pool_slack) & ~15ull) + 16u;   // a multiple of 16 records: sub-regions start on a 64-byte line
+    const size_t segs = (size_t)n_waves * n_sub;
+    if (c->pool_cap / segs > cw && c->pool_cap / segs < 0xFFFFFFF0ull) cw = (c->pool_cap / segs) & ~15ull;      // grow-only: use all of what is there
     size_t want = (size_t)cw * segs;
+    // 64-bit positions: their high part rides in a record's bits above t through k_part's stage (31 - bin_shift of them)
+    if ((uint64_t)want >> (32u + 31u - bin_shift)) return fail(LIME_ERR_ARG, "update record pool too large for one shard");
+    *p64 = c->force_p64 || want >= 0xF0000000ull;
     {   // the second level's 16-bit rows (one per tile, a bin's last one partly used) fit the pool
         const size_t rows_words = ((size_t)tiles_bound(want, n_bins) * row_stride() + 1) / 2;
         if (want < rows_words) want = rows_words;
     }
     if (want > c->pool_cap) {
         HIP_TRY(hipStreamSynchronize(st));
-        if ((rc = regrow(c->d_pool, want + 16))) return rc;      // slack: k_part2 / k_apply read aligned groups of four 4-byte records
-        if ((rc = regrow(c->d_recs, want + 16))) return rc;
+        c->pool_cap = 0; c->recs_cap = 0;                        // (nothing is there if one of the two cannot be had)
+        if ((rc = regrow(c->d_pool, want + 16)) || (rc = regrow(c->d_recs, want + 16))) {      // slack: k_part2 / k_apply read aligned groups of four 4-byte records
+            if (c->d_pool) { (void)hipFree(c->d_pool); c->d_pool = nullptr; }
+            return rc;
+        }
         c->pool_cap = want; c->recs_cap = want;
     }
-    if (segs > c->wave_cap) { HIP_TRY(hipStreamSynchronize(st)); if ((rc = regrow(c->d_wave_cnt, segs))) return rc; c->wave_cap = segs; }
-    const size_t want_counts = (size_t)n_bins * n_prod;
-    if (want_counts > c->counts_cap) { HIP_TRY(hipStreamSynchronize(st)); if ((rc = regrow(c->d_counts, want_counts))) return rc; c->counts_cap = want_counts; }
-    if (!c->d_totals) {
-        HIP_TRY(hipMalloc(&c->d_totals, (BIN_MAX + 1) * sizeof(uint32_t)));
-        HIP_TRY(hipMalloc(&c->d_binbase, (BIN_MAX + 2) * sizeof(uint64_t)));
-    }
+    if ((rc = ensure_bin_counters(c, segs, (size_t)n_bins * n_prod, st))) return rc;
     if (bin_shift > REGION_SHIFT) {
         if (!c->d_tbase) HIP_TRY(hipMalloc(&c->d_tbase, (BIN_MAX + 2) * sizeof(uint32_t)));
         const size_t want_idx = (size_t)tiles_bound(c->pool_cap, n_bins) * (((size_t)1 << (bin_shift - REGION_SHIFT)) + 1);
-        if (want_idx > c->tidx_cap) { HIP_TRY(hipStreamSynchronize(st)); if ((rc = regrow(c->d_tidx, want_idx))) return rc; c->tidx_cap = want_idx; }
+        if (want_idx > c->tidx_cap) { HIP_TRY(hipStreamSynchronize(st)); c->tidx_cap = 0; if ((rc = regrow(c->d_tidx, want_idx))) return rc; c->tidx_cap = want_idx; }
     }
     const size_t want_reg = ((size_t)n_bins << (bin_shift - REGION_SHIFT)) + 2;
     if (bin_shift > REGION_SHIFT && want_reg > c->regbase_cap) {
-        HIP_TRY(hipStreamSynchronize(st)); if ((rc = regrow(c->d_regbase, want_reg))) return rc; c->regbase_cap = want_reg;
+        HIP_TRY(hipStreamSynchronize(st)); c->regbase_cap = 0; if ((rc = regrow(c->d_regbase, want_reg))) return rc; c->regbase_cap = want_reg;
     }
     *cap_w = (uint32_t)cw;
     return LIME_OK;
@@ -418,6 +466,52 @@ static void bin_layout(const lime_ctx *c, size_t sim_bytes, uint32_t *n_bins, ui
     *bin_shift_out = bin_shift;
 }
 
+static int read_stats(lime_ctx *c, lime_stats_t *s, hipStream_t st, uint32_t *sticky = nullptr);
+
+// Update records per owned symbol, estimated from a sample before the first pass on a ctx: the record-emitting scan kernel runs over every
+// 2^ps-th chunk of 16 windows -- spread over the whole collection, on all CUs -- with sub-regions of capacity 0: every update record is counted
+// (lime_stats_t.n_updates) and none is stored, no histogram entry made, no table touched.  About 1/64 of a pass + one synchronisation.
+// Reference: what is sampled is the number of `SimArray_[r][g] += t` executions per symbol, ClusterBWT_DA.cpp:178-184, 243-248.
+static int density_probe(lime_ctx *c, const uint32_t *d_lcp, const uint32_t *d_da, const uint8_t *d_ebwt, uint64_t n_own, uint64_t n_avail, int eof,
+                         uint32_t n_reads, uint32_t n_refs, uint32_t alpha, size_t sim_bytes, hipStream_t st)
+{
+    int rc;
+    const auto t0 = std::chrono::steady_clock::now();
+    const int ebwt = d_ebwt != nullptr;
+    const uint32_t n_tiles = (uint32_t)((n_avail + WIN - 1) / WIN);
+    const uint32_t ps = n_own < (1ull << 30) ? 6u : n_own < (1ull << 32) ? 7u : 8u;
+    const uint32_t grid = scan_grid(ebwt, 0, 1, n_tiles, c->max_blocks, ps);
+    uint32_t n_bins = 0, bin_shift = REGION_SHIFT;
+    bin_layout(c, sim_bytes, &n_bins, &bin_shift);
+    const uint32_t n_sub = (uint32_t)((sim_bytes + 0xFFFFFFFFull) >> 32), wpw = scan_waves_per_wg(ebwt, 0);
+    const uint32_t prod_waves = part_prod_waves(c, ebwt, n_bins), n_prod = grid * (wpw / prod_waves);
+    g_alloc_ms = 0.0;
+    rc = ensure_bin_counters(c, (size_t)grid * wpw * n_sub, (size_t)n_bins * n_prod, st);
+    c->alloc_ms += g_alloc_ms;
+    if (rc) return rc;
+    launch_zero2(c->d_stats, sizeof(DevStats), nullptr, 0, st);
+    ScanArgs a = base_args(c, d_lcp, d_da, d_ebwt, n_own, n_avail, eof, n_reads, n_refs, alpha, nullptr);
+    a.upd_mode = 1; a.pool = reinterpret_cast<uint32_t *>(c->d_stats);       // (never written: no slot is below a capacity of 0)
+    a.cap_w = 0; a.n_sub = n_sub; a.wave_cnt = c->d_wave_cnt; a.counts = c->d_counts;
+    a.n_bins = n_bins; a.bin_shift = bin_shift; a.prod_waves = prod_waves;
+    a.sub_rb = 0xFFFFFFFFu; a.sub_gb = 0u;
+    if (n_sub == 2) { a.sub_rb = (uint32_t)((1ull << 32) / n_refs); a.sub_gb = (uint32_t)((1ull << 32) - (uint64_t)a.sub_rb * n_refs); }
+    a.probe_shift = ps; a.static_pct = 100u;
+    launch_tile(ebwt, 0, a, c->max_blocks, st);
+    HIP_TRY(hipGetLastError());
+    lime_stats_t s;
+    if ((rc = read_stats(c, &s, st))) return rc;                              // waits for the sample
+    HIP_TRY(hipMemsetAsync(c->d_sticky, 0, 4, st));                           // (every sub-region "overflowed": not a pass to settle)
+    const uint64_t chunk = (uint64_t)wpw * WIN, phys = (n_avail + chunk - 1) / chunk, logical = (phys + (1ull << ps) - 1) >> ps;
+    uint64_t sampled = logical * chunk;
+    if (sampled > n_own) sampled = n_own;
+    c->density = (double)s.n_updates / (double)(sampled ? sampled : 1); c->density_known = true;
+    c->probe_ms += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count(); ++c->n_probes;
+    if (getenv("LIME_DEBUG_STATS")) fprintf(stderr, "density_probe: every %u-th chunk, %llu symbols, %llu updates -> %.4f records per symbol\n", 1u << ps,
+                                            (unsigned long long)sampled, (unsigned long long)s.n_updates, c->density);
+    return LIME_OK;
+}
+
 // keep_stats: this call continues a position-range sequence on the same table (lime_fused_stream):
 // cluster / update counters and flags accumulate, only the per-call list counters restart.
 static int fused_dev_impl(lime_ctx *c, const uint32_t *d_lcp, const uint32_t *d_da, const uint8_t *d_ebwt,
@@ -434,31 +528,48 @@ static int fused_dev_impl(lime_ctx *c, const uint32_t *d_lcp, const uint32_t *d_
     if (n_refs >= MAX_REFS || (uint64_t)n_reads + n_refs > 0xFFFFFFF0ull)
         return fail(LIME_ERR_ARG, "lime_fused_dev: n_refs must be < 2^%u and n_reads + n_refs <= 2^32 - 16", T_SHIFT);
     if ((n_avail + WIN - 1) / WIN > 0xFFFFFFF0ull) return fail(LIME_ERR_ARG, "array too long for one shard: %llu", (unsigned long long)n_avail);
-    if ((rc = ensure_scratch(c, n_avail, false, true, st))) return rc;
+    g_alloc_ms = 0.0;
+    rc = ensure_scratch(c, n_avail, false, true, st);
+    c->alloc_ms += g_alloc_ms;
+    if (rc) return rc;
     const size_t sim_bytes = lime_sim_bytes(n_reads, n_refs);
     const int ebwt = d_ebwt != nullptr;
     const uint32_t n_tiles = (uint32_t)((n_avail + WIN - 1) / WIN);
     // no_bin: a chunk of a multi-chunk stream -- its device buffers are reused by later chunks, so the pass could not be
     // repeated after a pool overflow, and the later chunks add to the table by compare-and-swap
+    const bool bin_fits = !(sim_bytes > ((size_t)BIN_MAX << BIN_SHIFT_MAX) || sim_bytes >= (1ull << CELL_BITS) || sim_bytes > ((uint64_t)MAX_SUB << 32));
+    if (records_only && !bin_fits) return fail(LIME_ERR_ARG, "lime_fused_records_dev: table too large for update records");
+    // The first pass on a ctx knows nothing of the collection's update density, which decides the update path and sizes the record pool
+    // (rounds 2-4 guessed 0.2 records per symbol: text has 0.24 .. 0.39, the iid generators 0.03 .. 0.12, and a pass that guessed wrong
+    // was repeated or ran on the other path).  LiME_paired.sh:62-68 runs every collection ONCE, so the density is sampled first: the
+    // scan kernel itself over every 2^k-th chunk of 16 windows, counting its update records without storing one (density_probe).
+    if (n_avail && !no_bin && !keep_stats && zero_sim && bin_fits && c->probe && !c->density_known && !c->pool_density_fixed && !c->ablate &&
+        c->upd_pref != 0 && n_own >= (1u << 24) && sim_bytes >= (1u << 20) && n_tiles < 0x7FF00000u)
+        if ((rc = density_probe(c, d_lcp, d_da, d_ebwt, n_own, n_avail, eof, n_reads, n_refs, alpha, sim_bytes, st))) return rc;
     bool binned = n_avail && !no_bin && want_binned(c, n_own, sim_bytes, zero_sim, keep_stats, ebwt);
-    if (records_only) {                                   // the records ARE the result: the binned path or nothing
-        if (sim_bytes > ((size_t)BIN_MAX << BIN_SHIFT_MAX) || sim_bytes >= (1ull << CELL_BITS) || sim_bytes > ((uint64_t)MAX_SUB << 32))
-            return fail(LIME_ERR_ARG, "lime_fused_records_dev: table too large for update records");
-        binned = true;
-    }
-    const uint32_t n_sub_want = (uint32_t)((sim_bytes + 0xFFFFFFFFull) >> 32);
-    if (binned && ((double)n_own * sizing_density(c) * 1.35 + 512.0 * 4096.0) * n_sub_want > 3.9e9) {   // more records than 32-bit positions hold: compare-and-swap path
-        if (records_only) return fail(LIME_ERR_ARG, "lime_fused_records_dev: shard too long for 32-bit record positions (cut it in two)");
-        binned = false;
-    }
+    if (records_only) binned = true;                      // the records ARE the result: the binned path or nothing
     uint32_t grid = 0, cap_w = 0, n_bins = 0, bin_shift = REGION_SHIFT, n_sub = 1, prod_waves = 0, n_prod = 0;
+    bool p64 = false, fell_back = false;
+    const double share = sub_share(sim_bytes);
     if (binned) {
         grid = scan_grid(ebwt, 0, 1, n_tiles, c->max_blocks);
         bin_layout(c, sim_bytes, &n_bins, &bin_shift);
         n_sub = (uint32_t)((sim_bytes + 0xFFFFFFFFull) >> 32);
         prod_waves = part_prod_waves(c, ebwt, n_bins);
         n_prod = grid * (scan_waves_per_wg(ebwt, 0) / prod_waves);
-        if ((rc = ensure_binned(c, n_own, grid * scan_waves_per_wg(ebwt, 0), n_prod, n_bins, bin_shift, n_sub, &cap_w, st))) return rc;
+        g_alloc_ms = 0.0;
+        rc = ensure_binned(c, n_own, grid * scan_waves_per_wg(ebwt, 0), n_prod, n_bins, bin_shift, n_sub, share, &cap_w, &p64, st);
+        c->alloc_ms += g_alloc_ms;
+        if (rc == LIME_ERR_NOMEM && !records_only) {
+            // no room for the records: the pass runs on the compare-and-swap path -- several times slower where the binned path was wanted --
+            // and says so: LIME_FLAG_CAS_FALLBACK in the pass's statistics, the reason in lime_last_error()
+            (void)hipGetLastError();
+            const std::string why = g_err;
+            (void)fail(LIME_ERR_NOMEM, "lime_fused_dev: no device memory for the update records of the binned path (%s): this pass falls back to "
+                                       "compare-and-swap on the table (LIME_FLAG_CAS_FALLBACK)", why.c_str());
+            binned = false; fell_back = true; ++c->n_fallbacks;
+        } else if (rc) return rc;
+        if (p64 && !c->by_tiles && bin_shift > REGION_SHIFT) return fail(LIME_ERR_ARG, "LIME_SECOND_LEVEL=sweeps: a record pool of 2^32 records or more needs the tile kernels");
     }
     if ((rc = timing_mark(c, st))) return rc;
     if (keep_stats) {
@@ -498,13 +609,18 @@ static int fused_dev_impl(lime_ctx *c, const uint32_t *d_lcp, const uint32_t *d_
     if (binned && !c->ablate) {                          // (timing experiments cut the scan short: nothing to partition)
         launch_bin_rowscan(c->d_counts, c->d_totals, n_bins, n_prod, st);
         launch_scan_tiles(c->d_totals, c->d_binbase, n_bins, reinterpret_cast<unsigned long long *>(c->d_binbase + n_bins), st);
-        launch_part(a, n_prod, c->d_binbase, c->d_recs, st);
+        const uint32_t *recs = c->d_recs;
+        if (c->p64_test_base && !records_only && (c->by_tiles || bin_shift == REGION_SHIFT)) {      // tests: positions from a base near a multiple of 2^32 on
+            launch_add_u64(c->d_binbase, (size_t)n_bins + 1, c->p64_test_base, st);
+            recs = c->d_recs - c->p64_test_base;                   // (an address only: the kernels add positions >= the base to it)
+        }
+        launch_part(a, n_prod, c->d_binbase, const_cast<uint32_t *>(recs), st, p64);
         if (records_only) {
             // the records grouped by bin are the result: the owners of the bins build the table (lime_apply_records_dev)
         } else if (bin_shift > REGION_SHIFT && c->by_tiles) {      // second level tile by tile into the (by now free) pool, regions from the tiles' runs
             // (how many records: what the last pass counted per symbol, once one has been read back)
             const double expect = c->density_known ? c->density * (double)n_own : 0.0;
-            launch_apply_by_tiles(d_sim, sim_bytes, c->d_recs, c->d_binbase, n_bins, bin_shift, c->d_tbase, c->d_tidx,
+            launch_apply_by_tiles(d_sim, sim_bytes, recs, c->d_binbase, n_bins, bin_shift, c->d_tbase, c->d_tidx,
                                   reinterpret_cast<uint16_t *>(c->d_pool), expect >= 2e8, st, expect >= 1e8);
         } else if (bin_shift > REGION_SHIFT) {            // second level into the (by now free) pool, then regions from there
             uint32_t *recs2 = c->d_pool;
@@ -514,7 +630,7 @@ static int fused_dev_impl(lime_ctx *c, const uint32_t *d_lcp, const uint32_t *d_
                                    hipMemcpyDeviceToDevice, st));
             launch_apply(d_sim, sim_bytes, recs2, c->d_regbase, bin_shift, st);
         } else {
-            launch_apply(d_sim, sim_bytes, c->d_recs, c->d_binbase, bin_shift, st);
+            launch_apply(d_sim, sim_bytes, recs, c->d_binbase, bin_shift, st);
         }
     }
     launch_score_big(ebwt, a, c->d_big_scratch, st);      // after k_apply: its compare-and-swaps add to the finished table
@@ -525,7 +641,7 @@ static int fused_dev_impl(lime_ctx *c, const uint32_t *d_lcp, const uint32_t *d_
         l.valid = true; l.binned = binned; l.lcp = d_lcp; l.da = d_da; l.ebwt = d_ebwt; l.n_own = n_own; l.n_avail = n_avail;
         l.eof = eof; l.n_reads = n_reads; l.n_refs = n_refs; l.alpha = alpha; l.sim = d_sim; l.zero_sim = zero_sim; l.st = st;
         l.n_waves = grid * scan_waves_per_wg(ebwt, 0);
-        l.own_total = n_own; l.records_only = records_only;
+        l.own_total = n_own; l.records_only = records_only; l.share = share; l.fell_back = fell_back;
     } else {
         c->last.own_total += n_own;         // a later chunk of a stream: the update counter keeps accumulating
         c->last.binned = false;             // and the pass stored in `last` can no longer be repeated on its own
@@ -673,7 +789,7 @@ extern "C" int lime_apply_records_dev(lime_ctx *c, uint32_t n_src, const uint32_
     return LIME_OK;
 }
 
-static int read_stats(lime_ctx *c, lime_stats_t *s, hipStream_t st, uint32_t *sticky = nullptr)
+static int read_stats(lime_ctx *c, lime_stats_t *s, hipStream_t st, uint32_t *sticky)
 {
     struct { lime_stats_t s; uint32_t sticky[4]; } h;
     HIP_TRY(hipMemcpyAsync(&h, c->d_stats, sizeof(lime_stats_t) + 4, hipMemcpyDeviceToHost, st));
@@ -707,7 +823,9 @@ extern "C" int lime_get_stats(lime_ctx *c, lime_stats_t *out, void *stream)
     for (int attempt = 0; (s.flags & LIME_FLAG_POOL_FULL) && l.valid && l.binned && attempt < 3; ++attempt) {
         const int pref = c->upd_pref;
         if (attempt == 2 && !l.records_only) c->upd_pref = 0;
-        const double need = (double)s.wave_records_max * (double)l.n_waves / (double)(l.n_own ? l.n_own : 1);
+        // (wave_records_max is the fullest SUB-REGION's count, sized for `share` of its wave's records)
+        const double need = (double)s.wave_records_max * (double)l.n_waves / (double)(l.n_own ? l.n_own : 1) / (l.share > 0.0 ? l.share : 1.0);
+        ++c->n_repeats;
         const double was = sizing_density(c);
         c->pool_density = need * 1.08 > was * 1.5 ? need * 1.08 : was * 1.5; c->pool_density_fixed = true;
         const bool timing = c->timing; c->timing = false;
@@ -742,6 +860,7 @@ extern "C" int lime_get_stats(lime_ctx *c, lime_stats_t *out, void *stream)
         }
     }
     if (l.valid && l.own_total) { c->density = (double)s.n_updates / (double)l.own_total; c->density_known = true; }
+    if (l.valid && l.fell_back) s.flags |= LIME_FLAG_CAS_FALLBACK;
     if (out) *out = s;
     if (c->big_cap && s.n_big > c->big_cap)
         return fail(LIME_ERR_NOMEM, "more clusters longer than %u symbols (%u) than the list holds (%u)", SMALL_MAX, s.n_big, c->big_cap);
@@ -857,12 +976,12 @@ static int score_dev_impl(lime_ctx *c, const uint32_t *d_da, const uint8_t *d_eb
         a.pos_base = pos_base;
         uint32_t blocks = (uint32_t)(batches < c->list_blocks ? batches : c->list_blocks);
         uint32_t n_bins = 0, bin_shift = REGION_SHIFT, n_sub = 1, cap_w = 0;
+        bool p64 = false;
         if (binned) {
             if (blocks > 1024u) blocks = 1024u;           // fewer, longer producers: a partition workgroup per scoring workgroup
             bin_layout(c, sim_bytes, &n_bins, &bin_shift);
             n_sub = (uint32_t)((sim_bytes + 0xFFFFFFFFull) >> 32);
-            if (((double)n * sizing_density(c) * 1.35 + 512.0 * 4096.0) * n_sub > 3.9e9) { binned = false; --attempt; continue; }   // 32-bit record positions
-            if ((rc = ensure_binned(c, n, blocks * (SCAN_WG / 64), blocks, n_bins, bin_shift, n_sub, &cap_w, st))) return rc;
+            if ((rc = ensure_binned(c, n, blocks * (SCAN_WG / 64), blocks, n_bins, bin_shift, n_sub, sub_share(sim_bytes), &cap_w, &p64, st))) return rc;
             a.upd_mode = 1; a.pool = c->d_pool; a.cap_w = cap_w; a.n_sub = n_sub; a.wave_cnt = c->d_wave_cnt; a.counts = c->d_counts;
             a.n_bins = n_bins; a.bin_shift = bin_shift; a.prod_waves = SCAN_WG / 64;
             a.sub_rb = 0xFFFFFFFFu; a.sub_gb = 0u;
@@ -872,7 +991,7 @@ static int score_dev_impl(lime_ctx *c, const uint32_t *d_da, const uint8_t *d_eb
         if (binned) {
             launch_bin_rowscan(c->d_counts, c->d_totals, n_bins, blocks, st);
             launch_scan_tiles(c->d_totals, c->d_binbase, n_bins, reinterpret_cast<unsigned long long *>(c->d_binbase + n_bins), st);
-            launch_part(a, blocks, c->d_binbase, c->d_recs, st);
+            launch_part(a, blocks, c->d_binbase, c->d_recs, st, p64);
             if (bin_shift > REGION_SHIFT) launch_apply_by_tiles(d_sim, sim_bytes, c->d_recs, c->d_binbase, n_bins, bin_shift, c->d_tbase, c->d_tidx,
                                                                 reinterpret_cast<uint16_t *>(c->d_pool), false, st);
             else launch_apply(d_sim, sim_bytes, c->d_recs, c->d_binbase, bin_shift, st);

@@ -91,6 +91,7 @@ struct ScanArgs {
     uint32_t *tile_cnt; uint64_t *tile_off; CrossRec *cross; lime_cluster_t *out;   // detect only
     WinMasks *wmask;                             // detect only: count pass -> emit pass
     uint32_t *edge;                              // LIME_EDGE_* word of this shard (default: &stats->edge)
+    uint32_t probe_shift;                        // density probe (lime_api.cpp): only every 2^probe_shift-th chunk of a workgroup's wave count of windows is scanned; 0 = a pass
     uint32_t *dyn; uint32_t n_static, static_pct;           // k_scan: rounds of round-robin window chunks before the chunks come from the counter dyn[0] (dyn[1]: workgroups done; both are left at 0); set by the launch wrapper from static_pct
     uint32_t sub_rb, sub_gb;                     // binned, two sub-regions: cell >= 2^32 <=> read > sub_rb or (read == sub_rb and genome >= sub_gb); one sub-region: sub_rb = ~0
     uint32_t *sticky;                            // passes whose record pool overflowed and that lime_get_stats has not settled yet (never cleared by a pass)
@@ -106,11 +107,11 @@ struct ScanArgs {
 };
 
 void launch_tile(int ebwt, int mode, const ScanArgs &a, uint32_t max_blocks, hipStream_t st);
-uint32_t scan_grid(int ebwt, int mode, int binned, uint32_t n_tiles, uint32_t max_blocks);   // workgroups launch_tile will use
+uint32_t scan_grid(int ebwt, int mode, int binned, uint32_t n_tiles, uint32_t max_blocks, uint32_t probe_shift = 0);   // workgroups launch_tile will use
 // binned updates: after the scan (n_prod = its grid) -- per-bin prefix over the producers and bin totals,
 // records into bins, table regions from bins
 void launch_bin_rowscan(uint32_t *counts, uint32_t *totals, uint32_t n_bins, uint32_t n_prod, hipStream_t st);
-void launch_part(const ScanArgs &a, uint32_t n_prod, const uint64_t *binbase, uint32_t *out, hipStream_t st);
+void launch_part(const ScanArgs &a, uint32_t n_prod, const uint64_t *binbase, uint32_t *out, hipStream_t st, bool p64 = false);   // p64: the pool holds 2^32 records or more (64-bit positions in `out`)
 void launch_part2(const uint32_t *recs, const uint64_t *binbase, uint32_t n_bins, uint32_t bin_shift, uint64_t *regbase,
                   uint32_t *out, hipStream_t st);
 void launch_apply(uint8_t *sim, size_t sim_bytes, const uint32_t *recs, const uint64_t *regbase, uint32_t bin_shift, hipStream_t st);
@@ -133,6 +134,7 @@ void launch_choose(const uint8_t *sim, uint32_t n_reads, uint32_t n_refs, uint8_
 void launch_synth(uint64_t seed, uint64_t i0, uint64_t count, uint32_t n_reads, uint32_t n_refs,
                   uint32_t alpha, uint32_t mode, uint32_t *lcp, uint32_t *da, uint8_t *ebwt, hipStream_t st);
 void launch_fill_u32(uint32_t *p, size_t n, uint32_t v, hipStream_t st);
+void launch_add_u64(uint64_t *p, size_t n, uint64_t v, hipStream_t st);             // p[i] += v (tests: LIME_P64_TEST_BASE)
 void launch_zero2(void *a, size_t a_bytes, void *b, size_t b_bytes, hipStream_t st);   // a: a multiple of 4 bytes; b: 16-byte aligned, a multiple of 16 bytes
 
 } // namespace lime

@@ -19,6 +19,7 @@
 #include <stdint.h>
 #include <stdlib.h>
 #include <atomic>
+#include <type_traits>
 #include "lime_device.h"
 #include "lime_kernels.h"
 
@@ -1103,7 +1104,8 @@ __global__ __launch_bounds__((ScanCfg<EBWT, BIN>::wg)) __attribute__((amdgpu_wav
         uint32_t i = 0;
         if (lane == 0) i = atomicAdd(&wg_next, 1u);
         i = (uint32_t)__builtin_amdgcn_readfirstlane((int)i);
-        const uint32_t k = i / WPW, j = i % WPW, ks = (EBWT ? cold(a) : a).n_static;
+        const uint32_t ksw = cold(a).n_static, ks = ksw & 0xFFFFFFu, ps = ksw >> 24;   // rounds of round-robin chunks | probe shift << 24
+        const uint32_t k = i / WPW, j = i % WPW;
         uint32_t chunk = k * gridDim.x + blockIdx.x;
         if (k >= ks) {
             // slot k & 15 carries the tags k + 1 - 16 (or 0), k + 1, k + 1 + 16, ... in turn.  A wave that finds a LATER tag than its own was
@@ -1132,7 +1134,7 @@ __global__ __launch_bounds__((ScanCfg<EBWT, BIN>::wg)) __attribute__((amdgpu_wav
                 __hip_atomic_store(&wg_slot[(k + 1u) & 15u], ((uint64_t)(k + 2u) << 32) | (uint64_t)(ks * gridDim.x + g), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
             }
         }
-        return chunk * WPW + j;
+        return (chunk << ps) * WPW + j;                // (ps != 0: the density probe scans every 2^ps-th chunk only)
     };
     // end of a wave.  The counters of the pass are summed per workgroup in LDS and its last wave adds them to the device's:
     // the waves end together, and a few atomics per wave on the same few words took the last 0.1 .. 0.2 ms of the kernel
@@ -1727,22 +1729,28 @@ extern "C" int lime_debug_part_times(unsigned long long *out)
 
 // WGS threads and tiles of 16 WGS records: 512 / 8192, or -- few bins: the runs stay long enough -- 256 / 4096 with twice as many
 // workgroups per CU: a tile is a chain of short phases between barriers, and what hides their latencies is other workgroups
-template <int WGS, uint32_t NB_MAX>
+// P64 (round 5): a pass whose record pool holds 2^32 records or more (N = 1e10 at the update density of real text: 2.4 .. 3.9e9 records) --
+// positions in `out` are 64-bit: the bins' cursors are 64-bit registers, a bin's (position - slot) is a 64-bit word in LDS, and the high part
+// of a slot's position travels through the stage in the record's free bits above t (t is 1 here: a score of t left the scan as t records),
+// bits bin_shift + 1 .. 31: six bits at the widest bins, 2^38 records.  Rounds 1-4 sent such a pass to the compare-and-swap path.
+template <int WGS, uint32_t NB_MAX, bool P64>
 __global__ __launch_bounds__(WGS) void k_part(ScanArgs a, const uint64_t *binbase, uint32_t *out)
 {
     constexpr uint32_t PART_WG = WGS, PART_TILE = WGS * PART_PER, PART_BPT = (NB_MAX + WGS - 1) / WGS;   // (shadow the file's constants)
     __shared__ uint4 stage4[PART_TILE / 2];                              // (position in out, record) per slot
-    extern __shared__ uint32_t part_lds[];                               // per bin: tile count, cursor (LDS slot), position - slot
+    extern __shared__ __attribute__((aligned(8))) uint32_t part_lds[];   // per bin: tile count, cursor (LDS slot), position - slot (P64: two words)
     __shared__ uint32_t wsum[PART_WG / 64];
     uint2 *stage = reinterpret_cast<uint2 *>(stage4);
     const uint32_t nb = a.n_bins, tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
     uint32_t *cnt = part_lds, *cur = cnt + nb, *delta = cur + nb;
+    u64a *delta64 = reinterpret_cast<u64a *>(part_lds + 2u * nb);        // (8-byte aligned: 2 nb words in front; takes the place of delta)
+    typedef typename std::conditional<P64, uint64_t, uint32_t>::type pos_t;
     const uint32_t per = (nb + PART_WG - 1u) / PART_WG, b0 = tid * per;
-    uint32_t G[PART_BPT];                                                // where this producer's records of bins b0 .. go next
+    pos_t G[PART_BPT];                                                   // where this producer's records of bins b0 .. go next
 #pragma unroll
     for (uint32_t k = 0; k < PART_BPT; ++k) {
         G[k] = 0u;
-        if (k < per && b0 + k < nb) { G[k] = (uint32_t)binbase[b0 + k] + a.counts[(size_t)(b0 + k) * gridDim.x + blockIdx.x]; cnt[b0 + k] = 0u; }
+        if (k < per && b0 + k < nb) { G[k] = (pos_t)binbase[b0 + k] + a.counts[(size_t)(b0 + k) * gridDim.x + blockIdx.x]; cnt[b0 + k] = 0u; }
     }
     __syncthreads();
     const uint32_t sh = a.bin_shift, omask = (1u << sh) - 1u, tbit = 1u << sh;
@@ -1816,7 +1824,11 @@ __global__ __launch_bounds__(WGS) void k_part(ScanArgs a, const uint64_t *binbas
             for (uint32_t k = 0; k < wave; ++k) run += wsum[k];
 #pragma unroll
             for (uint32_t k = 0; k < PART_BPT; ++k)
-                if (k < per && b0 + k < nb) { cur[b0 + k] = run; delta[b0 + k] = G[k] - run; G[k] += c[k]; cnt[b0 + k] = 0u; run += c[k]; }
+                if (k < per && b0 + k < nb) {
+                    cur[b0 + k] = run;
+                    if (P64) delta64[b0 + k] = (uint64_t)G[k] - run; else delta[b0 + k] = (uint32_t)G[k] - run;
+                    G[k] += c[k]; cnt[b0 + k] = 0u; run += c[k];
+                }
             __syncthreads();
             PP(2)
         }
@@ -1830,6 +1842,10 @@ __global__ __launch_bounds__(WGS) void k_part(ScanArgs a, const uint64_t *binbas
                 if (i + k < tc.tn) {
                     const uint32_t b = (v[k] >> sh) + tc.binoff;
                     const uint32_t slot = atomicAdd(&cur[b], 1u);
+                    if (P64) {
+                        const uint64_t p = slot + delta64[b];
+                        stage[slot] = make_uint2((uint32_t)p, (v[k] & omask) | tbit | (((uint32_t)(p >> 32) << 1) << sh));
+                    } else
                     stage[slot] = make_uint2(slot + delta[b], (v[k] & omask) | tbit);      // t = 1
                 }
         }
@@ -1849,6 +1865,20 @@ __global__ __launch_bounds__(WGS) void k_part(ScanArgs a, const uint64_t *binbas
         // ---- ... while this one leaves LDS, four slots a lane: consecutive positions as one 16-byte store
         for (uint32_t q = tid; 4u * q < tc.tn; q += PART_WG) {
             const uint4 s0 = stage4[2u * q], s1 = stage4[2u * q + 1u];   // (p0, v0, p1, v1), (p2, v2, p3, v3)
+            if (P64) {                                                   // the positions' high parts ride in the records' bits above t
+                const uint32_t rm = (tbit << 1) - 1u;
+                const uint64_t h0 = (uint64_t)((s0.y >> sh) >> 1) << 32, h1 = (uint64_t)((s0.w >> sh) >> 1) << 32,
+                               h2 = (uint64_t)((s1.y >> sh) >> 1) << 32, h3 = (uint64_t)((s1.w >> sh) >> 1) << 32;
+                if (4u * q + 3u < tc.tn && s1.z == s0.x + 3u && h3 == h0) {
+                    u32x4u o = {s0.y & rm, s0.w & rm, s1.y & rm, s1.w & rm};
+                    *reinterpret_cast<u32x4u *>(out + (h0 | s0.x)) = o;
+                } else {
+                    out[h0 | s0.x] = s0.y & rm;
+                    if (4u * q + 1u < tc.tn) out[h1 | s0.z] = s0.w & rm;
+                    if (4u * q + 2u < tc.tn) out[h2 | s1.x] = s1.y & rm;
+                    if (4u * q + 3u < tc.tn) out[h3 | s1.z] = s1.w & rm;
+                }
+            } else
             if (4u * q + 3u < tc.tn && s1.z == s0.x + 3u) {
                 u32x4u o = {s0.y, s0.w, s1.y, s1.w};
                 *reinterpret_cast<u32x4u *>(out + s0.x) = o;
@@ -1879,8 +1909,9 @@ __global__ __launch_bounds__(WGS) void k_part(ScanArgs a, const uint64_t *binbas
 constexpr uint32_t PL_TASKS = PART_TILE / 16u + 16u;                     // + one task per bin (a first, aligning piece)
 // (tasks of a tile: its lines -- at most (PART_TILE + 15 nb) / 16 -- plus one per bin whose first piece is not aligned)
 constexpr uint32_t PL_CS = 17;                                          // words per bin's carry row: 16 records on a stride that spreads the bins over the LDS banks (a stride of 16 put every bin's record i on two banks: 77 % of the LDS cycles were bank conflicts)
-__host__ __device__ inline size_t part_lines_lds(uint32_t nb) { return (size_t)nb * (16u + 4u * PL_CS) + ((size_t)PL_TASKS + 2u * nb) * 4u; }
+__host__ __device__ inline size_t part_lines_lds(uint32_t nb, bool p64 = false) { return (size_t)nb * (16u + 4u * PL_CS) + ((size_t)PL_TASKS + 2u * nb) * 4u + (p64 ? 4u * (size_t)nb : 0u); }
 
+template <bool P64>           // P64: 64-bit positions in `out` (see k_part): the bins' cursors are 64-bit registers, a line's lanes read the high word from ghi[bin]
 __global__ __launch_bounds__(PART_WG) void k_part_lines(ScanArgs a, const uint64_t *binbase, uint32_t *out)
 {
     __shared__ uint4 stage4[PART_TILE / 4];                              // the tile's records, grouped by bin
@@ -1895,13 +1926,15 @@ __global__ __launch_bounds__(PART_WG) void k_part_lines(ScanArgs a, const uint64
     uint2 *dg = reinterpret_cast<uint2 *>(cur + nb);                     // (8-byte aligned: part_lds is, and cnt + cur are 2 nb words)
     uint32_t *cb = reinterpret_cast<uint32_t *>(dg + nb);                // [nb][PL_CS]: the bins' carried records
     uint32_t *task = cb + (size_t)nb * PL_CS;
+    uint32_t *ghi = task + PL_TASKS + 2u * nb;                           // P64: high word of the bin's next position (part_lines_lds(nb, true))
+    typedef typename std::conditional<P64, uint64_t, uint32_t>::type pos_t;
     const uint32_t per = (nb + PART_WG - 1u) / PART_WG, b0 = tid * per;
     constexpr uint32_t BPT = 3;                                          // bins a thread owns at most (launch_part: nb <= 3 * PART_WG)
-    uint32_t G[BPT], C[BPT];                                             // per owned bin: position of its next record in out; records carried
+    pos_t G[BPT]; uint32_t C[BPT];                                       // per owned bin: position of its next record in out; records carried
 #pragma unroll
     for (uint32_t k = 0; k < BPT; ++k) {
         G[k] = 0u; C[k] = 0u;
-        if (k < per && b0 + k < nb) { G[k] = (uint32_t)binbase[b0 + k] + a.counts[(size_t)(b0 + k) * gridDim.x + blockIdx.x]; cnt[b0 + k] = 0u; }
+        if (k < per && b0 + k < nb) { G[k] = (pos_t)binbase[b0 + k] + a.counts[(size_t)(b0 + k) * gridDim.x + blockIdx.x]; cnt[b0 + k] = 0u; }
     }
     __syncthreads();
     const uint32_t sh = a.bin_shift, omask = (1u << sh) - 1u, tbit = 1u << sh;
@@ -1971,8 +2004,8 @@ __global__ __launch_bounds__(PART_WG) void k_part_lines(ScanArgs a, const uint64
                 N[k] = 0u; E[k] = 0u; L[k] = 0u; Cold[k] = C[k];
                 if (k < per && b0 + k < nb) {
                     N[k] = cnt[b0 + k]; cnt[b0 + k] = 0u;
-                    const uint32_t end = G[k] + C[k] + N[k], border = end & ~15u;
-                    if (border > G[k]) { E[k] = border - G[k]; L[k] = (border >> 4) - (G[k] >> 4); }
+                    const pos_t end = G[k] + C[k] + N[k], border = end & ~(pos_t)15u;
+                    if (border > G[k]) { E[k] = (uint32_t)(border - G[k]); L[k] = (uint32_t)((border >> 4) - (G[k] >> 4)); }
                 }
                 mine += N[k] | (L[k] << 16);
             }
@@ -1985,7 +2018,8 @@ __global__ __launch_bounds__(PART_WG) void k_part_lines(ScanArgs a, const uint64
             for (uint32_t k = 0; k < BPT; ++k)
                 if (k < per && b0 + k < nb) {
                     const uint32_t b = b0 + k, s0 = run & 0xFFFFu, t0_ = run >> 16;
-                    S[k] = s0; cur[b] = s0; dg[b] = make_uint2(s0 | (C[k] << 14) | (E[k] << 18), G[k]);
+                    S[k] = s0; cur[b] = s0; dg[b] = make_uint2(s0 | (C[k] << 14) | (E[k] << 18), (uint32_t)G[k]);
+                    if (P64) ghi[b] = (uint32_t)((uint64_t)G[k] >> 32);
                     for (uint32_t i = 0; i < L[k]; ++i) task[t0_ + i] = b | (i << 11);
                     G[k] += E[k]; C[k] = C[k] + N[k] - E[k];
                     run += N[k] | (L[k] << 16);
@@ -2023,19 +2057,20 @@ __global__ __launch_bounds__(PART_WG) void k_part_lines(ScanArgs a, const uint64
             constexpr uint32_t GRPS = PART_WG / 16u, UT = 4;
             const uint32_t grp = tid >> 4, l16 = tid & 15u, n_tasks = n_tasks_s;
             for (uint32_t j0 = grp; j0 < n_tasks; j0 += GRPS * UT) {
-                uint32_t tt[UT], pp[UT], val[UT];
+                uint32_t tt[UT], val[UT], gh[UT];
+                pos_t pp[UT];
                 uint2 dd[UT];
                 bool on[UT];
 #pragma unroll
                 for (uint32_t u = 0; u < UT; ++u) { const uint32_t j = j0 + u * GRPS; on[u] = j < n_tasks; tt[u] = task[on[u] ? j : 0u]; }
 #pragma unroll
-                for (uint32_t u = 0; u < UT; ++u) dd[u] = dg[tt[u] & 0x7FFu];
+                for (uint32_t u = 0; u < UT; ++u) { dd[u] = dg[tt[u] & 0x7FFu]; gh[u] = P64 ? ghi[tt[u] & 0x7FFu] : 0u; }
 #pragma unroll
                 for (uint32_t u = 0; u < UT; ++u) {
                     const uint32_t bq = tt[u] & 0x7FFu, d = dd[u].x, g = dd[u].y;
                     const uint32_t s0 = d & 0x3FFFu, c = (d >> 14) & 15u, e_n = d >> 18;
                     const uint32_t e = ((tt[u] >> 11) << 4) + l16 - (g & 15u);      // the lane's element of the bin's stream (before the first one: wraps)
-                    pp[u] = g + e;
+                    pp[u] = P64 ? (pos_t)((((uint64_t)gh[u] << 32) | g) + e) : (pos_t)(g + e);      // (e < e_n <= 8207 where it is used: no wrap)
                     on[u] = on[u] && e < e_n;
                     const uint32_t *srcp = e < c ? cb + (bq * PL_CS + e) : stage + (s0 + e - c);
                     val[u] = on[u] ? *srcp : 0u;
@@ -2856,14 +2891,15 @@ template <typename K> static uint32_t resident_blocks(K kernel, int block)
 constexpr int MAX_DEV = 64;
 static int cur_device() { int d = 0; (void)hipGetDevice(&d); return d >= 0 && d < MAX_DEV ? d : 0; }
 
-template <int ID, int WG, typename K> static uint32_t scan_grid_of(K kernel, uint32_t n_tiles, uint32_t max_blocks)
+// (probe_shift: only every 2^probe_shift-th chunk is scanned -- the density probe)
+template <int ID, int WG, typename K> static uint32_t scan_grid_of(K kernel, uint32_t n_tiles, uint32_t max_blocks, uint32_t probe_shift = 0)
 {
     constexpr int SCANK_WG = WG;
     static std::atomic<uint32_t> resident_of[MAX_DEV];
     std::atomic<uint32_t> &slot = resident_of[cur_device()];
     uint32_t resident = slot.load(std::memory_order_relaxed);
     if (!resident) { resident = resident_blocks(kernel, SCANK_WG); slot.store(resident, std::memory_order_relaxed); }
-    const uint32_t want = (n_tiles + SCANK_WG / 64 - 1) / (SCANK_WG / 64), cap = max_blocks ? max_blocks : resident;
+    const uint32_t chunks = (n_tiles + SCANK_WG / 64 - 1) / (SCANK_WG / 64), want = (chunks + (1u << probe_shift) - 1u) >> probe_shift, cap = max_blocks ? max_blocks : resident;
     const uint32_t grid = want < cap ? want : cap;
     return grid ? grid : 1u;
 }
@@ -2871,19 +2907,22 @@ template <int ID, int WG, typename K> static uint32_t scan_grid_of(K kernel, uin
 template <int ID, int WG, typename K> static void launch_scan_kernel(K kernel, const ScanArgs &a, uint32_t max_blocks, hipStream_t st)
 {
     // persistent grid: as many workgroups as fit the device at once (per instantiation), or fewer for short inputs
-    const uint32_t grid = scan_grid_of<ID, WG>(kernel, a.n_tiles, max_blocks);
+    const uint32_t grid = scan_grid_of<ID, WG>(kernel, a.n_tiles, max_blocks, a.probe_shift);
     const uint32_t pct = a.static_pct > 100u ? 100u : a.static_pct;
     ScanArgs b = a;
-    const uint64_t rounds = ((uint64_t)a.n_tiles + WG / 64 - 1) / (WG / 64) / grid;      // whole rounds of chunks
+    const uint64_t chunks = (((uint64_t)a.n_tiles + WG / 64 - 1) / (WG / 64) + (1u << a.probe_shift) - 1u) >> a.probe_shift;
+    const uint64_t rounds = chunks / grid;             // whole rounds of chunks
     b.n_static = (uint32_t)(rounds * (uint64_t)pct / 100u);
     if (!b.n_static) b.n_static = 1u;                  // round 0 is always the workgroups' own chunks (grid <= number of chunks)
+    if (b.n_static > 0xFFFFFFu) b.n_static = 0xFFFFFFu;
+    b.n_static |= a.probe_shift << 24;                 // (the kernel's take() splits the word: one SGPR for both)
     hipLaunchKernelGGL(kernel, dim3(grid), dim3(WG), 0, st, b);
 }
 
-uint32_t scan_grid(int ebwt, int mode, int binned, uint32_t n_tiles, uint32_t max_blocks)
+uint32_t scan_grid(int ebwt, int mode, int binned, uint32_t n_tiles, uint32_t max_blocks, uint32_t probe_shift)
 {
     if (mode != 0) return scan_grid_of<2, ScanCfg<0, 0>::wg>(k_scan<0, 1, 0>, n_tiles, max_blocks);
-    if (binned) return ebwt ? scan_grid_of<4, ScanCfg<1, 1>::wg>(k_scan<1, 0, 1>, n_tiles, max_blocks) : scan_grid_of<3, ScanCfg<0, 1>::wg>(k_scan<0, 0, 1>, n_tiles, max_blocks);
+    if (binned) return ebwt ? scan_grid_of<4, ScanCfg<1, 1>::wg>(k_scan<1, 0, 1>, n_tiles, max_blocks, probe_shift) : scan_grid_of<3, ScanCfg<0, 1>::wg>(k_scan<0, 0, 1>, n_tiles, max_blocks, probe_shift);
     return ebwt ? scan_grid_of<1, ScanCfg<1, 0>::wg>(k_scan<1, 0, 0>, n_tiles, max_blocks) : scan_grid_of<0, ScanCfg<0, 0>::wg>(k_scan<0, 0, 0>, n_tiles, max_blocks);
 }
 
@@ -2892,27 +2931,29 @@ void launch_bin_rowscan(uint32_t *counts, uint32_t *totals, uint32_t n_bins, uin
     hipLaunchKernelGGL(k_bin_rowscan, dim3((n_bins + 3u) / 4u), dim3(256), 0, st, counts, totals, n_bins, n_prod);
 }
 
-void launch_part(const ScanArgs &a, uint32_t n_prod, const uint64_t *binbase, uint32_t *out, hipStream_t st)
+void launch_part(const ScanArgs &a, uint32_t n_prod, const uint64_t *binbase, uint32_t *out, hipStream_t st, bool p64)
 {
     static std::atomic<bool> attr_set[MAX_DEV];              // the attribute is per device
     std::atomic<bool> &set = attr_set[cur_device()];
     if (!set.load(std::memory_order_relaxed)) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(k_part<PART_WG, BIN_MAX>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)(BIN_MAX * 12u));
+        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(k_part<PART_WG, BIN_MAX, false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)(BIN_MAX * 12u));
+        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(k_part<PART_WG, BIN_MAX, true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)(BIN_MAX * 16u));
         set.store(true, std::memory_order_relaxed);
     }
     // whole-line writes (k_part_lines) wherever the bins' line buffers fit the LDS next to the stage; LIME_PART_LINES=0: comparison runs
     static const bool lines_ok = !(getenv("LIME_PART_LINES") && atoi(getenv("LIME_PART_LINES")) == 0);
-    static std::atomic<uint32_t> lines_room[MAX_DEV];        // dynamic LDS k_part_lines may ask for on this device (0: not asked yet)
-    const size_t lds_lines = part_lines_lds(a.n_bins);
+    static std::atomic<uint32_t> lines_room[MAX_DEV][2];     // dynamic LDS k_part_lines may ask for on this device (0: not asked yet)
+    const size_t lds_lines = part_lines_lds(a.n_bins, p64);
+    const void *kl = p64 ? reinterpret_cast<const void *>(k_part_lines<true>) : reinterpret_cast<const void *>(k_part_lines<false>);
     if (lines_ok && a.n_bins <= 3u * PART_WG) {
-        std::atomic<uint32_t> &room = lines_room[cur_device()];
+        std::atomic<uint32_t> &room = lines_room[cur_device()][p64 ? 1 : 0];
         uint32_t r = room.load(std::memory_order_relaxed);
         if (!r) {
             hipFuncAttributes fa;
             r = 1u;
-            if (hipFuncGetAttributes(&fa, reinterpret_cast<const void *>(k_part_lines)) == hipSuccess && fa.sharedSizeBytes < 160u * 1024u) {
+            if (hipFuncGetAttributes(&fa, kl) == hipSuccess && fa.sharedSizeBytes < 160u * 1024u) {
                 const uint32_t dyn = 160u * 1024u - (uint32_t)fa.sharedSizeBytes;
-                if (hipFuncSetAttribute(reinterpret_cast<const void *>(k_part_lines), hipFuncAttributeMaxDynamicSharedMemorySize, (int)dyn) == hipSuccess) r = dyn;
+                if (hipFuncSetAttribute(kl, hipFuncAttributeMaxDynamicSharedMemorySize, (int)dyn) == hipSuccess) r = dyn;
             }
             (void)hipGetLastError();
             room.store(r, std::memory_order_relaxed);
@@ -2921,14 +2962,13 @@ void launch_part(const ScanArgs &a, uint32_t n_prod, const uint64_t *binbase, ui
         // 0.72 against 0.48 ms; N = 1e10, 477 bins, two per CU: 3.8 against 4.2 .. 4.7 ms)
         const size_t stat = 160u * 1024u - (r > 1u ? r : 0u);               // the kernel's static LDS
         if (lds_lines <= r && 2u * (lds_lines + stat + 512u) <= 160u * 1024u) {
-            hipLaunchKernelGGL(k_part_lines, dim3(n_prod), dim3(PART_WG), lds_lines, st, a, binbase, out);
+            if (p64) hipLaunchKernelGGL(k_part_lines<true>, dim3(n_prod), dim3(PART_WG), lds_lines, st, a, binbase, out);
+            else     hipLaunchKernelGGL(k_part_lines<false>, dim3(n_prod), dim3(PART_WG), lds_lines, st, a, binbase, out);
             return;
         }
     }
-    if (a.n_bins <= 512u && getenv("LIME_PART_WG") && atoi(getenv("LIME_PART_WG")) == 256)      // comparison runs only: measured no faster on small inputs, 1.5 x slower on large ones
-        hipLaunchKernelGGL((k_part<256, 512>), dim3(n_prod), dim3(256), (size_t)a.n_bins * 12u, st, a, binbase, out);
-    else
-        hipLaunchKernelGGL((k_part<PART_WG, BIN_MAX>), dim3(n_prod), dim3(PART_WG), (size_t)a.n_bins * 12u, st, a, binbase, out);
+    if (p64) hipLaunchKernelGGL((k_part<PART_WG, BIN_MAX, true>), dim3(n_prod), dim3(PART_WG), (size_t)a.n_bins * 16u, st, a, binbase, out);
+    else     hipLaunchKernelGGL((k_part<PART_WG, BIN_MAX, false>), dim3(n_prod), dim3(PART_WG), (size_t)a.n_bins * 12u, st, a, binbase, out);
 }
 
 void launch_part2(const uint32_t *recs, const uint64_t *binbase, uint32_t n_bins, uint32_t bin_shift, uint64_t *regbase,
@@ -3054,6 +3094,15 @@ void launch_synth(uint64_t seed, uint64_t i0, uint64_t count, uint32_t n_reads, 
     if (!blocks) blocks = 1;
     hipLaunchKernelGGL(k_synth, dim3((uint32_t)blocks), dim3(WGSZ), 0, st, seed, i0, count, n_reads, n_refs,
                        alpha, mode, lcp, da, ebwt);
+}
+
+__global__ void k_add_u64(uint64_t *p, size_t n, uint64_t v)
+{
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) p[i] += v;
+}
+void launch_add_u64(uint64_t *p, size_t n, uint64_t v, hipStream_t st)
+{
+    hipLaunchKernelGGL(k_add_u64, dim3(8), dim3(256), 0, st, p, n, v);
 }
 
 void launch_fill_u32(uint32_t *p, size_t n, uint32_t v, hipStream_t st)

@@ -1,0 +1,232 @@
+"""Round 5: the binned update path beyond its old limits -- 64-bit positions of the binned records (passes whose
+record pool holds 2^32 records or more: N = 10^10 at the update density of real text), sub-regions sized for their share of a wave's
+records (tables beyond 4 GB), the sampled density probe in front of a context's first pass, and the loud compare-and-swap fallback.
+All through the C ABI, bit-exact against the oracle (or, at full size, against the compare-and-swap path of the same library).
+Reference site of the updates carried: ClusterBWT_DA.cpp:178-184, 243-248."""
+import numpy as np
+import pytest
+
+from oracle import oracle_py as O
+
+pytestmark = pytest.mark.gpu
+
+
+def _ctx(monkeypatch, **env):
+    import lime_amd
+    for k, v in env.items():
+        monkeypatch.setenv(k, str(v))
+    return lime_amd.Context()
+
+
+# (levels, nr, ng): one bin per region -> k_part + k_apply; bins of several regions, few of them -> k_part_lines + tiles;
+# many bins -> k_part + tiles
+P64_SHAPES = [(None, 3000, 300), ("2,3", 5000, 1200), ("4,7", 40000, 700), ("1,1", 3000, 300), (None, 150000, 3000), ("1,2", 1, 1), ("2000,2000", 60000, 2000)]
+
+
+@pytest.mark.parametrize("base", [0, (1 << 32) - 4096, (1 << 32) - 300_000, (3 << 32) - 160_000, (1 << 33) + 48])
+@pytest.mark.parametrize("levels,nr,ng", P64_SHAPES)
+def test_p64_partition_kernels_vs_oracle(monkeypatch, base, levels, nr, ng):
+    """k_part<.., true> / k_part_lines<true> (positions of the binned records as 64-bit numbers) on small passes whose record positions are
+    made to START at `base` (LIME_P64_TEST_BASE: the bin bases are shifted and the kernels get the array's address minus the base), so that the
+    positions cross a multiple of 2^32 inside a bin, inside a tile, between two bins -- or lie wholly above one.  base 0: LIME_FORCE_P64 alone."""
+    env = {"LIME_UPDATE_PATH": "bin", "LIME_FORCE_P64": 1}
+    if base:
+        env["LIME_P64_TEST_BASE"] = base
+    if levels:
+        env["LIME_BIN_LEVELS"] = levels
+    c = _ctx(monkeypatch, **env)
+    try:
+        n = 1_500_000
+        lcp, da, eb = O.synth(300 + nr, 0, n, nr, ng, 16, 1)
+        cl, nc, ml = O.detect(lcp, da, nr, 16)
+        for e in (eb, None):
+            exp = O.score(da, e, cl, nr, ng, threads=4)
+            sim, gnc, gml = c.fused(lcp, da, e, nr, ng, 16)
+            s, rc = c.stats()
+            assert rc == 0 and (s.wave_records_max > 0 or nc == 0)
+            assert (gnc, gml) == (nc, ml) and np.array_equal(sim, exp), (base, levels, nr, ng, int((sim != exp).sum()))
+    finally:
+        c.close()
+
+
+def test_p64_with_a_pool_too_small(monkeypatch):
+    """the repeated pass (pool sized from what the first attempt counted) on the 64-bit kernels"""
+    c = _ctx(monkeypatch, LIME_UPDATE_PATH="bin", LIME_P64_TEST_BASE=(1 << 32) - 100_000, LIME_POOL_DENSITY="0.001", LIME_POOL_SLACK=0)
+    try:
+        n, nr, ng = 2_500_000, 3000, 300
+        lcp, da, eb = O.synth(77, 0, n, nr, ng, 16, 1)
+        cl, nc, ml = O.detect(lcp, da, nr, 16)
+        exp = O.score(da, eb, cl, nr, ng, threads=4)
+        sim, gnc, gml = c.fused(lcp, da, eb, nr, ng, 16)
+        assert (gnc, gml) == (nc, ml) and np.array_equal(sim, exp)
+        assert c.host_times()["repeats"] >= 1
+    finally:
+        c.close()
+
+
+@pytest.mark.parametrize("nr,ng,ebwt_on,mode", [
+    (1_100_000, 4000, True, 1),        # 4.4 GB: two sub-regions (drain_lines), the second one a tenth of the first
+    (3_000_000, 3423, True, 1),        # configs[4]'s table, 10.3 GB: three sub-regions (drain_bin), shares 0.42 / 0.42 / 0.16
+    (2_200_000, 4000, False, 1),       # 8.8 GB, EBWT=0
+])
+def test_tables_of_several_sub_regions_vs_oracle(monkeypatch, nr, ng, ebwt_on, mode):
+    """Tables beyond 4 GB: a scan wave writes its records to one sub-region per 4 GB of table, each sized for its SHARE of the wave's
+    records (round 5; rounds 3-4: the wave's whole share each) -- clustered generator, 2*10^7 symbols, against the oracle's table (compared on
+    the device).  The density comes from the probe; no pass may be repeated and none may fall back."""
+    import torch
+    c = _ctx(monkeypatch, LIME_UPDATE_PATH="bin")
+    try:
+        n = 20_000_000
+        lcp, da, eb = O.synth(4100 + ng, 0, n, nr, ng, 16, mode)
+        e = eb if ebwt_on else None
+        cl, nc, ml = O.detect(lcp, da, nr, 16)
+        exp = O.score(da, e, cl, nr, ng, threads=8)
+        dev = torch.device("cuda", 0)
+        import lime_amd
+        tl = torch.from_numpy(lcp.view(np.int32)).to(dev); td = torch.from_numpy(da.view(np.int32)).to(dev)
+        te = torch.from_numpy(eb).to(dev) if ebwt_on else None
+        sim = torch.full((lime_amd.sim_bytes(nr, ng),), 0x5A, dtype=torch.uint8, device=dev)      # every byte must be written
+        c.fused_dev(tl, td, te, n, n, True, nr, ng, 16, sim, True)
+        s, rc = c.stats()
+        assert rc == 0 and (s.n_clusters, s.max_len) == (nc, ml) and s.wave_records_max > 0
+        ht = c.host_times()
+        assert ht["probes"] == 1 and ht["repeats"] == 0 and ht["cas_fallbacks"] == 0, ht
+        assert abs(ht["records_per_symbol"] - s.n_updates / n) < 1e-9                # (after the pass: what it counted)
+        texp = torch.from_numpy(exp.reshape(-1)).to(dev)
+        assert torch.equal(sim[:nr * ng], texp), int((sim[:nr * ng] != texp).sum())
+        del texp
+        # the same pass with the sub-regions far too small: overflow, repeat sized from the fullest SUB-REGION's count
+        c2 = _ctx(monkeypatch, LIME_UPDATE_PATH="bin", LIME_POOL_DENSITY="0.002", LIME_POOL_SLACK=0)
+        try:
+            sim2 = torch.full_like(sim, 0xA5)
+            c2.fused_dev(tl, td, te, n, n, True, nr, ng, 16, sim2, True)
+            s2, rc2 = c2.stats()
+            assert rc2 == 0 and c2.host_times()["repeats"] >= 1
+            assert torch.equal(sim, sim2)
+        finally:
+            c2.close()
+    finally:
+        c.close()
+
+
+@pytest.mark.parametrize("n,nr,ng,ebwt_on,mode", [
+    (40_000_000, 100_000, 500, True, 0),      # configs[1]'s shape: 0.03 records per symbol, 50 MB table
+    (40_000_000, 100_000, 500, True, 1),      # clustered: several times that
+    (30_000_000, 400_000, 2000, False, 0),    # 800 MB table, EBWT=0
+])
+def test_density_probe_lands_the_first_pass(n, nr, ng, ebwt_on, mode):
+    """A fresh context's first pass (LiME_paired.sh:62-68 runs every collection once): the sampled probe's density is within a few % of
+    what the pass then counts, the pass is not repeated, and its table is the oracle's."""
+    import torch
+    import lime_amd
+    lcp, da, eb = O.synth(5150 + mode, 0, n, nr, ng, 16, mode)
+    e = eb if ebwt_on else None
+    cl, nc, ml = O.detect(lcp, da, nr, 16)
+    exp = O.score(da, e, cl, nr, ng, threads=8)
+    dev = torch.device("cuda", 0)
+    tl = torch.from_numpy(lcp.view(np.int32)).to(dev); td = torch.from_numpy(da.view(np.int32)).to(dev)
+    te = torch.from_numpy(eb).to(dev) if ebwt_on else None
+    sim = torch.full((lime_amd.sim_bytes(nr, ng),), 0x33, dtype=torch.uint8, device=dev)
+    c = lime_amd.Context()
+    try:
+        c.fused_dev(tl, td, te, n, n, True, nr, ng, 16, sim, True)
+        probed = c.host_times()
+        assert probed["probes"] == 1 and probed["records_per_symbol"] is not None
+        s, rc = c.stats()
+        assert rc == 0 and (s.n_clusters, s.max_len) == (nc, ml)
+        true_density = s.n_updates / n
+        assert abs(probed["records_per_symbol"] - true_density) <= 0.05 * true_density + 1e-4, (probed, true_density)
+        ht = c.host_times()
+        assert ht["repeats"] == 0 and ht["cas_fallbacks"] == 0 and not (s.flags & 128)
+        assert np.array_equal(sim[:nr * ng].cpu().numpy().reshape(nr, ng), exp)
+        # a second pass on the context: no second probe
+        c.fused_dev(tl, td, te, n, n, True, nr, ng, 16, sim, True)
+        s, rc = c.stats()
+        assert rc == 0 and c.host_times()["probes"] == 1
+        assert np.array_equal(sim[:nr * ng].cpu().numpy().reshape(nr, ng), exp)
+    finally:
+        c.close()
+
+
+def test_probe_then_shards_and_streams_are_unchanged(monkeypatch):
+    """the probe runs in front of whole passes only: shards of a stream (keep_stats) and passes that add to a table never see it"""
+    import lime_amd
+    c = lime_amd.Context()
+    try:
+        n, nr, ng = 18_000_000, 50_000, 400
+        lcp, da, eb = O.synth(99, 0, n, nr, ng, 16, 1)
+        cl, nc, ml = O.detect(lcp, da, nr, 16)
+        exp = O.score(da, eb, cl, nr, ng, threads=8)
+        sim, gnc, gml = c.fused_stream(lcp, da, eb, nr, ng, 16, chunk=5_000_000)
+        assert (gnc, gml) == (nc, ml) and np.array_equal(sim, exp)
+        assert c.host_times()["probes"] == 0
+        sim, gnc, gml = c.fused(lcp, da, eb, nr, ng, 16)
+        assert (gnc, gml) == (nc, ml) and np.array_equal(sim, exp)
+    finally:
+        c.close()
+
+
+def test_fallback_to_compare_and_swap_is_loud(monkeypatch):
+    """No device memory for the update records: the pass runs by compare-and-swap, gives the same table, and SAYS so -- LIME_FLAG_CAS_FALLBACK in
+    the statistics, the reason in lime_last_error(), a count in lime_get_host_times.  (Provoked with a pool density no device can hold.)"""
+    import lime_amd
+    from lime_amd import _lib
+    c = _ctx(monkeypatch, LIME_UPDATE_PATH="bin", LIME_POOL_DENSITY="30000")        # 17e6 symbols x 3e4 records x 4 bytes x 2 buffers > 288 GB
+    try:
+        n, nr, ng = 17_000_000, 50_000, 400
+        lcp, da, eb = O.synth(123, 0, n, nr, ng, 16, 0)
+        cl, nc, ml = O.detect(lcp, da, nr, 16)
+        exp = O.score(da, eb, cl, nr, ng, threads=8)
+        sim, gnc, gml = c.fused(lcp, da, eb, nr, ng, 16)
+        assert (gnc, gml) == (nc, ml) and np.array_equal(sim, exp)
+        s, rc = c.stats()
+        assert rc == 0 and (s.flags & 128) and s.wave_records_max == 0
+        assert c.host_times()["cas_fallbacks"] >= 1
+        assert b"falls back to compare-and-swap" in _lib.load().lime_last_error()
+    finally:
+        c.close()
+
+
+@pytest.mark.parametrize("shape", ["n1e10_clustered", "c5_clustered"])
+def test_full_size_clustered_passes_stay_binned(shape):
+    """N = 10^10 on one GPU at several times the iid generators' update density (the clustered generator; rounds 1-4 sent these passes to the
+    compare-and-swap path: more records than 32-bit positions hold).  Size-independent properties: the pass takes the binned path with no
+    fallback and no repeat after the probe; its table equals the table accumulated over eight position-range shards (each small enough for
+    32-bit positions, each on the binned path too, added modulo 256 on the device); counters agree; the row scan is a plain reduction."""
+    import torch
+    import lime_amd
+    from lime_amd.dist import shard_ranges, combine_edges
+    n, nr, ng, ebwt_on = {"n1e10_clustered": (10_000_000_000, 1_000_000, 1000, False), "c5_clustered": (10_000_000_000, 3_000_000, 3423, True)}[shape]
+    alpha, dev = 16, torch.device("cuda:0")
+    c = lime_amd.Context()
+    try:
+        lcp = torch.empty(n, dtype=torch.int32, device=dev); da = torch.empty_like(lcp)
+        eb = torch.empty(n, dtype=torch.uint8, device=dev) if ebwt_on else None
+        c.synth_dev(42, 0, n, nr, ng, alpha, 1, lcp, da, eb)
+        tb = lime_amd.sim_bytes(nr, ng)
+        A = torch.empty(tb, dtype=torch.uint8, device=dev)
+        c.fused_dev(lcp, da, eb, n, n, True, nr, ng, alpha, A, True)
+        sA, rc = c.stats(); assert rc == 0
+        ht = c.host_times()
+        assert sA.wave_records_max > 0 and not (sA.flags & 128), "the pass left the binned path"
+        assert ht["probes"] == 1 and ht["repeats"] == 0 and ht["cas_fallbacks"] == 0, ht
+        assert sA.n_updates > n // 10, int(sA.n_updates)             # clustered: well above the iid generators' 0.03 .. 0.12 per symbol
+        B = torch.empty(tb, dtype=torch.uint8, device=dev)
+        S = torch.zeros(tb, dtype=torch.uint8, device=dev)
+        tot_c, tot_m, tot_u, edges = 0, 0, 0, []
+        for lo, hi, hh in shard_ranges(n, 8):
+            c.fused_dev(lcp[lo:], da[lo:], None if eb is None else eb[lo:], hi - lo, hh - lo, hh == n, nr, ng, alpha, B, True)
+            s, rc = c.stats(); assert rc == 0 and s.wave_records_max > 0
+            tot_c += s.n_clusters; tot_m = max(tot_m, s.max_len); tot_u += s.n_updates; edges.append(s.edge)
+            S += B                                                   # uint8: modulo 256, like the ranks' reduce-scatter
+        combine_edges(edges)
+        assert (tot_c, tot_m, tot_u) == (sA.n_clusters, sA.max_len, sA.n_updates)
+        assert torch.equal(A, S)
+        del B, S
+        mx = torch.empty(nr, dtype=torch.uint8, device=dev); nz = torch.empty(nr, dtype=torch.int32, device=dev)
+        c.choose_dev(A, nr, ng, mx, nz)
+        t2 = A[:nr * ng].view(nr, ng)
+        assert torch.equal(mx, t2.amax(dim=1))
+        assert int(nz.sum()) == int(torch.count_nonzero(t2))
+    finally:
+        c.close()
