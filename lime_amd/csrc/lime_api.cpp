@@ -45,6 +45,7 @@ struct lime_ctx {
     int device = 0;
     DevStats *d_stats = nullptr;                // followed by the sticky word: passes with a pool overflow not settled by lime_get_stats
     uint32_t *d_sticky = nullptr;
+    void *h_stats = nullptr;                    // pinned: where read_stats lands the counters (a copy into pageable memory is staged by the runtime: +30 us per call)
     unsigned long long *d_total = nullptr;
     // per-tile scratch (capacity in tiles)
     size_t tile_cap = 0;
@@ -155,6 +156,7 @@ extern "C" int lime_init(int device, lime_ctx **out)
     c->d_sticky = reinterpret_cast<uint32_t *>(c->d_stats + 1);
     HIP_TRY(hipMalloc(&c->d_total, sizeof(unsigned long long)));
     HIP_TRY(hipMemset(c->d_stats, 0, sizeof(DevStats) + 16));
+    HIP_TRY(hipHostMalloc(&c->h_stats, sizeof(lime_stats_t) + 16));
 #ifdef LIME_ABLATE_BUILD
     if (const char *s = getenv("LIME_ABLATE")) c->ablate = atoi(s);
 #endif
@@ -182,6 +184,7 @@ extern "C" void lime_shutdown(lime_ctx *c)
     (void)hipSetDevice(c->device);
     (void)hipDeviceSynchronize();
     for (hipEvent_t e : c->ev) (void)hipEventDestroy(e);
+    if (c->h_stats) (void)hipHostFree(c->h_stats);
     (void)hipFree(c->d_stats); (void)hipFree(c->d_total); (void)hipFree(c->d_summ);
     (void)hipFree(c->d_tile_cnt); (void)hipFree(c->d_tile_off); (void)hipFree(c->d_cross); (void)hipFree(c->d_wmask);
     (void)hipFree(c->d_small); (void)hipFree(c->d_big); (void)hipFree(c->d_out);
@@ -378,8 +381,7 @@ static uint32_t part_prod_waves(const lime_ctx *c, int ebwt, uint32_t n_bins)
 static double sizing_density(const lime_ctx *c)
 {
     if (c->pool_density_fixed || !c->density_known) return c->pool_density;
-    const double d = c->density * 1.25 + 0.002;
-    return d < c->pool_density ? d : c->pool_density;
+    return c->density * 1.25 + 0.002;             // (rounds 3-4 capped this at the default: a collection denser than 0.2 overflowed its first pool)
 }
 
 // the largest part of a wave's records that one of its sub-regions (4 GB of table each, the last one what is left) has to take when the
@@ -791,11 +793,12 @@ extern "C" int lime_apply_records_dev(lime_ctx *c, uint32_t n_src, const uint32_
 
 static int read_stats(lime_ctx *c, lime_stats_t *s, hipStream_t st, uint32_t *sticky)
 {
-    struct { lime_stats_t s; uint32_t sticky[4]; } h;
-    HIP_TRY(hipMemcpyAsync(&h, c->d_stats, sizeof(lime_stats_t) + 4, hipMemcpyDeviceToHost, st));
+    struct H { lime_stats_t s; uint32_t sticky[4]; };
+    H *h = static_cast<H *>(c->h_stats);
+    HIP_TRY(hipMemcpyAsync(h, c->d_stats, sizeof(lime_stats_t) + 4, hipMemcpyDeviceToHost, st));
     HIP_TRY(hipStreamSynchronize(st));
-    *s = h.s;
-    if (sticky) *sticky = h.sticky[0];
+    *s = h->s;
+    if (sticky) *sticky = h->sticky[0];
     return LIME_OK;
 }
 
