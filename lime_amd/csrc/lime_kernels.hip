@@ -2397,7 +2397,12 @@ template <bool WIDE> __global__ __launch_bounds__(APPLY_WG) void k_apply_tiles(u
         // was a memory round trip, and added in a pass of its own it cost the instructions of a full pass for one or two lanes.
         if (WIDE) {
             const uint32_t ux = lane >> 4, lx = l0 + ux;
-            s.fax = lx < nl_ ? (uint32_t)__shfl((int)a_, (int)lx) : 0u; s.fex = lx < nl_ ? (uint32_t)__shfl((int)e_, (int)lx) : 0u;
+            // (the shuffles by ALL lanes, then the select: under the condition the compiler branches, and a lane reading from a lane the branch
+            // has switched off gets 0 -- with 33 .. 63 runs per wave and a last step of fewer than four, the source lanes l0 + ux sit in lane groups
+            // whose own run does not exist: the groups 64 .. 79 of the step's runs were dropped, silently -- a bin of 257 .. 511 tiles whose count
+            // is not a multiple of 32, e.g. the N = 1e10 series' 307 tiles per bin; found in round 5 by the clustered full-size test)
+            const uint32_t sa = (uint32_t)__shfl((int)a_, (int)(lx & 63u)), se = (uint32_t)__shfl((int)e_, (int)(lx & 63u));
+            s.fax = lx < nl_ ? sa : 0u; s.fex = lx < nl_ ? se : 0u;
             s.qx = (s.fax >> 2) + 64u + (lane & 15u);
             s.vx = make_uint2(0u, 0u);
             if (s.qx * 4u < s.fex) s.vx = *reinterpret_cast<const uint2 *>(recs16 + (size_t)(row_w + NWV * lx) * ROW_STRIDE + (size_t)s.qx * 4u);

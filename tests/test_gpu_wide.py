@@ -230,3 +230,25 @@ def test_full_size_clustered_passes_stay_binned(shape):
         assert int(nz.sum()) == int(torch.count_nonzero(t2))
     finally:
         c.close()
+
+
+@pytest.mark.parametrize("wide", ["0", "1"])
+@pytest.mark.parametrize("n", [12_000_000, 14_000_000, 17_700_000])
+def test_bins_of_257_to_511_tiles(monkeypatch, n, wide):
+    """One bin of 32 regions holding 336 / 392 / 495 second-level tiles: a wave of k_apply_tiles then walks 33 .. 63 runs per region, in steps of
+    four, and the last step is short.  k_apply_tiles<true> took the index entries of a step's runs with __shfl inside a condition: a lane whose own run
+    of the short last step does not exist was switched off, and whoever read from it got 0 -- groups 64 .. 79 of those runs were dropped without a
+    trace (rounds 4: the N = 10^10 series has 308 tiles per bin; no test had a bin between 256 and 512 tiles).  Found by
+    test_full_size_clustered_passes_stay_binned in round 5; this is the small case, against the oracle."""
+    c = _ctx(monkeypatch, LIME_UPDATE_PATH="bin", LIME_BIN_LEVELS="1,1", LIME_APPLY_WIDE=wide)
+    try:
+        nr, ng = 2048, 1024
+        lcp, da, _ = O.synth(77, 0, n, nr, ng, 16, 1)
+        cl, nc, ml = O.detect(lcp, da, nr, 16)
+        exp = O.score(da, None, cl, nr, ng, threads=8)
+        sim, gnc, gml = c.fused(lcp, da, None, nr, ng, 16)
+        s, rc = c.stats()
+        assert rc == 0 and 256 * 8192 < s.n_updates < 512 * 8192, int(s.n_updates)
+        assert (gnc, gml) == (nc, ml) and np.array_equal(sim, exp), int((sim != exp).sum())
+    finally:
+        c.close()
