@@ -103,6 +103,18 @@ int lime_detect(lime_ctx *ctx, const uint32_t *lcp, const uint32_t *da, uint64_t
                 uint32_t n_reads, uint32_t alpha,
                 lime_cluster_t **clusters, uint64_t *n_clusters, uint64_t *max_len);
 
+/* lime_detect with the records appended to the file `path` (fileFasta.<alpha>.clrs, ClusterLCP.cpp:229-235) as the chunks complete --
+ * no list of the whole collection in host memory.  What the drop-in ClusterLCP calls. */
+int lime_detect_to_file(lime_ctx *ctx, const uint32_t *lcp, const uint32_t *da, uint64_t n,
+                        uint32_t n_reads, uint32_t alpha, const char *path, uint64_t *n_clusters, uint64_t *max_len);
+
+/* The host-pointer entry points take arrays in pageable memory and stage them through pinned buffers on a few host threads.  When an array IS a
+ * mapped file (the drop-in programs map fileFasta.lcp / .da / .ebwt / .clrs), registering the mapping lets those threads fill the pinned buffers with
+ * pread() from `fd` instead of touching the mapping page by page (ClusterLCP.cpp:100-123 reads with one FILE* per thread).  The library keeps its
+ * own duplicate of the descriptor until lime_unregister_file(base). */
+int  lime_register_file(const void *base, size_t bytes, int fd);
+void lime_unregister_file(const void *base);
+
 /* clusterAnalyze, src/ClusterBWT_DA.cpp:256-358 (Update_ref_symb :81-105,
  * Analysis_and_updating :107-190 / :192-252).  ebwt == NULL selects the EBWT=0 build.
  * sim: caller-owned n_reads*n_refs bytes; it is OVERWRITTEN with the table for these

@@ -50,6 +50,9 @@ SYMBOLS = {
     "lime_device_count": (_i, []),
     "lime_pick_device": (_i, [C.c_uint]),
     "lime_detect": (_i, [_vp, _vp, _vp, _u64, _u32, _u32, _pp, _pu64, _pu64]),
+    "lime_detect_to_file": (_i, [_vp, _vp, _vp, _u64, _u32, _u32, C.c_char_p, _pu64, _pu64]),
+    "lime_register_file": (_i, [_vp, _sz, _i]),
+    "lime_unregister_file": (None, [_vp]),
     "lime_score": (_i, [_vp, _vp, _vp, _u64, _vp, _u64, _u32, _u32, _vp]),
     "lime_fused": (_i, [_vp, _vp, _vp, _vp, _u64, _u32, _u32, _u32, _vp, _pu64, _pu64]),
     "lime_choose": (_i, [_vp, _vp, _u32, _u32, _vp, _vp]),

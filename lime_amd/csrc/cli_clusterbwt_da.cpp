@@ -18,6 +18,7 @@ static int env_flag(const char *name, int dflt)
 
 int main(int argc, char **argv)
 {
+    CliClock clk;
     if (argc != 5) {
         std::cerr << "Error usage " << argv[0] << " fileFasta readLen beta threads" << std::endl;
         exit(1);
@@ -58,6 +59,7 @@ int main(int argc, char **argv)
     const uint64_t n = da.bytes / 4;
 
     auto t0 = std::chrono::steady_clock::now();
+    clk.mark("arguments, files mapped");
     std::cerr << "Computing similarity arrays SimArray_i[1,numRead]..." << std::endl;
     // the table stays in HBM: the row scan and the (idRef, sim) lists of the passing reads are made
     // on the device and only those come back (lime_score_choose).  LIME_GPUS=k: the cluster list is cut over k GPUs
@@ -74,6 +76,7 @@ int main(int argc, char **argv)
                                      rmax.data(), roff.data(), &pairs, &nPairs);
     } else {
         if (lime_init(pick_device(), &ctx) != LIME_OK) { std::cerr << "Error: " << lime_last_error() << std::endl; exit(EXIT_FAILURE); }
+        clk.mark("lime_init (HIP runtime)");
         rc = lime_score_choose(ctx, (const uint32_t *)da.data, EBWT ? (const uint8_t *)bwt.data : nullptr, n,
                                (const lime_cluster_t *)clrs.data, nClusters, numRead, numRef, norm, beta,
                                rmax.data(), roff.data(), &pairs, &nPairs, nullptr);
@@ -81,6 +84,7 @@ int main(int argc, char **argv)
     if (rc != LIME_OK) { std::cerr << "Error: " << lime_last_error() << std::endl; exit(1); }
     fprintf(stderr, "TIME clusterAnalyze: %.6lf\n", std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count());
 
+    clk.mark("scoring + choose");
     auto t1 = std::chrono::steady_clock::now();
     const std::string fnF = fileFasta + ".res";
     if (BIN) {
@@ -93,7 +97,9 @@ int main(int argc, char **argv)
     lime_free(pairs);
     if (rc != LIME_OK) { std::cerr << "Error opening " << fnF << "." << std::endl; exit(EXIT_FAILURE); }
     fprintf(stdout, "Time: %.6lf\n", std::chrono::duration<double>(std::chrono::steady_clock::now() - t1).count());
+    clk.mark("result files");
     if (ctx) lime_shutdown(ctx);
+    clk.mark("shutdown");
     std::cout << "Cluster analysis completed with beta=" << beta << "." << std::endl;
     std::cout << "Number of clusters: " << nClusters << "." << std::endl;
     fprintf(stdout, "Time: %.6lf\n", std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count());

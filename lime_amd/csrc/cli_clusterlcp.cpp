@@ -11,6 +11,7 @@
 
 int main(int argc, char **argv)
 {
+    CliClock clk;
     if (argc != 6) {
         std::cerr << "Error usage: " << argv[0] << " fileFasta numReads numGenomes alpha threads" << std::endl;
         exit(1);
@@ -39,20 +40,22 @@ int main(int argc, char **argv)
     if (da.bytes / 4 < n) { std::cerr << "Error: " << fnDA << " is shorter than " << fnLCP << "." << std::endl; exit(EXIT_FAILURE); }
 
     auto t0 = std::chrono::steady_clock::now();
+    clk.mark("arguments, files mapped");
     lime_ctx *ctx = nullptr;
     if (lime_init(pick_device(), &ctx) != LIME_OK) { std::cerr << "Error: " << lime_last_error() << std::endl; exit(EXIT_FAILURE); }
-    lime_cluster_t *cl = nullptr;
+    clk.mark("lime_init (HIP runtime)");
     uint64_t nClusters = 0, maxLen = 0;
-    int rc = lime_detect(ctx, (const uint32_t *)lcp.data, (const uint32_t *)da.data, n, numReads, alpha,
-                         &cl, &nClusters, &maxLen);
+    // the records go to the .clrs file chunk by chunk while the scan goes on (lime_detect_to_file)
+    int rc = lime_detect_to_file(ctx, (const uint32_t *)lcp.data, (const uint32_t *)da.data, n, numReads, alpha, fnOut.c_str(), &nClusters, &maxLen);
+    if (rc == LIME_ERR_IO) { std::cerr << "Error opening " << fnOut << "."; exit(1); }
     if (rc != LIME_OK) { std::cerr << "Error: " << lime_last_error() << std::endl; exit(EXIT_FAILURE); }
-    if (lime_write_clrs(fnOut.c_str(), cl, nClusters) != LIME_OK) { std::cerr << "Error opening " << fnOut << "."; exit(1); }
+    clk.mark("scan + .clrs");
     const std::string fileaux = aux_name(fileFasta);
     if (lime_write_aux(fileaux.c_str(), numReads, numGenomes, alpha, maxLen, nClusters) != LIME_OK) {
         std::cerr << "Error opening " << fileaux << "." << std::endl; exit(EXIT_FAILURE);
     }
-    lime_free(cl);
     lime_shutdown(ctx);
+    clk.mark("aux file, shutdown");
     std::cout << "Clustering process with alpha=" << alpha << " completed.\nTotal number of clusters: " << nClusters
               << ".\nMaximum cluster size: " << maxLen << "." << std::endl;
     fprintf(stdout, "Time: %.6lf\n", std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count());

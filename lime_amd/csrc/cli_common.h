@@ -26,12 +26,14 @@ struct MappedFile {
             void *p = mmap(nullptr, bytes, PROT_READ, MAP_PRIVATE, fd, 0);
             if (p == MAP_FAILED) return false;
             data = p;
+            // the library's staging threads read the file with pread() instead of faulting the mapping in page by page
+            (void)lime_register_file(data, bytes, fd);
         }
         return true;
     }
     ~MappedFile()
     {
-        if (data) munmap(const_cast<void *>(data), bytes);
+        if (data) { lime_unregister_file(data); munmap(const_cast<void *>(data), bytes); }
         if (fd >= 0) close(fd);
     }
 };
@@ -45,13 +47,28 @@ static inline int pick_device()
     return lime_pick_device((unsigned)getpid());
 }
 
-// the reference's `threads` argument: here the host threads that stage the mapped files into pinned memory
+// the reference's `threads` argument: here the host threads that stage the files into pinned memory -- at least 8 (the scan is on the GPU; what
+// the host does is move the page cache to the link, about 3 GB/s per thread), more if the caller asks; LIME_IO_THREADS overrides
 static inline void io_threads_from_argv(int threads)
 {
-    if (threads < 1) threads = 1;
+    if (threads < 8) threads = 8;
     char buf[16]; snprintf(buf, sizeof buf, "%d", threads);
     setenv("LIME_IO_THREADS", buf, 0);
 }
+
+// LIME_CLI_TIMING=1: wall-clock marks of the program's phases on stderr (tools/bench_cli.py)
+#include <chrono>
+struct CliClock {
+    std::chrono::steady_clock::time_point t0 = std::chrono::steady_clock::now(), last = t0;
+    bool on = getenv("LIME_CLI_TIMING") != nullptr;
+    void mark(const char *what)
+    {
+        const auto now = std::chrono::steady_clock::now();
+        if (on) fprintf(stderr, "[cli] %-28s %8.3f ms (at %8.3f)\n", what, std::chrono::duration<double, std::milli>(now - last).count(),
+                        std::chrono::duration<double, std::milli>(now - t0).count());
+        last = now;
+    }
+};
 
 static inline std::string aux_name(const std::string &fileFasta)
 {

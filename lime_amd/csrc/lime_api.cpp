@@ -6,8 +6,11 @@
 #include <algorithm>
 #include <stdarg.h>
 #include <stdio.h>
+#include <errno.h>
+#include <fcntl.h>
 #include <stdlib.h>
 #include <string.h>
+#include <unistd.h>
 #include <atomic>
 #include <chrono>
 #include <condition_variable>
@@ -24,6 +27,7 @@
 using namespace lime;
 
 static thread_local std::string g_err;
+static uint64_t PROBE_MIN = 1ull << 28;     // first passes of fewer symbols run without the density probe (binned, pool for 0.45 records per symbol); LIME_PROBE_MIN: tests
 
 static int fail(int code, const char *fmt, ...)
 {
@@ -82,7 +86,7 @@ struct lime_ctx {
     bool density_known = false; double density = 0.0;          // table updates per owned symbol of the last pass read back
     bool bin_levels_forced = false;
     uint32_t bin_one_level = BIN_ONE_LEVEL, bin_two_level = BIN_TWO_LEVEL;   // LIME_BIN_LEVELS="a,b" (tests: force the second level on small tables)
-    double pool_density = 0.20;             // records per owned symbol the pool is sized for before a pass has been measured (grows on LIME_FLAG_POOL_FULL)
+    double pool_density = 0.45;             // records per owned symbol the pool is sized for before anything has been measured (first passes below 2^28 symbols, which run without the density probe: text has 0.24 .. 0.39; grows on LIME_FLAG_POOL_FULL)
     bool pool_density_fixed = false;        // set by LIME_POOL_DENSITY or by a repeated pass: sizing_density() then leaves it alone
     int scan_static_pct = -1;               // share (%) of the scan's rounds of window chunks that go round-robin, the rest is handed out as workgroups get there; -1: by the input's length (base_args); LIME_SCAN_STATIC_PCT: tests, comparison runs
     uint32_t part_split = 2;                // producers (of k_part) per scan workgroup at most (LIME_PART_SPLIT: comparison runs): two = one partition workgroup per resident slot of the device; four -- round 4's first choice -- cut the streams into more, less filled tiles: k_part_lines +4 % at N = 1e10 and on the text workload
@@ -171,6 +175,7 @@ extern "C" int lime_init(int device, lime_ctx **out)
     if (const char *s = getenv("LIME_PART_SPLIT")) { const long v = atol(s); if (v >= 1 && v <= 16) c->part_split = (uint32_t)v; }
     if (const char *s = getenv("LIME_POOL_SLACK")) { const long v = atol(s); if (v >= 0) c->pool_slack = (uint32_t)v; }
     if (const char *s = getenv("LIME_NO_PROBE")) c->probe = atoi(s) == 0;
+    if (const char *s = getenv("LIME_PROBE_MIN")) { const unsigned long long v = strtoull(s, nullptr, 0); PROBE_MIN = v < (1ull << 24) ? (1ull << 24) : v; }
     if (const char *s = getenv("LIME_FORCE_P64")) c->force_p64 = atoi(s) != 0;
     if (const char *s = getenv("LIME_P64_TEST_BASE")) { c->p64_test_base = strtoull(s, nullptr, 0) & ~15ull; if (c->p64_test_base) c->force_p64 = true; }
     if (const char *s = getenv("LIME_MAX_BLOCKS")) { long v = atol(s); if (v > 0) c->max_blocks = (uint32_t)v; }
@@ -358,7 +363,11 @@ static bool want_binned(const lime_ctx *c, uint64_t n_own, size_t sim_bytes, int
     // configs[4]'s 10.3 GB table 31.5 against 20.8, configs[3]'s shape 8.3 against 7.6) -- worth ~0.3 ms of extra launches
     // from about 5 million records on.
     if (c->density_known) return sim_bytes > (256u << 20) ? c->density * (double)n_own >= 5e6 : c->density >= 0.06;
-    return sim_bytes > (256u << 20);                      // nothing known yet: tables beyond the Infinity Cache
+    // Nothing known yet (a first pass too short for the density probe to pay -- below 2^28 symbols its fixed 0.13 ms is a third to a half of the
+    // pass --, or LIME_NO_PROBE): binned.  It is the path that loses little where it loses (configs[1], 0.03 records per symbol: 0.29 against
+    // 0.24 ms) and wins much where it wins (the same shape at 0.17: 0.40 against 0.85 ms; text statistics: 0.56 against 4.3 ms); rounds 2-4 took
+    // compare-and-swap for tables the Infinity Cache holds.
+    return true;
 }
 
 // records per owned symbol the pool of the next pass is sized for: what the last pass measured, with a margin (the waves'
@@ -546,7 +555,7 @@ static int fused_dev_impl(lime_ctx *c, const uint32_t *d_lcp, const uint32_t *d_
     // was repeated or ran on the other path).  LiME_paired.sh:62-68 runs every collection ONCE, so the density is sampled first: the
     // scan kernel itself over every 2^k-th chunk of 16 windows, counting its update records without storing one (density_probe).
     if (n_avail && !no_bin && !keep_stats && zero_sim && bin_fits && c->probe && !c->density_known && !c->pool_density_fixed && !c->ablate &&
-        c->upd_pref != 0 && n_own >= (1u << 24) && sim_bytes >= (1u << 20) && n_tiles < 0x7FF00000u)
+        c->upd_pref != 0 && n_own >= PROBE_MIN && sim_bytes >= (1u << 20) && n_tiles < 0x7FF00000u)
         if ((rc = density_probe(c, d_lcp, d_da, d_ebwt, n_own, n_avail, eof, n_reads, n_refs, alpha, sim_bytes, st))) return rc;
     bool binned = n_avail && !no_bin && want_binned(c, n_own, sim_bytes, zero_sim, keep_stats, ebwt);
     if (records_only) binned = true;                      // the records ARE the result: the binned path or nothing
@@ -1091,8 +1100,93 @@ const uint64_t STAGED_CHUNK = 4ull << 20;                               // throu
 // pinned slots instead: a producer thread (with LIME_IO_THREADS helpers) copies the chunk's pieces into slot k % 3
 // while the copy engine empties slot (k-1) % 3 into one device buffer set and the kernels work on the other.
 // Sources that are already pinned (hipHostMalloc / hipHostRegister) skip the ring.
+// ---- mapped files the callers hand over as arrays (the drop-in programs): lime_register_file tells the library which file a mapping shows, and
+// the staging threads then fill the pinned slots with pread() from the file -- the page cache copied by the kernel at several GB/s per thread --
+// instead of memcpy from the mapping, which takes a page fault per 4 KB (16-page fault-around) of every first touch: 10.6 GB/s with 8 threads in
+// round 4, a fifth of what the link takes from pinned memory.  Reference: the per-thread FILE* reads of ClusterLCP.cpp:100-123, 206-212.
+namespace {
+struct FileMap { const char *base; size_t bytes; int fd; };
+std::mutex g_files_mu;
+std::vector<FileMap> g_files;
+// bytes [src, src + len) from the registered file that holds them (false: not in one -- the caller copies from memory)
+bool read_from_file(void *dst, const void *src, size_t len)
+{
+    FileMap m{nullptr, 0, -1};
+    {
+        std::lock_guard<std::mutex> g(g_files_mu);
+        for (const FileMap &f : g_files)
+            if ((const char *)src >= f.base && (const char *)src + len <= f.base + f.bytes) { m = f; break; }
+    }
+    if (m.fd < 0) return false;
+    size_t done = 0;
+    const off_t at = (off_t)((const char *)src - m.base);
+    while (done < len) {
+        const ssize_t k = pread(m.fd, (char *)dst + done, len - done, at + (off_t)done);
+        if (k <= 0) { if (k < 0 && errno == EINTR) continue; return false; }
+        done += (size_t)k;
+    }
+    return true;
+}
+}
+extern "C" int lime_register_file(const void *base, size_t bytes, int fd)
+{
+    if (!base || fd < 0) return fail(LIME_ERR_ARG, "lime_register_file: bad argument");
+    const int own = dup(fd);                               // the caller may close its descriptor
+    if (own < 0) return fail(LIME_ERR_IO, "lime_register_file: dup failed");
+    std::lock_guard<std::mutex> g(g_files_mu);
+    g_files.push_back(FileMap{(const char *)base, bytes, own});
+    return LIME_OK;
+}
+extern "C" void lime_unregister_file(const void *base)
+{
+    std::lock_guard<std::mutex> g(g_files_mu);
+    for (size_t i = 0; i < g_files.size(); ++i)
+        if (g_files[i].base == (const char *)base) { close(g_files[i].fd); g_files.erase(g_files.begin() + (long)i); return; }
+}
+
 namespace {
 struct Piece { const void *src; size_t bytes; void *dst; };
+
+// a few host threads that copy (or pread) pieces of 1 MB: created once per walk, not per piece
+struct IoPool {
+    struct Task { void *dst; const void *src; size_t len; };
+    std::vector<std::thread> th;
+    std::mutex mu; std::condition_variable cv_go, cv_done;
+    std::vector<Task> tasks; size_t next = 0, left = 0; bool stop = false;
+    void start(int n)
+    {
+        for (int t = 0; t < n; ++t)
+            th.emplace_back([this]() {
+                for (;;) {
+                    Task k;
+                    {
+                        std::unique_lock<std::mutex> lk(mu);
+                        cv_go.wait(lk, [&] { return stop || next < tasks.size(); });
+                        if (stop) return;
+                        k = tasks[next++];
+                    }
+                    if (!read_from_file(k.dst, k.src, k.len)) memcpy(k.dst, k.src, k.len);
+                    { std::lock_guard<std::mutex> g(mu); if (--left == 0) cv_done.notify_all(); }
+                }
+            });
+    }
+    void run(std::vector<Task> &&t)                        // returns when every task is done
+    {
+        if (t.empty()) return;
+        if (th.empty()) { for (const Task &k : t) if (!read_from_file(k.dst, k.src, k.len)) memcpy(k.dst, k.src, k.len); return; }
+        std::unique_lock<std::mutex> lk(mu);
+        tasks = std::move(t); next = 0; left = tasks.size();
+        cv_go.notify_all();
+        cv_done.wait(lk, [&] { return left == 0; });
+        tasks.clear(); next = 0;
+    }
+    ~IoPool()
+    {
+        { std::lock_guard<std::mutex> g(mu); stop = true; }
+        cv_go.notify_all();
+        for (auto &t : th) t.join();
+    }
+};
 
 struct Feeder {
     static constexpr int NS = 3, MAXP = 3;
@@ -1119,19 +1213,7 @@ struct Feeder {
         if (hipPointerGetAttributes(&at, p) != hipSuccess) { (void)hipGetLastError(); return false; }
         return at.type == hipMemoryTypeHost;
     }
-    static void copy_parallel(void *dst, const void *src, size_t bytes, int threads)
-    {
-        if (threads <= 1 || bytes < (8u << 20)) { memcpy(dst, src, bytes); return; }
-        std::vector<std::thread> th;
-        const size_t part = ((bytes + (size_t)threads - 1) / (size_t)threads + 4095) & ~(size_t)4095;    // threads * part >= bytes
-        for (int t = 0; t < threads; ++t) {
-            const size_t o = part * (size_t)t;
-            if (o >= bytes) break;
-            const size_t len = bytes - o < part ? bytes - o : part;
-            th.emplace_back([=]() { memcpy((char *)dst + o, (const char *)src + o, len); });
-        }
-        for (auto &t : th) t.join();
-    }
+    IoPool pool;
     int init(size_t bytes_per_chunk, uint64_t chunks, bool all_sources_pinned, std::function<int(uint64_t, Piece *)> d)
     {
         describe = std::move(d); n_chunks = chunks; slot_bytes = bytes_per_chunk;
@@ -1139,8 +1221,11 @@ struct Feeder {
         staged = will_stage(all_sources_pinned, bytes_per_chunk * chunks);
         if (!staged) return LIME_OK;
         HIP_TRY(hipGetDevice(&device));
-        io_threads = 4;
-        if (const char *e = getenv("LIME_IO_THREADS")) { const int v = atoi(e); if (v >= 1) io_threads = v > 32 ? 32 : v; }
+        // staging threads: LIME_IO_THREADS (the drop-in programs pass their `threads` argument, at least 8), else 8 -- as many as the machine has at most
+        io_threads = 8;
+        if (const char *e = getenv("LIME_IO_THREADS")) { const int v = atoi(e); if (v >= 1) io_threads = v > 64 ? 64 : v; }
+        { const unsigned hw = std::thread::hardware_concurrency(); if (hw && (unsigned)io_threads > hw) io_threads = (int)hw; }
+        if (io_threads > 1) pool.start(io_threads);
         for (int i = 0; i < NS; ++i) {
             HIP_TRY(hipHostMalloc(&slot[i], slot_bytes + 64, hipHostMallocDefault));
             HIP_TRY(hipEventCreateWithFlags(&h2d_done[i], hipEventDisableTiming));
@@ -1159,7 +1244,13 @@ struct Feeder {
                 { std::lock_guard<std::mutex> g(mu); if (stop) return; }
                 const int np = describe(k, pc);
                 size_t off = 0;
-                for (int i = 0; i < np; ++i) { copy_parallel((char *)slot[k % NS] + off, pc[i].src, pc[i].bytes, io_threads); off += (pc[i].bytes + 15) & ~(size_t)15; }
+                std::vector<IoPool::Task> tk;
+                for (int i = 0; i < np; ++i) {
+                    for (size_t o = 0; o < pc[i].bytes; o += (size_t)1 << 20)
+                        tk.push_back(IoPool::Task{(char *)slot[k % NS] + off + o, (const char *)pc[i].src + o, pc[i].bytes - o < ((size_t)1 << 20) ? pc[i].bytes - o : (size_t)1 << 20});
+                    off += (pc[i].bytes + 15) & ~(size_t)15;
+                }
+                pool.run(std::move(tk));
                 { std::lock_guard<std::mutex> g(mu); filled = k + 1; }
                 cv.notify_all();
             }
@@ -1296,6 +1387,63 @@ extern "C" int lime_fused_stream(lime_ctx *c, const uint32_t *lcp, const uint32_
     return LIME_OK;
 }
 
+// The walk of lime_detect / lime_detect_to_file: position-range chunks with a read-ahead halo (see lime_fused_stream); records of chunk k follow
+// those of chunk k-1, so the list stays in ascending pStart = the reference's 1-thread order.  The copy of chunk k+1 (through the pinned ring
+// when the arrays are pageable) is under way while chunk k is scanned.  sink(device records, count, stream): takes a chunk's records (the list
+// of the ctx is reused by the next chunk: the walk waits for the stream after every sink call).
+static int detect_walk(lime_ctx *c, const uint32_t *lcp, const uint32_t *da, uint64_t n, uint32_t n_reads, uint32_t alpha, uint64_t chunk,
+                       uint64_t *max_len, const std::function<int(const lime_cluster_t *, uint64_t, hipStream_t)> &sink)
+{
+    chunk = (chunk + LIME_TILE - 1) / LIME_TILE * LIME_TILE;
+    const uint64_t cap = (chunk < n ? chunk : n) + STREAM_HALO, n_chunks = (n + chunk - 1) / chunk;
+    int rc;
+    uint64_t ml = 0;
+    Pipe pp;
+    if ((rc = pp.init())) return rc;
+    DevBuf dl[2], dd[2];
+    for (int b = 0; b < (n_chunks > 1 ? 2 : 1); ++b) { if ((rc = dl[b].alloc(cap * 4 + 16))) return rc; if ((rc = dd[b].alloc(cap * 4 + 16))) return rc; }
+    Feeder feeder;
+    if ((rc = feeder.init(cap * 8 + 64, n_chunks, Feeder::pinned(lcp) && Feeder::pinned(da), [&](uint64_t kk, Piece *pc) {
+            const uint64_t lo = kk * chunk, own = n - lo < chunk ? n - lo : chunk;
+            const uint64_t avail = n - lo < own + STREAM_HALO ? n - lo : own + STREAM_HALO;
+            pc[0] = Piece{lcp + lo, (size_t)avail * 4, dl[kk & 1].p}; pc[1] = Piece{da + lo, (size_t)avail * 4, dd[kk & 1].p};
+            return 2;
+        }))) return rc;
+    if ((rc = feeder.feed(0, pp.copy))) return rc;
+    HIP_TRY(hipEventRecord(pp.copied[0], pp.copy));
+    for (uint64_t k = 0; k < n_chunks; ++k) {
+        const int b = (int)(k & 1);
+        const uint64_t lo = k * chunk, own = n - lo < chunk ? n - lo : chunk;
+        const uint64_t avail = n - lo < own + STREAM_HALO ? n - lo : own + STREAM_HALO;
+        if (k + 1 < n_chunks) {                       // the next chunk's copy goes out before this chunk's scan is waited for
+            const int nb = (int)((k + 1) & 1);
+            if (k + 1 >= 2) HIP_TRY(hipStreamWaitEvent(pp.copy, pp.consumed[nb], 0));
+            if ((rc = feeder.feed(k + 1, pp.copy))) { (void)hipDeviceSynchronize(); return rc; }
+            HIP_TRY(hipEventRecord(pp.copied[nb], pp.copy));
+        }
+        HIP_TRY(hipStreamWaitEvent(pp.comp, pp.copied[b], 0));
+        const lime_cluster_t *dc = nullptr;
+        uint64_t cnt = 0, m = 0;
+        rc = lime_detect_dev(c, (const uint32_t *)dl[b].p, (const uint32_t *)dd[b].p, own, avail, lo + avail == n, lo, n_reads,
+                             alpha, &dc, &cnt, &m, pp.comp);
+        if (rc) { (void)hipDeviceSynchronize(); return rc; }
+        if (m > ml) ml = m;
+        HIP_TRY(hipEventRecord(pp.consumed[b], pp.comp));   // (the arrays of the chunk have been read: lime_detect_dev waited for its count)
+        if (cnt && (rc = sink(dc, cnt, pp.comp))) { (void)hipDeviceSynchronize(); return rc; }
+        HIP_TRY(hipStreamSynchronize(pp.comp));           // the record list of the ctx is reused by the next chunk
+    }
+    HIP_TRY(hipStreamSynchronize(pp.copy));
+    *max_len = ml;
+    return LIME_OK;
+}
+
+static uint64_t detect_chunk(const uint32_t *lcp, const uint32_t *da, uint64_t n)
+{
+    uint64_t chunk0 = Feeder::will_stage(Feeder::pinned(lcp) && Feeder::pinned(da), (size_t)n * 8) ? STAGED_CHUNK : STREAM_CHUNK;
+    if (const char *e = getenv("LIME_DETECT_CHUNK")) { const uint64_t v = strtoull(e, nullptr, 10); if (v) chunk0 = v; }
+    return chunk0;
+}
+
 extern "C" int lime_detect(lime_ctx *c, const uint32_t *lcp, const uint32_t *da, uint64_t n, uint32_t n_reads,
                            uint32_t alpha, lime_cluster_t **clusters, uint64_t *n_clusters, uint64_t *max_len)
 {
@@ -1304,72 +1452,118 @@ extern "C" int lime_detect(lime_ctx *c, const uint32_t *lcp, const uint32_t *da,
     *clusters = nullptr; *n_clusters = 0; *max_len = 0;
     if (n && (!lcp || !da)) return fail(LIME_ERR_ARG, "lime_detect: NULL array");
     if (!n) return LIME_OK;
-    // position-range chunks with a read-ahead halo (see lime_fused_stream); records of chunk k follow
-    // those of chunk k-1, so the list stays in ascending pStart = the reference's 1-thread order.  The copy of
-    // chunk k+1 (through the pinned ring when the arrays are pageable) is under way while chunk k is scanned.
-    uint64_t chunk0 = Feeder::will_stage(Feeder::pinned(lcp) && Feeder::pinned(da), (size_t)n * 8) ? STAGED_CHUNK : STREAM_CHUNK;
-    if (const char *e = getenv("LIME_DETECT_CHUNK")) { const uint64_t v = strtoull(e, nullptr, 10); if (v) chunk0 = v; }
+    const uint64_t chunk0 = detect_chunk(lcp, da, n);
     lime_cluster_t *h = nullptr;
     uint64_t have = 0, room = 0, ml = 0;
-    auto walk = [&](uint64_t chunk) -> int {
-        chunk = (chunk + LIME_TILE - 1) / LIME_TILE * LIME_TILE;
-        const uint64_t cap = (chunk < n ? chunk : n) + STREAM_HALO, n_chunks = (n + chunk - 1) / chunk;
-        int rc;
-        Pipe pp;
-        if ((rc = pp.init())) return rc;
-        DevBuf dl[2], dd[2];
-        for (int b = 0; b < (n_chunks > 1 ? 2 : 1); ++b) { if ((rc = dl[b].alloc(cap * 4 + 16))) return rc; if ((rc = dd[b].alloc(cap * 4 + 16))) return rc; }
-        Feeder feeder;
-        if ((rc = feeder.init(cap * 8 + 64, n_chunks, Feeder::pinned(lcp) && Feeder::pinned(da), [&](uint64_t kk, Piece *pc) {
-                const uint64_t lo = kk * chunk, own = n - lo < chunk ? n - lo : chunk;
-                const uint64_t avail = n - lo < own + STREAM_HALO ? n - lo : own + STREAM_HALO;
-                pc[0] = Piece{lcp + lo, (size_t)avail * 4, dl[kk & 1].p}; pc[1] = Piece{da + lo, (size_t)avail * 4, dd[kk & 1].p};
-                return 2;
-            }))) return rc;
-        if ((rc = feeder.feed(0, pp.copy))) return rc;
-        HIP_TRY(hipEventRecord(pp.copied[0], pp.copy));
-        for (uint64_t k = 0; k < n_chunks; ++k) {
-            const int b = (int)(k & 1);
-            const uint64_t lo = k * chunk, own = n - lo < chunk ? n - lo : chunk;
-            const uint64_t avail = n - lo < own + STREAM_HALO ? n - lo : own + STREAM_HALO;
-            if (k + 1 < n_chunks) {                       // the next chunk's copy goes out before this chunk's scan is waited for
-                const int nb = (int)((k + 1) & 1);
-                if (k + 1 >= 2) HIP_TRY(hipStreamWaitEvent(pp.copy, pp.consumed[nb], 0));
-                if ((rc = feeder.feed(k + 1, pp.copy))) { (void)hipDeviceSynchronize(); return rc; }
-                HIP_TRY(hipEventRecord(pp.copied[nb], pp.copy));
-            }
-            HIP_TRY(hipStreamWaitEvent(pp.comp, pp.copied[b], 0));
-            const lime_cluster_t *dc = nullptr;
-            uint64_t cnt = 0, m = 0;
-            rc = lime_detect_dev(c, (const uint32_t *)dl[b].p, (const uint32_t *)dd[b].p, own, avail, lo + avail == n, lo, n_reads,
-                                 alpha, &dc, &cnt, &m, pp.comp);
-            if (rc) { (void)hipDeviceSynchronize(); return rc; }
-            if (m > ml) ml = m;
-            if (cnt) {
-                if (have + cnt > room) {
-                    room = (have + cnt) + (have + cnt) / 2 + 1024;
-                    lime_cluster_t *g = (lime_cluster_t *)realloc(h, (size_t)room * sizeof(lime_cluster_t));
-                    if (!g) { (void)hipDeviceSynchronize(); return fail(LIME_ERR_NOMEM, "lime_detect: out of host memory"); }
-                    h = g;
-                }
-                HIP_TRY(hipMemcpyAsync(h + have, dc, (size_t)cnt * sizeof(lime_cluster_t), hipMemcpyDeviceToHost, pp.comp));
-                have += cnt;
-            }
-            HIP_TRY(hipEventRecord(pp.consumed[b], pp.comp));
-            HIP_TRY(hipStreamSynchronize(pp.comp));       // the record list of the ctx is reused by the next chunk
+    auto sink = [&](const lime_cluster_t *dc, uint64_t cnt, hipStream_t st) -> int {
+        if (have + cnt > room) {
+            room = (have + cnt) + (have + cnt) / 2 + 1024;
+            lime_cluster_t *g = (lime_cluster_t *)realloc(h, (size_t)room * sizeof(lime_cluster_t));
+            if (!g) return fail(LIME_ERR_NOMEM, "lime_detect: out of host memory");
+            h = g;
         }
-        HIP_TRY(hipStreamSynchronize(pp.copy));
+        HIP_TRY(hipMemcpyAsync(h + have, dc, (size_t)cnt * sizeof(lime_cluster_t), hipMemcpyDeviceToHost, st));
+        have += cnt;
         return LIME_OK;
     };
-    rc = walk(chunk0);
+    rc = detect_walk(c, lcp, da, n, n_reads, alpha, chunk0, &ml, sink);
     if (rc == LIME_ERR_HALO && chunk0 < n) {
         // a run longer than the halo crosses a chunk border.  ClusterLCP itself has no length limit (only
         // ClusterBWT_DA refuses such a cluster later): redo the whole collection as one chunk
         have = 0; ml = 0;
-        rc = walk(n);
+        rc = detect_walk(c, lcp, da, n, n_reads, alpha, n, &ml, sink);
     }
     if (rc) { free(h); return rc; }
     *clusters = h; *n_clusters = have; *max_len = ml;
+    return LIME_OK;
+}
+
+// lime_detect with the records written to `path` as they come (the .clrs file of ClusterLCP.cpp:229-235, ascending pStart): every chunk's
+// records land in one of two pinned buffers and a writer thread appends them to the file while the next chunk is scanned -- no list of the
+// whole collection on the host (10^9 symbols: 0.9 GB that round 4 grew by realloc, copied through a pageable buffer and wrote at the end).
+extern "C" int lime_detect_to_file(lime_ctx *c, const uint32_t *lcp, const uint32_t *da, uint64_t n, uint32_t n_reads,
+                                   uint32_t alpha, const char *path, uint64_t *n_clusters, uint64_t *max_len)
+{
+    int rc = check_ctx(c, "lime_detect_to_file"); if (rc) return rc;
+    if (!path || !n_clusters || !max_len) return fail(LIME_ERR_ARG, "lime_detect_to_file: NULL argument");
+    *n_clusters = 0; *max_len = 0;
+    if (n && (!lcp || !da)) return fail(LIME_ERR_ARG, "lime_detect_to_file: NULL array");
+    const int fd = open(path, O_WRONLY | O_CREAT | O_TRUNC, 0644);
+    if (fd < 0) return fail(LIME_ERR_IO, "lime_detect_to_file: cannot create %s", path);
+    if (!n) { close(fd); return LIME_OK; }
+    const uint64_t chunk0 = detect_chunk(lcp, da, n);
+    const size_t buf_records = (size_t)((chunk0 < n ? chunk0 : n) / 2 + 4096);      // a chunk has at most half as many clusters as positions
+    void *pin[2] = {nullptr, nullptr};
+    struct Job { int b; uint64_t cnt, at; };
+    std::mutex mu; std::condition_variable cv;
+    std::vector<Job> jobs; size_t taken = 0, written = 0; bool stop = false, io_failed = false;
+    uint64_t have = 0, ml = 0;
+    std::thread writer;
+    auto finish = [&]() {
+        { std::lock_guard<std::mutex> g(mu); stop = true; }
+        cv.notify_all();
+        if (writer.joinable()) writer.join();
+        for (int b = 0; b < 2; ++b) if (pin[b]) (void)hipHostFree(pin[b]);
+        close(fd);
+    };
+    if (hipHostMalloc(&pin[0], buf_records * sizeof(lime_cluster_t), hipHostMallocDefault) != hipSuccess ||
+        hipHostMalloc(&pin[1], buf_records * sizeof(lime_cluster_t), hipHostMallocDefault) != hipSuccess) {
+        (void)hipGetLastError(); finish();
+        return fail(LIME_ERR_NOMEM, "lime_detect_to_file: no pinned memory for the record buffers");
+    }
+    writer = std::thread([&]() {
+        for (;;) {
+            Job j;
+            {
+                std::unique_lock<std::mutex> lk(mu);
+                cv.wait(lk, [&] { return stop || taken < jobs.size(); });
+                if (taken >= jobs.size()) return;
+                j = jobs[taken++];
+            }
+            size_t done = 0; const size_t len = (size_t)j.cnt * sizeof(lime_cluster_t);
+            while (done < len) {
+                const ssize_t k = pwrite(fd, (const char *)pin[j.b] + done, len - done, (off_t)(j.at * sizeof(lime_cluster_t) + done));
+                if (k <= 0) { if (k < 0 && errno == EINTR) continue; std::lock_guard<std::mutex> g(mu); io_failed = true; break; }
+                done += (size_t)k;
+            }
+            { std::lock_guard<std::mutex> g(mu); ++written; }
+            cv.notify_all();
+        }
+    });
+    uint64_t n_jobs = 0;
+    auto sink = [&](const lime_cluster_t *dc, uint64_t cnt, hipStream_t st) -> int {
+        if (cnt > buf_records) return fail(LIME_ERR_HIP, "internal: %llu records in one chunk", (unsigned long long)cnt);
+        const int b = (int)(n_jobs & 1);
+        {   // the buffer's previous content (two jobs ago) must be in the file
+            std::unique_lock<std::mutex> lk(mu);
+            cv.wait(lk, [&] { return n_jobs < 2 || written + 2 > n_jobs || io_failed; });
+            if (io_failed) return fail(LIME_ERR_IO, "lime_detect_to_file: write to %s failed", path);
+        }
+        HIP_TRY(hipMemcpyAsync(pin[b], dc, (size_t)cnt * sizeof(lime_cluster_t), hipMemcpyDeviceToHost, st));
+        HIP_TRY(hipStreamSynchronize(st));
+        { std::lock_guard<std::mutex> g(mu); jobs.push_back(Job{b, cnt, have}); }
+        cv.notify_all();
+        have += cnt; ++n_jobs;
+        return LIME_OK;
+    };
+    rc = detect_walk(c, lcp, da, n, n_reads, alpha, chunk0, &ml, sink);
+    {   // everything handed over is in the file
+        std::unique_lock<std::mutex> lk(mu);
+        cv.wait(lk, [&] { return written == jobs.size() || io_failed; });
+    }
+    const bool bad_io = io_failed;
+    finish();
+    if (!rc && bad_io) rc = fail(LIME_ERR_IO, "lime_detect_to_file: write to %s failed", path);
+    if (rc == LIME_ERR_HALO && chunk0 < n) {
+        // (a run longer than the halo across a chunk border: the whole collection as one chunk, through memory)
+        lime_cluster_t *h = nullptr;
+        if ((rc = lime_detect(c, lcp, da, n, n_reads, alpha, &h, &have, &ml))) return rc;
+        rc = lime_write_clrs(path, h, have);
+        free(h);
+        if (rc) return fail(LIME_ERR_IO, "lime_detect_to_file: write to %s failed", path);
+    }
+    if (rc) return rc;
+    *n_clusters = have; *max_len = ml;
     return LIME_OK;
 }
 

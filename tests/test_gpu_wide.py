@@ -74,7 +74,7 @@ def test_tables_of_several_sub_regions_vs_oracle(monkeypatch, nr, ng, ebwt_on, m
     records (round 5; rounds 3-4: the wave's whole share each) -- clustered generator, 2*10^7 symbols, against the oracle's table (compared on
     the device).  The density comes from the probe; no pass may be repeated and none may fall back."""
     import torch
-    c = _ctx(monkeypatch, LIME_UPDATE_PATH="bin")
+    c = _ctx(monkeypatch, LIME_UPDATE_PATH="bin", LIME_PROBE_MIN=1 << 24)      # (the probe in front of first passes of 2^28 symbols and more by default)
     try:
         n = 20_000_000
         lcp, da, eb = O.synth(4100 + ng, 0, n, nr, ng, 16, mode)
@@ -114,11 +114,13 @@ def test_tables_of_several_sub_regions_vs_oracle(monkeypatch, nr, ng, ebwt_on, m
     (40_000_000, 100_000, 500, True, 1),      # clustered: several times that
     (30_000_000, 400_000, 2000, False, 0),    # 800 MB table, EBWT=0
 ])
-def test_density_probe_lands_the_first_pass(n, nr, ng, ebwt_on, mode):
+def test_density_probe_lands_the_first_pass(monkeypatch, n, nr, ng, ebwt_on, mode):
     """A fresh context's first pass (LiME_paired.sh:62-68 runs every collection once): the sampled probe's density is within a few % of
-    what the pass then counts, the pass is not repeated, and its table is the oracle's."""
+    what the pass then counts, the pass is not repeated, and its table is the oracle's.  (LIME_PROBE_MIN: by default only first passes of
+    2^28 symbols and more are probed -- too long for the oracle; the shorter ones go binned with a pool for 0.45 records per symbol.)"""
     import torch
     import lime_amd
+    monkeypatch.setenv("LIME_PROBE_MIN", str(1 << 24))
     lcp, da, eb = O.synth(5150 + mode, 0, n, nr, ng, 16, mode)
     e = eb if ebwt_on else None
     cl, nc, ml = O.detect(lcp, da, nr, 16)
@@ -151,6 +153,7 @@ def test_density_probe_lands_the_first_pass(n, nr, ng, ebwt_on, mode):
 def test_probe_then_shards_and_streams_are_unchanged(monkeypatch):
     """the probe runs in front of whole passes only: shards of a stream (keep_stats) and passes that add to a table never see it"""
     import lime_amd
+    monkeypatch.setenv("LIME_PROBE_MIN", str(1 << 24))
     c = lime_amd.Context()
     try:
         n, nr, ng = 18_000_000, 50_000, 400
@@ -250,5 +253,29 @@ def test_bins_of_257_to_511_tiles(monkeypatch, n, wide):
         s, rc = c.stats()
         assert rc == 0 and 256 * 8192 < s.n_updates < 512 * 8192, int(s.n_updates)
         assert (gnc, gml) == (nc, ml) and np.array_equal(sim, exp), int((sim != exp).sum())
+    finally:
+        c.close()
+
+
+@pytest.mark.parametrize("mode,ebwt_on", [(0, True), (1, True), (1, False)])
+def test_first_pass_without_probe_is_binned_and_right(mode, ebwt_on):
+    """first passes below 2^28 symbols run without the probe: binned, a pool for 0.45 records per symbol -- no repeat at the generators' 0.03 .. 0.23 --,
+    and later passes choose their path from the density the first one counted"""
+    import lime_amd
+    n, nr, ng = 20_000_000, 100_000, 500
+    lcp, da, eb = O.synth(61 + mode, 0, n, nr, ng, 16, mode)
+    e = eb if ebwt_on else None
+    cl, nc, ml = O.detect(lcp, da, nr, 16)
+    exp = O.score(da, e, cl, nr, ng, threads=8)
+    c = lime_amd.Context()
+    try:
+        for k in range(2):
+            sim, gnc, gml = c.fused(lcp, da, e, nr, ng, 16)
+            s, rc = c.stats()
+            assert rc == 0 and (gnc, gml) == (nc, ml) and np.array_equal(sim, exp)
+            if k == 0:
+                assert s.wave_records_max > 0, "an unmeasured first pass takes the binned path"
+        ht = c.host_times()
+        assert ht["probes"] == 0 and ht["repeats"] == 0 and ht["cas_fallbacks"] == 0, ht
     finally:
         c.close()
