@@ -232,6 +232,15 @@ int lime_choose_pairs_dev(lime_ctx *ctx, const uint8_t *d_sim, uint32_t n_reads,
                           uint32_t norm, float beta, uint8_t *row_max, uint64_t *row_off,
                           lime_pair_t **pairs, uint64_t *n_pairs, void *stream);
 
+/* ClusterLCP scan + clusterAnalyze + clusterChoose (ClusterLCP.cpp:140-283, ClusterBWT_DA.cpp:256-358, :385-423) on device-resident arrays of the
+ * whole collection, outputs as lime_choose_pairs_dev.  Where the binned update path serves the pass (tables beyond 64 MB, n_refs >= 256) the
+ * table is never written or read: its 64 KB regions are built in LDS and give the rows' maxima / non-zero counts, then the passing rows' lists.
+ * Elsewhere the table is built and scanned.  *stats (may be NULL) as lime_get_stats.  Synchronises `stream`. */
+int lime_fused_choose_dev(lime_ctx *ctx, const uint32_t *d_lcp, const uint32_t *d_da, const uint8_t *d_ebwt, uint64_t n,
+                          uint32_t n_reads, uint32_t n_refs, uint32_t alpha, uint32_t norm, float beta,
+                          uint8_t *row_max, uint64_t *row_off, lime_pair_t **pairs, uint64_t *n_pairs,
+                          lime_stats_t *stats, void *stream);
+
 /* Synthetic inputs of SURVEY.md section 8(d): element i is a pure function of (seed, i0+i).
  * Any of the three outputs may be NULL.  mode 0 = iid, 1 = block-correlated symbols. */
 int lime_synth_dev(lime_ctx *ctx, uint64_t seed, uint64_t i0, uint64_t count,

@@ -78,6 +78,7 @@ SYMBOLS = {
     "lime_classify_error": (C.c_char_p, []),
     "lime_fused_stream": (_i, [_vp, _vp, _vp, _vp, _u64, _u32, _u32, _u32, _u64, _vp, _pu64, _pu64]),
     "lime_choose_pairs_dev": (_i, [_vp, _vp, _u32, _u32, _u32, C.c_float, _vp, _vp, _pp, _pu64, _vp]),
+    "lime_fused_choose_dev": (_i, [_vp, _vp, _vp, _vp, _u64, _u32, _u32, _u32, _u32, C.c_float, _vp, _vp, _pp, _pu64, C.POINTER(Stats), _vp]),
     "lime_score_choose": (_i, [_vp, _vp, _vp, _u64, _vp, _u64, _u32, _u32, _u32, C.c_float, _vp, _vp, _pp, _pu64, _vp]),
     "lime_combine_edges": (_i, [_vp, _u32]),
     "lime_comm_unique_id": (_i, [_vp]),

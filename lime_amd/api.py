@@ -131,6 +131,16 @@ class Context:
                                              off.ctypes.data, C.byref(pp), C.byref(npairs), stream))
         return mx[:n_reads], off[:n_reads + 1], self._pairs_out(pp, npairs)
 
+    def fused_choose_dev(self, lcp_t, da_t, ebwt_t, n, n_reads, n_refs, alpha, norm, beta, stream=None):
+        """scan + clusterAnalyze + clusterChoose on device-resident arrays, without the table where the binned path serves the pass
+        -> (row_max, row_off, pairs, Stats)"""
+        mx = np.zeros(n_reads + 1, dtype=np.uint8)
+        off = np.zeros(n_reads + 2, dtype=np.uint64)
+        pp, npairs, s = C.c_void_p(), C.c_uint64(0), Stats()
+        check(self.lib.lime_fused_choose_dev(self.h, _ptr(lcp_t), _ptr(da_t), _ptr(ebwt_t), n, n_reads, n_refs, alpha, norm, beta,
+                                             mx.ctypes.data, off.ctypes.data, C.byref(pp), C.byref(npairs), C.byref(s), stream))
+        return mx[:n_reads], off[:n_reads + 1], self._pairs_out(pp, npairs), s
+
     # ---- array level, device pointers (torch tensors on this ctx's device) ---------------
     def stats(self, stream=None):
         s = Stats()

@@ -27,7 +27,6 @@
 using namespace lime;
 
 static thread_local std::string g_err;
-static uint64_t PROBE_MIN = 1ull << 28;     // first passes of fewer symbols run without the density probe (binned, pool for 0.45 records per symbol); LIME_PROBE_MIN: tests
 
 static int fail(int code, const char *fmt, ...)
 {
@@ -91,6 +90,7 @@ struct lime_ctx {
     int scan_static_pct = -1;               // share (%) of the scan's rounds of window chunks that go round-robin, the rest is handed out as workgroups get there; -1: by the input's length (base_args); LIME_SCAN_STATIC_PCT: tests, comparison runs
     uint32_t part_split = 2;                // producers (of k_part) per scan workgroup at most (LIME_PART_SPLIT: comparison runs): two = one partition workgroup per resident slot of the device; four -- round 4's first choice -- cut the streams into more, less filled tiles: k_part_lines +4 % at N = 1e10 and on the text workload
     uint32_t pool_slack = 512;              // + this many records per wave and sub-region (LIME_POOL_SLACK: tests make pools overflow)
+    uint64_t probe_min = 1ull << 28;        // first passes of fewer symbols run without the density probe (binned, pool for 0.45 records per symbol); LIME_PROBE_MIN: tests
     bool probe = true;                      // LIME_NO_PROBE: no sampled density probe in front of a ctx's first pass (tests, comparison runs)
     bool force_p64 = false;                 // LIME_FORCE_P64: the partition kernels' 64-bit-position variants on any pass (tests)
     uint64_t p64_test_base = 0;             // LIME_P64_TEST_BASE (tests): the binned records' positions start at this number instead of 0 -- the bin bases are
@@ -175,7 +175,7 @@ extern "C" int lime_init(int device, lime_ctx **out)
     if (const char *s = getenv("LIME_PART_SPLIT")) { const long v = atol(s); if (v >= 1 && v <= 16) c->part_split = (uint32_t)v; }
     if (const char *s = getenv("LIME_POOL_SLACK")) { const long v = atol(s); if (v >= 0) c->pool_slack = (uint32_t)v; }
     if (const char *s = getenv("LIME_NO_PROBE")) c->probe = atoi(s) == 0;
-    if (const char *s = getenv("LIME_PROBE_MIN")) { const unsigned long long v = strtoull(s, nullptr, 0); PROBE_MIN = v < (1ull << 24) ? (1ull << 24) : v; }
+    if (const char *s = getenv("LIME_PROBE_MIN")) { const unsigned long long v = strtoull(s, nullptr, 0); c->probe_min = v < (1ull << 24) ? (1ull << 24) : v; }
     if (const char *s = getenv("LIME_FORCE_P64")) c->force_p64 = atoi(s) != 0;
     if (const char *s = getenv("LIME_P64_TEST_BASE")) { c->p64_test_base = strtoull(s, nullptr, 0) & ~15ull; if (c->p64_test_base) c->force_p64 = true; }
     if (const char *s = getenv("LIME_MAX_BLOCKS")) { long v = atol(s); if (v > 0) c->max_blocks = (uint32_t)v; }
@@ -555,7 +555,7 @@ static int fused_dev_impl(lime_ctx *c, const uint32_t *d_lcp, const uint32_t *d_
     // was repeated or ran on the other path).  LiME_paired.sh:62-68 runs every collection ONCE, so the density is sampled first: the
     // scan kernel itself over every 2^k-th chunk of 16 windows, counting its update records without storing one (density_probe).
     if (n_avail && !no_bin && !keep_stats && zero_sim && bin_fits && c->probe && !c->density_known && !c->pool_density_fixed && !c->ablate &&
-        c->upd_pref != 0 && n_own >= PROBE_MIN && sim_bytes >= (1u << 20) && n_tiles < 0x7FF00000u)
+        c->upd_pref != 0 && n_own >= c->probe_min && sim_bytes >= (1u << 20) && n_tiles < 0x7FF00000u)
         if ((rc = density_probe(c, d_lcp, d_da, d_ebwt, n_own, n_avail, eof, n_reads, n_refs, alpha, sim_bytes, st))) return rc;
     bool binned = n_avail && !no_bin && want_binned(c, n_own, sim_bytes, zero_sim, keep_stats, ebwt);
     if (records_only) binned = true;                      // the records ARE the result: the binned path or nothing
@@ -1742,6 +1742,97 @@ extern "C" int lime_choose_pairs_dev(lime_ctx *c, const uint8_t *d_sim, uint32_t
     HIP_TRY(hipGetLastError());
     lime_pair_t *h = (lime_pair_t *)malloc((size_t)total * sizeof(lime_pair_t));
     if (!h) return fail(LIME_ERR_NOMEM, "lime_choose_pairs_dev: out of host memory");
+    hipError_t e = hipMemcpyAsync(h, dp.p, (size_t)total * sizeof(lime_pair_t), hipMemcpyDeviceToHost, st);
+    if (e == hipSuccess) e = hipStreamSynchronize(st);
+    if (e != hipSuccess) { free(h); return fail(LIME_ERR_HIP, "hipMemcpy: %s", hipGetErrorString(e)); }
+    *pairs = h;
+    return LIME_OK;
+}
+
+// ClusterLCP scan + clusterAnalyze + clusterChoose on device-resident arrays in one call.  Where the binned update path serves the pass with its
+// second level by tiles (tables beyond 64 MB) the TABLE IS NEVER WRITTEN: the pass stops at the binned records (the long clusters' updates as
+// records of their own, bucketed by region), k_sort_tiles sorts them into tile rows once, and k_apply_tiles builds every 64 KB region in LDS
+// twice -- first for the rows' maxima and non-zero counts (clusterChoose's row scan, ClusterBWT_DA.cpp:385-402), then, after the host's test
+// `float(max) / norm > beta` (:404-406), for the passing rows' (idRef, sim) lists (:408-423; regions without a passing row are skipped).  Against
+// table + k_choose + k_gather_pairs that saves writing T bytes and reading them once or twice.  Elsewhere (small tables, short passes, n_refs < 256):
+// the table is built and scanned as before.  Outputs as lime_choose_pairs_dev; *stats (may be NULL) as lime_get_stats.
+extern "C" int lime_fused_choose_dev(lime_ctx *c, const uint32_t *d_lcp, const uint32_t *d_da, const uint8_t *d_ebwt, uint64_t n,
+                                     uint32_t n_reads, uint32_t n_refs, uint32_t alpha, uint32_t norm, float beta,
+                                     uint8_t *row_max, uint64_t *row_off, lime_pair_t **pairs, uint64_t *n_pairs,
+                                     lime_stats_t *stats, void *stream)
+{
+    int rc = check_ctx(c, "lime_fused_choose_dev"); if (rc) return rc;
+    if (!pairs || !n_pairs || !row_off || !row_max) return fail(LIME_ERR_ARG, "lime_fused_choose_dev: NULL output");
+    if (!n_reads || !n_refs) return fail(LIME_ERR_ARG, "lime_fused_choose_dev: n_reads and n_refs must be > 0");
+    *pairs = nullptr; *n_pairs = 0; row_off[0] = 0;
+    hipStream_t st = (hipStream_t)stream;
+    const size_t sim_bytes = lime_sim_bytes(n_reads, n_refs);
+    const bool bin_fits = !(sim_bytes > ((size_t)BIN_MAX << BIN_SHIFT_MAX) || sim_bytes >= (1ull << CELL_BITS) || sim_bytes > ((uint64_t)MAX_SUB << 32));
+    uint32_t n_bins = 0, bin_shift = REGION_SHIFT;
+    if (bin_fits) bin_layout(c, sim_bytes, &n_bins, &bin_shift);
+    const char *force = getenv("LIME_CHOOSE_FREE");              // tests: 1 = without the table wherever the layout has a second level, 0 = never
+    bool table_free = bin_fits && c->by_tiles && bin_shift > REGION_SHIFT && n && c->upd_pref != 0 && n_refs < MAX_REFS &&
+                      (force ? atoi(force) != 0 : (n_refs >= 256u && n >= (1u << 24)));
+    lime_stats_t s;
+    memset(&s, 0, sizeof s);
+    if (!table_free) {
+        DevBuf ds;
+        if ((rc = ds.alloc(sim_bytes))) return rc;
+        if ((rc = lime_fused_dev(c, d_lcp, d_da, d_ebwt, n, n, 1, n_reads, n_refs, alpha, (uint8_t *)ds.p, 1, stream))) return rc;
+        rc = lime_get_stats(c, &s, stream);
+        if (stats) *stats = s;
+        if (rc) return rc;
+        return lime_choose_pairs_dev(c, (const uint8_t *)ds.p, n_reads, n_refs, norm, beta, row_max, row_off, pairs, n_pairs, stream);
+    }
+    if ((rc = fused_dev_impl(c, d_lcp, d_da, d_ebwt, n, n, 1, n_reads, n_refs, alpha, nullptr, 1, false, st, nullptr, false, true))) return rc;
+    rc = lime_get_stats(c, &s, stream);                          // (waits; repeats the pass if the record pool or the long clusters' list was too small)
+    if (stats) *stats = s;
+    if (rc) return rc;
+    uint32_t nb = 0;
+    HIP_TRY(hipMemcpyAsync(&nb, c->d_bigrec_n, sizeof nb, hipMemcpyDeviceToHost, st));
+    HIP_TRY(hipStreamSynchronize(st));
+    if (nb > c->bigrec_cap) return fail(LIME_ERR_NOMEM, "more update records of long clusters (%u) than their list holds (%u)", nb, c->bigrec_cap);
+    const uint32_t n_regions = (uint32_t)((sim_bytes + ((size_t)1 << REGION_SHIFT) - 1) >> REGION_SHIFT);
+    DevBuf dmax, dnnz, dlast, bcnt, bcur, boff, bout, doff, dp;
+    if ((rc = dmax.alloc((size_t)n_reads * 4)) || (rc = dnnz.alloc((size_t)n_reads * 4)) || (rc = dlast.alloc((size_t)n_regions * 4))) return rc;
+    HIP_TRY(hipMemsetAsync(dmax.p, 0, (size_t)n_reads * 4, st));
+    HIP_TRY(hipMemsetAsync(dnnz.p, 0, (size_t)n_reads * 4, st));
+    ApplyFin fin;
+    memset(&fin, 0, sizeof fin);
+    fin.n_refs = n_refs; fin.table_bytes = (uint64_t)n_reads * n_refs;
+    fin.row_max = (uint32_t *)dmax.p; fin.row_nnz = (uint32_t *)dnnz.p; fin.last_nnz = (uint32_t *)dlast.p;
+    if (nb) {
+        if ((rc = bcnt.alloc((size_t)n_regions * 4)) || (rc = bcur.alloc((size_t)n_regions * 4)) || (rc = boff.alloc(((size_t)n_regions + 1) * 8)) ||
+            (rc = bout.alloc((size_t)nb * 8))) return rc;
+        launch_bigrec_buckets(c->d_bigrec, nb, n_regions, (uint32_t *)bcnt.p, (uint32_t *)bcur.p, (uint64_t *)boff.p, (uint64_t *)bout.p, st);
+        fin.big_off = (const uint64_t *)boff.p; fin.bigrecs = (const uint64_t *)bout.p;
+    }
+    const double expect = (double)s.n_updates;
+    uint16_t *rows = reinterpret_cast<uint16_t *>(c->d_pool);
+    launch_sort_tiles(c->d_recs, c->d_binbase, n_bins, bin_shift, c->d_tbase, c->d_tidx, rows, st, expect >= 1e8);
+    launch_apply_tiles_fin(1, sim_bytes, bin_shift, c->d_tbase, c->d_tidx, rows, expect >= 2e8, fin, st);
+    HIP_TRY(hipGetLastError());
+    std::vector<uint32_t> hm(n_reads), hz(n_reads);
+    HIP_TRY(hipMemcpyAsync(hm.data(), dmax.p, (size_t)n_reads * 4, hipMemcpyDeviceToHost, st));
+    HIP_TRY(hipMemcpyAsync(hz.data(), dnnz.p, (size_t)n_reads * 4, hipMemcpyDeviceToHost, st));
+    HIP_TRY(hipStreamSynchronize(st));
+    uint64_t total = 0;
+    for (uint32_t r = 0; r < n_reads; ++r) {                     // the reference's test, in the reference's types (ClusterBWT_DA.cpp:404-406)
+        row_max[r] = (uint8_t)hm[r];
+        const float top = static_cast<float>(row_max[r]) / norm;
+        row_off[r] = total;
+        if (top > beta) total += hz[r];
+    }
+    row_off[n_reads] = total;
+    *n_pairs = total;
+    if (!total) return LIME_OK;
+    if ((rc = doff.upload(row_off, ((size_t)n_reads + 1) * 8))) return rc;
+    if ((rc = dp.alloc((size_t)total * sizeof(lime_pair_t)))) return rc;
+    fin.row_off = (const uint64_t *)doff.p; fin.pairs = (lime_pair_t *)dp.p;
+    launch_apply_tiles_fin(2, sim_bytes, bin_shift, c->d_tbase, c->d_tidx, rows, expect >= 2e8, fin, st);
+    HIP_TRY(hipGetLastError());
+    lime_pair_t *h = (lime_pair_t *)malloc((size_t)total * sizeof(lime_pair_t));
+    if (!h) return fail(LIME_ERR_NOMEM, "lime_fused_choose_dev: out of host memory");
     hipError_t e = hipMemcpyAsync(h, dp.p, (size_t)total * sizeof(lime_pair_t), hipMemcpyDeviceToHost, st);
     if (e == hipSuccess) e = hipStreamSynchronize(st);
     if (e != hipSuccess) { free(h); return fail(LIME_ERR_HIP, "hipMemcpy: %s", hipGetErrorString(e)); }

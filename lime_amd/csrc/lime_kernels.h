@@ -106,6 +106,15 @@ struct ScanArgs {
     uint64_t *bigrec; uint32_t *bigrec_n; uint32_t bigrec_cap;   // sim == NULL (records for an owner-partitioned exchange): the long clusters' updates, cell | t << CELL_BITS
 };
 
+// what k_apply_tiles does with a finished region instead of writing it to the table (clusterChoose without the table: lime_fused_choose_dev)
+struct ApplyFin {
+    uint32_t n_refs; uint64_t table_bytes;          // n_reads * n_refs (no padding)
+    uint32_t *row_max, *row_nnz;                    // mode 1 out: a word per read, zeroed beforehand
+    uint32_t *last_nnz;                             // per region: the non-zero cells of its last row segment (mode 1 out, mode 2 in)
+    const uint64_t *row_off; lime_pair_t *pairs;    // mode 2: where the passing reads' (idRef, sim) lists go
+    const uint64_t *big_off; const uint64_t *bigrecs;   // the long clusters' update records bucketed by region (big_off: n_regions + 1), or NULL
+};
+
 void launch_tile(int ebwt, int mode, const ScanArgs &a, uint32_t max_blocks, hipStream_t st);
 uint32_t scan_grid(int ebwt, int mode, int binned, uint32_t n_tiles, uint32_t max_blocks, uint32_t probe_shift = 0);   // workgroups launch_tile will use
 // binned updates: after the scan (n_prod = its grid) -- per-bin prefix over the producers and bin totals,
@@ -118,6 +127,14 @@ void launch_apply(uint8_t *sim, size_t sim_bytes, const uint32_t *recs, const ui
 void launch_resolve(int mode, const ScanArgs &a, hipStream_t st);
 void launch_apply_by_tiles(uint8_t *sim, size_t sim_bytes, const uint32_t *recs, const uint64_t *binbase, uint32_t n_bins, uint32_t bin_shift,
                            uint32_t *tbase, uint16_t *idx, uint16_t *out16, bool many_records, hipStream_t st, bool big_rows = false);   // many_records: about 2e8 and more (a variant of k_apply_tiles); big_rows: about 1e8 records and more (the 16-bit rows written non-temporally)
+// the same in two steps, for clusterChoose without the table: the bins' records sorted into tile rows once (launch_sort_tiles), then
+// k_apply_tiles in mode 1 (row maxima / non-zero counts) and, after the host's pass test, mode 2 (the passing rows' pairs) on the same rows
+void launch_sort_tiles(const uint32_t *recs, const uint64_t *binbase, uint32_t n_bins, uint32_t bin_shift, uint32_t *tbase, uint16_t *idx, uint16_t *out16,
+                       hipStream_t st, bool big_rows);
+void launch_apply_tiles_fin(int mode, size_t sim_bytes, uint32_t bin_shift, const uint32_t *tbase, const uint16_t *idx, const uint16_t *out16, bool many_records,
+                            const ApplyFin &fin, hipStream_t st);
+// the long clusters' update records (cell | t << CELL_BITS) bucketed by 64 KB table region: cnt / cursor: n_regions words (zeroed here), off: n_regions + 1
+void launch_bigrec_buckets(const uint64_t *recs, uint32_t n, uint32_t n_regions, uint32_t *cnt, uint32_t *cursor, uint64_t *off, uint64_t *out, hipStream_t st);
 uint64_t tiles_bound(uint64_t n_records, uint32_t n_bins);
 uint32_t part_tile();
 uint32_t row_stride();

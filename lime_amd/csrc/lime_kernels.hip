@@ -18,6 +18,7 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include <stdlib.h>
+#include <string.h>
 #include <atomic>
 #include <type_traits>
 #include "lime_device.h"
@@ -2310,12 +2311,104 @@ __global__ __launch_bounds__(PART_WG) void k_sort_tiles(const uint32_t *recs, co
 // Wave w takes the tiles w, w + 8, ... of the bin (a lane reads one tile's two index entries), then their runs one after
 // the other, four 16-bit records per lane and step from 8-byte-aligned loads (and the 65th group of a run with them); the
 // loads of the next four runs are in flight while four are added.
-template <bool WIDE> __global__ __launch_bounds__(APPLY_WG) void k_apply_tiles(uint8_t *sim, size_t sim_bytes, const uint16_t *recs16, const uint32_t *tbase,
-                                                          const uint16_t *idx, uint32_t bin_shift, uint32_t n_regions)
+// MODE (round 5; clusterChoose without the table, ClusterBWT_DA.cpp:385-423): 0 -- the finished region is written to the table; 1 -- nothing is
+// written: the region's row segments give row maxima and non-zero counts (whole rows: plain stores; rows that cross a region border: atomic max /
+// add on the zeroed arrays) and the count of its last segment; 2 -- the regions are built once more and the rows that passed the host's test
+// (row_off[r + 1] > row_off[r]) leave their non-zero cells as (idRef, sim) pairs in ascending idRef at pairs[row_off[r] ..] (regions without a passing
+// row are skipped before a record is read).  Both need n_refs >= 256 (at most 257 row segments per 64 KB region, a wave each).
+// bytes wb .. wb + 3 of a word that lie in [s, e)
+__device__ __forceinline__ uint32_t keep_bytes(uint32_t x, uint32_t wb, uint32_t s, uint32_t e)
+{
+    uint32_t m = 0xFFFFFFFFu;
+    if (wb < s) { const uint32_t d = s - wb; m = d >= 4u ? 0u : m << (8u * d); }
+    if (wb + 4u > e) { const uint32_t d = e > wb ? e - wb : 0u; m &= d >= 4u ? 0xFFFFFFFFu : ((1u << (8u * d)) - 1u); }
+    return x & m;
+}
+__device__ __forceinline__ uint32_t nz_bytes(uint32_t x) { return (((x & 0x7F7F7F7Fu) + 0x7F7F7F7Fu) | x) & 0x80808080u; }   // bit 7 of every non-zero byte
+
+template <int MODE>
+__device__ __forceinline__ void fin_region(const uint4 *reg4, const ApplyFin &f, uint32_t region, uint64_t r0, uint32_t o0, uint32_t nseg, uint32_t len)
+{
+    constexpr uint32_t NWV = APPLY_WG / 64;
+    const uint32_t lane = lane_id(), wave = (uint32_t)__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    const uint64_t reg_base = (uint64_t)region << REGION_SHIFT;
+    for (uint32_t j = wave; j < nseg; j += NWV) {                 // a wave per row segment: row r0 + j, bytes [s, e) of the region
+        const uint64_t row = r0 + j;
+        const uint32_t s = j ? (uint32_t)((uint64_t)j * f.n_refs - o0) : 0u;
+        const uint64_t e64 = (uint64_t)(j + 1u) * f.n_refs - o0;
+        const uint32_t e = e64 < len ? (uint32_t)e64 : len;
+        if (MODE == 1) {
+            uint32_t mx = 0, nz = 0;
+            for (uint32_t c = (s >> 4) + lane; 16u * c < e; c += 64u) {
+                uint4 v = reg4[c];
+                if (16u * c < s || 16u * c + 16u > e) {
+                    v.x = keep_bytes(v.x, 16u * c, s, e); v.y = keep_bytes(v.y, 16u * c + 4u, s, e);
+                    v.z = keep_bytes(v.z, 16u * c + 8u, s, e); v.w = keep_bytes(v.w, 16u * c + 12u, s, e);
+                }
+                if (v.x | v.y | v.z | v.w) {
+                    const uint32_t w[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+                    for (uint32_t i = 0; i < 4; ++i) {
+                        const uint32_t a0 = w[i] & 255u, a1 = (w[i] >> 8) & 255u, a2 = (w[i] >> 16) & 255u, a3 = w[i] >> 24;
+                        const uint32_t m01 = a0 > a1 ? a0 : a1, m23 = a2 > a3 ? a2 : a3, m = m01 > m23 ? m01 : m23;
+                        mx = m > mx ? m : mx;
+                        nz += (uint32_t)__popc(nz_bytes(w[i]));
+                    }
+                }
+            }
+            mx = wave_max(mx); nz = wave_sum(nz);
+            if (lane == 0) {
+                const bool whole = (j != 0u || o0 == 0u) && e64 <= len;
+                if (whole) { f.row_max[row] = mx; f.row_nnz[row] = nz; }
+                else { if (mx) atomicMax(&f.row_max[row], mx); if (nz) atomicAdd(&f.row_nnz[row], nz); }
+                if (j == nseg - 1u) f.last_nnz[region] = nz;
+            }
+        } else {
+            const uint64_t p0 = f.row_off[row], p1 = f.row_off[row + 1u];
+            if (p1 == p0) continue;                                // the read did not pass (wave-uniform)
+            uint64_t run = p0;
+            if (j == 0u && o0 != 0u) {                             // the row began in an earlier region: its cells there come first
+                const uint32_t k0 = (uint32_t)((row * f.n_refs) >> REGION_SHIFT);
+                for (uint32_t kk = k0; kk < region; ++kk) run += f.last_nnz[kk];
+            }
+            const uint32_t id0 = (uint32_t)(reg_base - row * f.n_refs);      // idRef of the region's byte 0 in this row (wraps for j > 0: added back below)
+            for (uint32_t c0 = s >> 4; 16u * c0 < e; c0 += 64u) {
+                const uint32_t c = c0 + lane;
+                uint4 v = make_uint4(0u, 0u, 0u, 0u);
+                if (16u * c < e) {
+                    v = reg4[c];
+                    if (16u * c < s || 16u * c + 16u > e) {
+                        v.x = keep_bytes(v.x, 16u * c, s, e); v.y = keep_bytes(v.y, 16u * c + 4u, s, e);
+                        v.z = keep_bytes(v.z, 16u * c + 8u, s, e); v.w = keep_bytes(v.w, 16u * c + 12u, s, e);
+                    }
+                }
+                const uint32_t w[4] = {v.x, v.y, v.z, v.w};
+                const uint32_t cnt = (uint32_t)(__popc(nz_bytes(w[0])) + __popc(nz_bytes(w[1])) + __popc(nz_bytes(w[2])) + __popc(nz_bytes(w[3])));
+                if (!__ballot(cnt != 0u)) continue;
+                const uint32_t incl = wave_incl_scan(cnt);
+                uint64_t at = run + (incl - cnt);
+                if (cnt) {
+#pragma unroll
+                    for (uint32_t i = 0; i < 4; ++i)
+#pragma unroll
+                        for (uint32_t b = 0; b < 4; ++b) {
+                            const uint32_t val = (w[i] >> (8u * b)) & 255u;
+                            if (val) { lime_pair_t pr; pr.id_ref = id0 + 16u * c + 4u * i + b; pr.sim = val; f.pairs[at++] = pr; }
+                        }
+                }
+                run += rl32(incl, 63);
+            }
+        }
+    }
+}
+
+template <bool WIDE, int MODE> __global__ __launch_bounds__(APPLY_WG) void k_apply_tiles(uint8_t *sim, size_t sim_bytes, const uint16_t *recs16, const uint32_t *tbase,
+                                                          const uint16_t *idx, uint32_t bin_shift, uint32_t n_regions, ApplyFin fin)
 {
     constexpr uint32_t RW = (1u << REGION_SHIFT) / 4u;           // words per region
     constexpr uint32_t NWV = APPLY_WG / 64, UR = 4;
     __shared__ uint4 reg4[RW / 4];
+    __shared__ uint32_t fin_s[6];                                // MODE 1, 2: the region's first row (two words), offset of the region in it, row segments, bytes, skip
     uint32_t *reg = reinterpret_cast<uint32_t *>(reg4);
     const uint32_t lane = lane_id(), wave = (uint32_t)__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));   // wave-uniform: the runs' borders and sources stay scalar
     const uint32_t f2 = 1u << (bin_shift - REGION_SHIFT);
@@ -2325,12 +2418,12 @@ template <bool WIDE> __global__ __launch_bounds__(APPLY_WG) void k_apply_tiles(u
     // there: a cell's sum is bounded by the read length; the wrap-around fixtures and the iid generator at few reads do).
     __shared__ uint32_t ovf_s;
     bool exact = false;
-    auto add_exact = [&](uint32_t o) {
+    auto add_exact = [&](uint32_t o, uint32_t t = 1u) {
         const uint32_t sh = (o & 3u) * 8u;
         uint32_t *w = &reg[o >> 2];
         uint32_t seen = *w;
         for (;;) {
-            const uint32_t b = ((seen >> sh) + 1u) & 255u;
+            const uint32_t b = ((seen >> sh) + t) & 255u;
             const uint32_t old = atomicCAS(w, seen, (seen & ~(255u << sh)) | (b << sh));
             if (old == seen) break;
             seen = old;
@@ -2420,6 +2513,20 @@ template <bool WIDE> __global__ __launch_bounds__(APPLY_WG) void k_apply_tiles(u
         const bool more = next < n_regions;
         uint32_t nrow0 = 0, nrow1 = 0;                            // the next region's tile range: needed only after this one's records
         if (more) { nrow0 = tbase[next >> bsh]; nrow1 = tbase[(next >> bsh) + 1u]; }
+        bool skip = false;
+        if (MODE != 0) {                                          // the region's rows (one thread divides); MODE 2: anything to gather here?
+            if (threadIdx.x == 0) {
+                const uint64_t rb = (uint64_t)region << REGION_SHIFT;
+                const uint32_t len = fin.table_bytes - rb < (1ull << REGION_SHIFT) ? (uint32_t)(fin.table_bytes - rb) : (1u << REGION_SHIFT);
+                const uint64_t r0 = rb / fin.n_refs, r1 = (rb + len - 1u) / fin.n_refs;
+                fin_s[0] = (uint32_t)r0; fin_s[1] = (uint32_t)(r0 >> 32); fin_s[2] = (uint32_t)(rb - r0 * fin.n_refs);
+                fin_s[3] = (uint32_t)(r1 - r0) + 1u; fin_s[4] = len;
+                fin_s[5] = MODE == 2 && fin.row_off[r1 + 1u] == fin.row_off[r0] ? 1u : 0u;
+            }
+            __syncthreads();
+            skip = fin_s[5] != 0u;
+        }
+        if (!skip)
         for (exact = false;; exact = true) {                      // once; twice if a cell passed 255 under the fast adds
         for (uint32_t i = threadIdx.x; i < RW / 4; i += APPLY_WG) reg4[i] = make_uint4(0u, 0u, 0u, 0u);
         __syncthreads();
@@ -2471,9 +2578,20 @@ template <bool WIDE> __global__ __launch_bounds__(APPLY_WG) void k_apply_tiles(u
         __syncthreads();                                          // (everybody has seen the flag)
         if (threadIdx.x == 0) ovf_s = 0u;
         }
+        if (MODE != 0 && !skip && fin.big_off) {                  // the long clusters' updates of this region (bucketed by region: k_bigrec_*), exact
+            const uint64_t lo = fin.big_off[region], hi = fin.big_off[region + 1u];
+            for (uint64_t i = lo + threadIdx.x; i < hi; i += APPLY_WG) {
+                const uint64_t r = fin.bigrecs[i];
+                add_exact((uint32_t)r & ((1u << REGION_SHIFT) - 1u), (uint32_t)(r >> CELL_BITS));
+            }
+            __syncthreads();
+        }
         // the next region's index entries go out now and land while this region is written
         uint32_t na = 0, ne = 0;
         if (more) index_of(next, nrow0, nrow1 - nrow0, 0u, na, ne);
+        if (MODE != 0) {
+            if (!skip) fin_region<MODE>(reg4, fin, region, (uint64_t)fin_s[0] | ((uint64_t)fin_s[1] << 32), fin_s[2], fin_s[3], fin_s[4]);
+        } else {
         const size_t reg_base = (size_t)region << REGION_SHIFT;  // regions start inside the table
         uint4 *dst = reinterpret_cast<uint4 *>(sim + reg_base);
         const size_t left16 = (sim_bytes - reg_base) / 16u;      // sim_bytes is a multiple of 16
@@ -2495,6 +2613,7 @@ template <bool WIDE> __global__ __launch_bounds__(APPLY_WG) void k_apply_tiles(u
 #undef LIME_ST
         } else {                                                  // the table's last region, cut short (it is its workgroup's last one)
             for (uint32_t i = threadIdx.x; i < left16; i += APPLY_WG) dst[i] = reg4[i];
+        }
         }
         AP(6)
         if (!more) break;
@@ -2990,27 +3109,79 @@ void launch_apply(uint8_t *sim, size_t sim_bytes, const uint32_t *recs, const ui
 
 // second level by tiles (k_sort_tiles + k_apply_tiles).  tbase: n_bins + 1 words; idx: (tiles + n_bins) * (f2 + 1) 16-bit entries;
 // out16: PART_TILE 16-bit records per tile row (tiles_bound() rows at most)
-void launch_apply_by_tiles(uint8_t *sim, size_t sim_bytes, const uint32_t *recs, const uint64_t *binbase, uint32_t n_bins, uint32_t bin_shift,
-                           uint32_t *tbase, uint16_t *idx, uint16_t *out16, bool many_records, hipStream_t st, bool big_rows)
+void launch_sort_tiles(const uint32_t *recs, const uint64_t *binbase, uint32_t n_bins, uint32_t bin_shift, uint32_t *tbase, uint16_t *idx, uint16_t *out16,
+                       hipStream_t st, bool big_rows)
 {
     if (const char *e = getenv("LIME_SORT_NT")) big_rows = atoi(e) != 0;                     // tests: either kind of row stores on any input
-
     hipLaunchKernelGGL(k_tile_bases, dim3(1), dim3(PART_WG), 0, st, binbase, n_bins, tbase);
     // enough workgroups to fill the device evenly: about 8 per CU (two are resident at a time)
     const uint32_t per_bin = n_bins >= 2048u ? 1u : (2048u + n_bins - 1u) / n_bins;
     hipLaunchKernelGGL(k_sort_tiles, dim3(n_bins, per_bin), dim3(PART_WG), 0, st, recs, binbase, bin_shift, tbase, idx, out16, big_rows ? 1u : 0u);
-    const uint32_t n_regions = (uint32_t)((sim_bytes + ((size_t)1 << REGION_SHIFT) - 1) >> REGION_SHIFT);
+}
+
+static uint32_t apply_tiles_grid(uint32_t n_regions)
+{
     static std::atomic<uint32_t> resident_of[MAX_DEV];           // workgroups that fit the device at once (two per CU: 64 KB of LDS each)
     std::atomic<uint32_t> &slot = resident_of[cur_device()];
     uint32_t resident = slot.load(std::memory_order_relaxed);
-    if (!resident) { resident = resident_blocks(k_apply_tiles<false>, APPLY_WG); slot.store(resident, std::memory_order_relaxed); }
+    if (!resident) { resident = resident_blocks(k_apply_tiles<false, 0>, APPLY_WG); slot.store(resident, std::memory_order_relaxed); }
     const uint32_t grid = n_regions < resident ? n_regions : resident;
+    return grid ? grid : 1u;
+}
+
+void launch_apply_tiles_fin(int mode, size_t sim_bytes, uint32_t bin_shift, const uint32_t *tbase, const uint16_t *idx, const uint16_t *out16, bool many_records,
+                            const ApplyFin &fin, hipStream_t st)
+{
+    const uint32_t n_regions = (uint32_t)((sim_bytes + ((size_t)1 << REGION_SHIFT) - 1) >> REGION_SHIFT);
+    const dim3 grid(apply_tiles_grid(n_regions)), wg(APPLY_WG);
+    if (const char *e = getenv("LIME_APPLY_WIDE")) many_records = atoi(e) != 0;            // tests: either variant on any input
+    if (mode == 1) {
+        if (many_records) hipLaunchKernelGGL((k_apply_tiles<true, 1>), grid, wg, 0, st, nullptr, sim_bytes, out16, tbase, idx, bin_shift, n_regions, fin);
+        else              hipLaunchKernelGGL((k_apply_tiles<false, 1>), grid, wg, 0, st, nullptr, sim_bytes, out16, tbase, idx, bin_shift, n_regions, fin);
+    } else {
+        if (many_records) hipLaunchKernelGGL((k_apply_tiles<true, 2>), grid, wg, 0, st, nullptr, sim_bytes, out16, tbase, idx, bin_shift, n_regions, fin);
+        else              hipLaunchKernelGGL((k_apply_tiles<false, 2>), grid, wg, 0, st, nullptr, sim_bytes, out16, tbase, idx, bin_shift, n_regions, fin);
+    }
+}
+
+void launch_apply_by_tiles(uint8_t *sim, size_t sim_bytes, const uint32_t *recs, const uint64_t *binbase, uint32_t n_bins, uint32_t bin_shift,
+                           uint32_t *tbase, uint16_t *idx, uint16_t *out16, bool many_records, hipStream_t st, bool big_rows)
+{
+    launch_sort_tiles(recs, binbase, n_bins, bin_shift, tbase, idx, out16, st, big_rows);
+    const uint32_t n_regions = (uint32_t)((sim_bytes + ((size_t)1 << REGION_SHIFT) - 1) >> REGION_SHIFT);
+    const uint32_t grid = apply_tiles_grid(n_regions);
+    ApplyFin none; memset(&none, 0, sizeof none);
     // the variant for many records (a step's groups 64 .. 79 in one pass): N = 1e10 (1.2e9 records) 1.09 -> 0.84 ms, configs[4]'s shape (3.2e8)
     // 2.43 -> 2.08; the other one where there are fewer: configs[2] (1.2e8) +3 %, configs[3]'s shape +3 %, text +7 % with the first
     if (const char *e = getenv("LIME_APPLY_WIDE")) many_records = atoi(e) != 0;            // tests: either variant on any input
-    if (many_records) hipLaunchKernelGGL(k_apply_tiles<true>, dim3(grid ? grid : 1u), dim3(APPLY_WG), 0, st, sim, sim_bytes, out16, tbase, idx, bin_shift, n_regions);
-    else hipLaunchKernelGGL(k_apply_tiles<false>, dim3(grid ? grid : 1u), dim3(APPLY_WG), 0, st, sim, sim_bytes, out16, tbase, idx, bin_shift, n_regions);
+    if (many_records) hipLaunchKernelGGL((k_apply_tiles<true, 0>), dim3(grid), dim3(APPLY_WG), 0, st, sim, sim_bytes, out16, tbase, idx, bin_shift, n_regions, none);
+    else hipLaunchKernelGGL((k_apply_tiles<false, 0>), dim3(grid), dim3(APPLY_WG), 0, st, sim, sim_bytes, out16, tbase, idx, bin_shift, n_regions, none);
 }
+
+// the long clusters' update records bucketed by table region (a few, rarely millions): count, prefix, scatter
+__global__ __launch_bounds__(256) void k_bigrec_count(const uint64_t *recs, uint32_t n, uint32_t *cnt)
+{
+    for (uint32_t i = blockIdx.x * 256u + threadIdx.x; i < n; i += gridDim.x * 256u)
+        atomicAdd(&cnt[(uint32_t)((recs[i] & ((1ull << CELL_BITS) - 1ull)) >> REGION_SHIFT)], 1u);
+}
+__global__ __launch_bounds__(256) void k_bigrec_scatter(const uint64_t *recs, uint32_t n, const uint64_t *off, uint32_t *cursor, uint64_t *out)
+{
+    for (uint32_t i = blockIdx.x * 256u + threadIdx.x; i < n; i += gridDim.x * 256u) {
+        const uint64_t r = recs[i];
+        const uint32_t reg = (uint32_t)((r & ((1ull << CELL_BITS) - 1ull)) >> REGION_SHIFT);
+        out[off[reg] + atomicAdd(&cursor[reg], 1u)] = r;
+    }
+}
+void launch_bigrec_buckets(const uint64_t *recs, uint32_t n, uint32_t n_regions, uint32_t *cnt, uint32_t *cursor, uint64_t *off, uint64_t *out, hipStream_t st)
+{
+    launch_zero2(cnt, (size_t)n_regions * 4u, nullptr, 0, st);
+    launch_zero2(cursor, (size_t)n_regions * 4u, nullptr, 0, st);
+    const uint32_t grid = n ? ((n + 255u) / 256u < 1024u ? (n + 255u) / 256u : 1024u) : 1u;
+    if (n) hipLaunchKernelGGL(k_bigrec_count, dim3(grid), dim3(256), 0, st, recs, n, cnt);
+    launch_scan_tiles(cnt, off, n_regions, reinterpret_cast<unsigned long long *>(off + n_regions), st);
+    if (n) hipLaunchKernelGGL(k_bigrec_scatter, dim3(grid), dim3(256), 0, st, recs, n, off, cursor, out);
+}
+
 uint64_t tiles_bound(uint64_t n_records, uint32_t n_bins) { return n_records / PART_TILE + n_bins; }
 
 uint32_t part_tile() { return PART_TILE; }
