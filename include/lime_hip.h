@@ -263,8 +263,9 @@ int lime_get_timing_ex(lime_ctx *ctx, double ms_avg[4], uint64_t *launches);
 /* What the passes on this ctx have cost on the host side so far (LiME_paired.sh:62-68 runs every collection once: a cold pass pays all of it):
  * out[0] ms inside device allocations, [1] ms inside the sampled density probe in front of the ctx's first pass (synchronisation included),
  * [2] probes run, [3] passes repeated by lime_get_stats (record pool too small), [4] passes that fell back to compare-and-swap
- * (LIME_FLAG_CAS_FALLBACK), [5] update records per owned symbol as last measured (-1: nothing measured yet). */
-int lime_get_host_times(lime_ctx *ctx, double out[6]);
+ * (LIME_FLAG_CAS_FALLBACK), [5] update records per owned symbol as last measured (-1: nothing measured yet), [6] lime_fused_choose_dev calls
+ * served without the table, [7] reserved. */
+int lime_get_host_times(lime_ctx *ctx, double out[8]);
 
 /* ---- multi-GPU: the one exchange step of the path (RCCL over xGMI; librccl is loaded on first use) ---- *
  * The reference partitions positions over OpenMP threads (ClusterLCP.cpp:150-161, skip :196-202, straddle

@@ -216,10 +216,10 @@ class Context:
 
     def host_times(self):
         """what the passes on this context cost on the host so far (lime_get_host_times)"""
-        v = (C.c_double * 6)()
+        v = (C.c_double * 8)()
         check(self.lib.lime_get_host_times(self.h, v))
         return {"alloc_ms": v[0], "probe_ms": v[1], "probes": int(v[2]), "repeats": int(v[3]), "cas_fallbacks": int(v[4]),
-                "records_per_symbol": None if v[5] < 0 else v[5]}
+                "records_per_symbol": None if v[5] < 0 else v[5], "choose_without_table": int(v[6])}
 
 
 def _ptr(t):

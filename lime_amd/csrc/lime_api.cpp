@@ -95,7 +95,7 @@ struct lime_ctx {
     bool force_p64 = false;                 // LIME_FORCE_P64: the partition kernels' 64-bit-position variants on any pass (tests)
     uint64_t p64_test_base = 0;             // LIME_P64_TEST_BASE (tests): the binned records' positions start at this number instead of 0 -- the bin bases are
                                             // shifted by it and the kernels get the records' array address minus it --, so that a small pass crosses a multiple of 2^32
-    double alloc_ms = 0.0, probe_ms = 0.0; uint32_t n_probes = 0, n_repeats = 0, n_fallbacks = 0;   // host-side costs a cold pass pays (lime_get_host_times)
+    double alloc_ms = 0.0, probe_ms = 0.0; uint32_t n_probes = 0, n_repeats = 0, n_fallbacks = 0, n_table_free = 0;   // host-side costs a cold pass pays (lime_get_host_times)
     struct Last {                           // the last lime_fused_dev call, so that lime_get_stats can repeat it with a larger pool
         bool valid = false, binned = false;
         const uint32_t *lcp = nullptr, *da = nullptr; const uint8_t *ebwt = nullptr;
@@ -329,12 +329,13 @@ extern "C" int lime_get_timing_ex(lime_ctx *c, double ms_avg[4], uint64_t *launc
     return LIME_OK;
 }
 
-extern "C" int lime_get_host_times(lime_ctx *c, double out[6])
+extern "C" int lime_get_host_times(lime_ctx *c, double out[8])
 {
     int rc = check_ctx(c, "lime_get_host_times"); if (rc) return rc;
     if (!out) return fail(LIME_ERR_ARG, "lime_get_host_times: out is NULL");
     out[0] = c->alloc_ms; out[1] = c->probe_ms; out[2] = (double)c->n_probes; out[3] = (double)c->n_repeats; out[4] = (double)c->n_fallbacks;
     out[5] = c->density_known ? c->density : -1.0;
+    out[6] = (double)c->n_table_free; out[7] = 0.0;
     return LIME_OK;
 }
 
@@ -1784,6 +1785,7 @@ extern "C" int lime_fused_choose_dev(lime_ctx *c, const uint32_t *d_lcp, const u
         if (rc) return rc;
         return lime_choose_pairs_dev(c, (const uint8_t *)ds.p, n_reads, n_refs, norm, beta, row_max, row_off, pairs, n_pairs, stream);
     }
+    ++c->n_table_free;
     if ((rc = fused_dev_impl(c, d_lcp, d_da, d_ebwt, n, n, 1, n_reads, n_refs, alpha, nullptr, 1, false, st, nullptr, false, true))) return rc;
     rc = lime_get_stats(c, &s, stream);                          // (waits; repeats the pass if the record pool or the long clusters' list was too small)
     if (stats) *stats = s;

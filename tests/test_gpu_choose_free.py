@@ -38,6 +38,7 @@ def _run(monkeypatch, lcp, da, eb, nr, ng, norm, beta, **env):
         tl = torch.from_numpy(lcp.view(np.int32)).to(dev); td = torch.from_numpy(da.view(np.int32)).to(dev)
         te = None if eb is None else torch.from_numpy(eb).to(dev)
         mx, off, pairs, s = c.fused_choose_dev(tl, td, te, len(lcp), nr, ng, 16, norm, beta)
+        s.table_free = c.host_times()["choose_without_table"]
         return mx, off, pairs, s
     finally:
         c.close()
@@ -68,7 +69,7 @@ def test_choose_without_the_table_vs_oracle(monkeypatch, levels, nr, ng, mode, w
         sim = O.score(da, e, cl, nr, ng, threads=8)
         emx, eoff, epairs = _expected(sim, 85, beta)
         mx, off, pairs, s = _run(monkeypatch, lcp, da, e, nr, ng, 85, beta, **env)
-        assert (s.n_clusters, s.max_len) == (nc, ml) and s.wave_records_max > 0
+        assert (s.n_clusters, s.max_len) == (nc, ml) and s.wave_records_max > 0 and s.table_free == 1
         assert np.array_equal(mx, emx), int((mx != emx).sum())
         assert np.array_equal(off, eoff)
         assert np.array_equal(pairs, epairs), (len(pairs), len(epairs))
@@ -114,7 +115,7 @@ def test_choose_without_the_table_wraps_modulo_256(monkeypatch):
         for beta in (0.0, 0.5, 2.0):
             emx, eoff, epairs = _expected(sim, 85, beta)
             mx, off, pairs, s = _run(monkeypatch, lcp, da, e, nr, ng, 85, beta, LIME_UPDATE_PATH="bin", LIME_CHOOSE_FREE=1, LIME_BIN_LEVELS="1,1")
-            assert s.n_updates > 256 * 8 and s.wave_records_max > 0
+            assert s.n_updates > 256 * 8 and s.wave_records_max > 0 and s.table_free == 1
             assert np.array_equal(mx, emx) and np.array_equal(off, eoff) and np.array_equal(pairs, epairs)
 
 
@@ -136,6 +137,7 @@ def test_choose_without_the_table_at_full_size(monkeypatch, shape):
             monkeypatch.setenv("LIME_CHOOSE_FREE", free)
             mx, off, pairs, s = c.fused_choose_dev(lcp, da, eb, n, nr, ng, 16, 85, 0.03)      # max >= 3 passes
             res.append((mx, off, pairs, s.n_updates, s.n_clusters))
+        assert c.host_times()["choose_without_table"] == 1
     finally:
         c.close()
     assert res[0][3] == res[1][3] and res[0][4] == res[1][4]
