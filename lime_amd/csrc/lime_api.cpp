@@ -1795,14 +1795,17 @@ extern "C" int lime_fused_choose_dev(lime_ctx *c, const uint32_t *d_lcp, const u
     HIP_TRY(hipStreamSynchronize(st));
     if (nb > c->bigrec_cap) return fail(LIME_ERR_NOMEM, "more update records of long clusters (%u) than their list holds (%u)", nb, c->bigrec_cap);
     const uint32_t n_regions = (uint32_t)((sim_bytes + ((size_t)1 << REGION_SHIFT) - 1) >> REGION_SHIFT);
-    DevBuf dmax, dnnz, dlast, bcnt, bcur, boff, bout, doff, dp;
-    if ((rc = dmax.alloc((size_t)n_reads * 4)) || (rc = dnnz.alloc((size_t)n_reads * 4)) || (rc = dlast.alloc((size_t)n_regions * 4))) return rc;
+    DevBuf dmax, dnnz, dlast, drr, bcnt, bcur, boff, bout, doff, dp;
+    if ((rc = dmax.alloc((size_t)n_reads * 4)) || (rc = dnnz.alloc((size_t)n_reads * 4)) || (rc = dlast.alloc((size_t)n_regions * 4)) ||
+        (rc = drr.alloc((size_t)n_regions * 16))) return rc;
     HIP_TRY(hipMemsetAsync(dmax.p, 0, (size_t)n_reads * 4, st));
     HIP_TRY(hipMemsetAsync(dnnz.p, 0, (size_t)n_reads * 4, st));
     ApplyFin fin;
     memset(&fin, 0, sizeof fin);
     fin.n_refs = n_refs; fin.table_bytes = (uint64_t)n_reads * n_refs;
     fin.row_max = (uint32_t *)dmax.p; fin.row_nnz = (uint32_t *)dnnz.p; fin.last_nnz = (uint32_t *)dlast.p;
+    fin.region_rows = (const uint4 *)drr.p;
+    launch_region_rows(n_regions, n_refs, fin.table_bytes, nullptr, drr.p, st);
     if (nb) {
         if ((rc = bcnt.alloc((size_t)n_regions * 4)) || (rc = bcur.alloc((size_t)n_regions * 4)) || (rc = boff.alloc(((size_t)n_regions + 1) * 8)) ||
             (rc = bout.alloc((size_t)nb * 8))) return rc;
@@ -1831,6 +1834,7 @@ extern "C" int lime_fused_choose_dev(lime_ctx *c, const uint32_t *d_lcp, const u
     if ((rc = doff.upload(row_off, ((size_t)n_reads + 1) * 8))) return rc;
     if ((rc = dp.alloc((size_t)total * sizeof(lime_pair_t)))) return rc;
     fin.row_off = (const uint64_t *)doff.p; fin.pairs = (lime_pair_t *)dp.p;
+    launch_region_rows(n_regions, n_refs, fin.table_bytes, fin.row_off, drr.p, st);          // (now with the regions that have nothing to gather marked)
     launch_apply_tiles_fin(2, sim_bytes, bin_shift, c->d_tbase, c->d_tidx, rows, expect >= 2e8, fin, st);
     HIP_TRY(hipGetLastError());
     lime_pair_t *h = (lime_pair_t *)malloc((size_t)total * sizeof(lime_pair_t));

@@ -113,6 +113,7 @@ struct ApplyFin {
     uint32_t *last_nnz;                             // per region: the non-zero cells of its last row segment (mode 1 out, mode 2 in)
     const uint64_t *row_off; lime_pair_t *pairs;    // mode 2: where the passing reads' (idRef, sim) lists go
     const uint64_t *big_off; const uint64_t *bigrecs;   // the long clusters' update records bucketed by region (big_off: n_regions + 1), or NULL
+    const uint4 *region_rows;                       // per region (launch_region_rows): first row, offset of the region's first byte in it, row segments, bytes | skip << 31
 };
 
 void launch_tile(int ebwt, int mode, const ScanArgs &a, uint32_t max_blocks, hipStream_t st);
@@ -133,6 +134,7 @@ void launch_sort_tiles(const uint32_t *recs, const uint64_t *binbase, uint32_t n
                        hipStream_t st, bool big_rows);
 void launch_apply_tiles_fin(int mode, size_t sim_bytes, uint32_t bin_shift, const uint32_t *tbase, const uint16_t *idx, const uint16_t *out16, bool many_records,
                             const ApplyFin &fin, hipStream_t st);
+void launch_region_rows(uint32_t n_regions, uint32_t n_refs, uint64_t table_bytes, const uint64_t *row_off /* mode 2; NULL for mode 1 */, void *out /* n_regions x 16 bytes */, hipStream_t st);
 // the long clusters' update records (cell | t << CELL_BITS) bucketed by 64 KB table region: cnt / cursor: n_regions words (zeroed here), off: n_regions + 1
 void launch_bigrec_buckets(const uint64_t *recs, uint32_t n, uint32_t n_regions, uint32_t *cnt, uint32_t *cursor, uint64_t *off, uint64_t *out, hipStream_t st);
 uint64_t tiles_bound(uint64_t n_records, uint32_t n_bins);

@@ -2326,6 +2326,59 @@ __device__ __forceinline__ uint32_t keep_bytes(uint32_t x, uint32_t wb, uint32_t
 }
 __device__ __forceinline__ uint32_t nz_bytes(uint32_t x) { return (((x & 0x7F7F7F7Fu) + 0x7F7F7F7Fu) | x) & 0x80808080u; }   // bit 7 of every non-zero byte
 
+// MODE 1 with at most FIN_SEGS row segments per region (n_refs >= 256): every thread looks at its eight 16-byte pieces of the region -- 97 % of
+// them are zero on configs[2] --, finds the row segment of a non-zero piece with one multiplication by 1 / n_refs (corrected by one) and adds the
+// piece's maximum / non-zero count to the segment's two LDS words; a piece that holds a row border goes byte by byte.  (The first version gave every
+// segment to a wave -- 14 segments of 5000 bytes on 8 waves, each a chain of dependent LDS reads and wave reductions: 1.27 ms on configs[2]
+// against 0.89 for the kernel that WRITES the table.)
+constexpr uint32_t FIN_SEGS = 258;
+__device__ __forceinline__ void fin_region_rows(uint4 *reg4, uint32_t *seg_acc, const ApplyFin &f, uint32_t region, uint64_t r0, uint32_t o0, uint32_t nseg, uint32_t len)
+{
+    // (seg_acc is all zero on entry: cleared at the kernel's start, and by the loop at the end of this function behind every use; the region's LDS copy
+    // is left all zero too -- a piece that is looked at and not zero is zeroed right there: the next region needs no clearing pass)
+    const uint32_t tid = threadIdx.x;
+    const float invf = 1.0f / (float)f.n_refs;
+    const uint32_t nq = (len + 15u) >> 4;
+    for (uint32_t c = tid; c < nq; c += APPLY_WG) {
+        const uint4 v = reg4[c];
+        if (!(v.x | v.y | v.z | v.w)) continue;
+        reg4[c] = make_uint4(0u, 0u, 0u, 0u);
+        const uint32_t x0 = o0 + 16u * c;                          // position of the piece's first byte counted from the start of row r0 (< 2^26)
+        uint32_t seg = (uint32_t)((float)x0 * invf);
+        if (seg * f.n_refs > x0) --seg; else if ((seg + 1u) * f.n_refs <= x0) ++seg;      // (float: off by one at most)
+        const uint32_t border = (seg + 1u) * f.n_refs - o0;        // where the next row starts, in region bytes
+        const uint32_t w[4] = {v.x, v.y, v.z, v.w};
+        if (border >= 16u * c + 16u) {                             // the whole piece lies in one row
+            uint32_t m = 0, z = 0;
+#pragma unroll
+            for (uint32_t i = 0; i < 4; ++i) {
+                const uint32_t a0 = w[i] & 255u, a1 = (w[i] >> 8) & 255u, a2 = (w[i] >> 16) & 255u, a3 = w[i] >> 24;
+                const uint32_t m01 = a0 > a1 ? a0 : a1, m23 = a2 > a3 ? a2 : a3, mm = m01 > m23 ? m01 : m23;
+                m = mm > m ? mm : m;
+                z += (uint32_t)__popc(nz_bytes(w[i]));
+            }
+            atomicMax(&seg_acc[seg], m); atomicAdd(&seg_acc[nseg + seg], z);
+        } else {                                                   // a row border inside (n_refs >= 256: at most one)
+            for (uint32_t b = 0; b < 16u; ++b) {
+                const uint32_t val = (w[b >> 2] >> (8u * (b & 3u))) & 255u;
+                if (!val) continue;
+                const uint32_t sg = seg + (16u * c + b >= border ? 1u : 0u);
+                atomicMax(&seg_acc[sg], val); atomicAdd(&seg_acc[nseg + sg], 1u);
+            }
+        }
+    }
+    __syncthreads();
+    for (uint32_t j = tid; j < nseg; j += APPLY_WG) {
+        const uint32_t mx = seg_acc[j], nz = seg_acc[nseg + j];
+        seg_acc[j] = 0u; seg_acc[nseg + j] = 0u;
+        const uint64_t row = r0 + j, e64 = (uint64_t)(j + 1u) * f.n_refs - o0;
+        const bool whole = (j != 0u || o0 == 0u) && e64 <= len;
+        if (whole) { f.row_max[row] = mx; f.row_nnz[row] = nz; }
+        else { if (mx) atomicMax(&f.row_max[row], mx); if (nz) atomicAdd(&f.row_nnz[row], nz); }
+        if (j == nseg - 1u) f.last_nnz[region] = nz;
+    }
+}
+
 template <int MODE>
 __device__ __forceinline__ void fin_region(const uint4 *reg4, const ApplyFin &f, uint32_t region, uint64_t r0, uint32_t o0, uint32_t nseg, uint32_t len)
 {
@@ -2408,7 +2461,7 @@ template <bool WIDE, int MODE> __global__ __launch_bounds__(APPLY_WG) void k_app
     constexpr uint32_t RW = (1u << REGION_SHIFT) / 4u;           // words per region
     constexpr uint32_t NWV = APPLY_WG / 64, UR = 4;
     __shared__ uint4 reg4[RW / 4];
-    __shared__ uint32_t fin_s[6];                                // MODE 1, 2: the region's first row (two words), offset of the region in it, row segments, bytes, skip
+    __shared__ uint32_t seg_acc[MODE == 1 ? 2 * FIN_SEGS : 2];   // MODE 1: maximum and non-zero count of the region's row segments
     uint32_t *reg = reinterpret_cast<uint32_t *>(reg4);
     const uint32_t lane = lane_id(), wave = (uint32_t)__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));   // wave-uniform: the runs' borders and sources stay scalar
     const uint32_t f2 = 1u << (bin_shift - REGION_SHIFT);
@@ -2506,6 +2559,12 @@ template <bool WIDE, int MODE> __global__ __launch_bounds__(APPLY_WG) void k_app
     uint32_t row0 = tbase[region >> bsh], n_rows = tbase[(region >> bsh) + 1u] - row0;
     uint32_t a, e;
     index_of(region, row0, n_rows, 0u, a, e);
+    // MODE 1, 2: the region's rows -- first row, offset of the region's first byte in it, row segments, bytes inside the table | (MODE 2: no row of
+    // it passed) << 31 -- from k_region_rows' array: a scalar load per region, the next region's in flight while this one is built
+    uint4 ri = make_uint4(0u, 0u, 0u, 0u);
+    if (MODE != 0) ri = fin.region_rows[region];
+    if (MODE == 1) for (uint32_t i = threadIdx.x; i < 2u * FIN_SEGS; i += APPLY_WG) seg_acc[i] = 0u;
+    bool clean = false;                                           // the LDS copy is all zero already (MODE 1: the last region's look at it left it so)
     __syncthreads();                                              // (everybody sees the cleared flag)
     AP_DECL
     for (;;) {
@@ -2513,23 +2572,15 @@ template <bool WIDE, int MODE> __global__ __launch_bounds__(APPLY_WG) void k_app
         const bool more = next < n_regions;
         uint32_t nrow0 = 0, nrow1 = 0;                            // the next region's tile range: needed only after this one's records
         if (more) { nrow0 = tbase[next >> bsh]; nrow1 = tbase[(next >> bsh) + 1u]; }
-        bool skip = false;
-        if (MODE != 0) {                                          // the region's rows (one thread divides); MODE 2: anything to gather here?
-            if (threadIdx.x == 0) {
-                const uint64_t rb = (uint64_t)region << REGION_SHIFT;
-                const uint32_t len = fin.table_bytes - rb < (1ull << REGION_SHIFT) ? (uint32_t)(fin.table_bytes - rb) : (1u << REGION_SHIFT);
-                const uint64_t r0 = rb / fin.n_refs, r1 = (rb + len - 1u) / fin.n_refs;
-                fin_s[0] = (uint32_t)r0; fin_s[1] = (uint32_t)(r0 >> 32); fin_s[2] = (uint32_t)(rb - r0 * fin.n_refs);
-                fin_s[3] = (uint32_t)(r1 - r0) + 1u; fin_s[4] = len;
-                fin_s[5] = MODE == 2 && fin.row_off[r1 + 1u] == fin.row_off[r0] ? 1u : 0u;
-            }
-            __syncthreads();
-            skip = fin_s[5] != 0u;
-        }
+        uint4 nri = make_uint4(0u, 0u, 0u, 0u);
+        if (MODE != 0 && more) nri = fin.region_rows[next];
+        const bool skip = MODE == 2 && (ri.w >> 31) != 0u;
         if (!skip)
         for (exact = false;; exact = true) {                      // once; twice if a cell passed 255 under the fast adds
-        for (uint32_t i = threadIdx.x; i < RW / 4; i += APPLY_WG) reg4[i] = make_uint4(0u, 0u, 0u, 0u);
-        __syncthreads();
+        if (!(MODE == 1 && clean && !exact)) {
+            for (uint32_t i = threadIdx.x; i < RW / 4; i += APPLY_WG) reg4[i] = make_uint4(0u, 0u, 0u, 0u);
+            __syncthreads();
+        }
         AP(0)
         for (uint32_t outer = 0; outer < n_rows; outer += NWV * 64u) {
             const uint32_t nl = runs_of(n_rows, outer);
@@ -2590,7 +2641,12 @@ template <bool WIDE, int MODE> __global__ __launch_bounds__(APPLY_WG) void k_app
         uint32_t na = 0, ne = 0;
         if (more) index_of(next, nrow0, nrow1 - nrow0, 0u, na, ne);
         if (MODE != 0) {
-            if (!skip) fin_region<MODE>(reg4, fin, region, (uint64_t)fin_s[0] | ((uint64_t)fin_s[1] << 32), fin_s[2], fin_s[3], fin_s[4]);
+            if (!skip) {
+                const uint32_t len = ri.w & 0x7FFFFFFFu;
+                clean = false;
+                if (MODE == 1 && ri.z <= FIN_SEGS && fin.n_refs >= 16u) { fin_region_rows(reg4, seg_acc, fin, region, (uint64_t)ri.x, ri.y, ri.z, len); clean = true; }
+                else fin_region<MODE>(reg4, fin, region, (uint64_t)ri.x, ri.y, ri.z, len);
+            }
         } else {
         const size_t reg_base = (size_t)region << REGION_SHIFT;  // regions start inside the table
         uint4 *dst = reinterpret_cast<uint4 *>(sim + reg_base);
@@ -2618,6 +2674,7 @@ template <bool WIDE, int MODE> __global__ __launch_bounds__(APPLY_WG) void k_app
         AP(6)
         if (!more) break;
         __syncthreads();                                          // (the region's LDS copy has been read: it may be cleared)
+        ri = nri;
         AP(7)
         region = next; row0 = nrow0; n_rows = nrow1 - nrow0; a = na; e = ne;
     }
@@ -3156,6 +3213,23 @@ void launch_apply_by_tiles(uint8_t *sim, size_t sim_bytes, const uint32_t *recs,
     if (const char *e = getenv("LIME_APPLY_WIDE")) many_records = atoi(e) != 0;            // tests: either variant on any input
     if (many_records) hipLaunchKernelGGL((k_apply_tiles<true, 0>), dim3(grid), dim3(APPLY_WG), 0, st, sim, sim_bytes, out16, tbase, idx, bin_shift, n_regions, none);
     else hipLaunchKernelGGL((k_apply_tiles<false, 0>), dim3(grid), dim3(APPLY_WG), 0, st, sim, sim_bytes, out16, tbase, idx, bin_shift, n_regions, none);
+}
+
+// the rows of every 64 KB region of the table (k_apply_tiles, modes 1 and 2): first row, offset of the region's first byte in it, row segments,
+// bytes of the region inside the table | (row_off given: none of its rows passed) << 31
+__global__ __launch_bounds__(256) void k_region_rows(uint32_t n_regions, uint32_t n_refs, uint64_t table_bytes, const uint64_t *row_off, uint4 *out)
+{
+    const uint32_t region = blockIdx.x * 256u + threadIdx.x;
+    if (region >= n_regions) return;
+    const uint64_t rb = (uint64_t)region << REGION_SHIFT;
+    const uint32_t len = table_bytes - rb < (1ull << REGION_SHIFT) ? (uint32_t)(table_bytes - rb) : (1u << REGION_SHIFT);
+    const uint64_t r0 = rb / n_refs, r1 = (rb + len - 1u) / n_refs;
+    const uint32_t skip = row_off && row_off[r1 + 1u] == row_off[r0] ? 1u : 0u;
+    out[region] = make_uint4((uint32_t)r0, (uint32_t)(rb - r0 * n_refs), (uint32_t)(r1 - r0) + 1u, len | (skip << 31));
+}
+void launch_region_rows(uint32_t n_regions, uint32_t n_refs, uint64_t table_bytes, const uint64_t *row_off, void *out, hipStream_t st)
+{
+    hipLaunchKernelGGL(k_region_rows, dim3((n_regions + 255u) / 256u), dim3(256), 0, st, n_regions, n_refs, table_bytes, row_off, static_cast<uint4 *>(out));
 }
 
 // the long clusters' update records bucketed by table region (a few, rarely millions): count, prefix, scatter
