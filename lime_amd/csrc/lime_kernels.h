@@ -152,7 +152,8 @@ void launch_choose(const uint8_t *sim, uint32_t n_reads, uint32_t n_refs, uint8_
                    uint32_t *row_nnz, hipStream_t st);
 void launch_synth(uint64_t seed, uint64_t i0, uint64_t count, uint32_t n_reads, uint32_t n_refs,
                   uint32_t alpha, uint32_t mode, uint32_t *lcp, uint32_t *da, uint8_t *ebwt, hipStream_t st);
-void launch_fill_u32(uint32_t *p, size_t n, uint32_t v, hipStream_t st);
+void launch_preload();      // lime_init: load every kernel, fill the launch wrappers' per-device caches
+void launch_fill_u32(uint32_t *p, size_t n, uint32_t v, hipStream_t st, uint32_t count = 1, size_t pitch = 0);   // count arrays of n words, pitch words apart
 void launch_add_u64(uint64_t *p, size_t n, uint64_t v, hipStream_t st);             // p[i] += v (tests: LIME_P64_TEST_BASE)
 void launch_zero2(void *a, size_t a_bytes, void *b, size_t b_bytes, hipStream_t st);   // a: a multiple of 4 bytes; b: 16-byte aligned, a multiple of 16 bytes
 

@@ -19,7 +19,7 @@ for n, nr, ng, ebwt, mode in shapes:
     s, rc = c.stats()
     torch.cuda.synchronize(); t1 = time.perf_counter()
     h1 = c.host_times()
-    print(f"n={n} {nr}x{ng} ebwt={ebwt} mode={mode}: rc={rc} probed={h0['records_per_symbol']:.5f} counted={s.n_updates / n:.5f} wave_records_max={s.wave_records_max} "
+    print(f"n={n} {nr}x{ng} ebwt={ebwt} mode={mode}: rc={rc} probed={h0['records_per_symbol']} counted={s.n_updates / n:.5f} wave_records_max={s.wave_records_max} "
           f"repeats={h1['repeats']} fallbacks={h1['cas_fallbacks']} cold_ms={(t1 - t0) * 1e3:.2f} alloc_ms={h1['alloc_ms']:.2f} probe_ms={h1['probe_ms']:.3f} flags={s.flags}", flush=True)
     c.set_timing(True)
     for _ in range(3):
