@@ -2332,6 +2332,19 @@ __device__ __forceinline__ uint32_t nz_bytes(uint32_t x) { return (((x & 0x7F7F7
 // segment to a wave -- 14 segments of 5000 bytes on 8 waves, each a chain of dependent LDS reads and wave reductions: 1.27 ms on configs[2]
 // against 0.89 for the kernel that WRITES the table.)
 constexpr uint32_t FIN_SEGS = 258;
+// the segments' owner threads: whole rows are stored, rows that cross a region border added atomically (the arrays were zeroed); seg_acc is left zero
+__device__ __forceinline__ void fin_region_store(uint32_t *seg_acc, const ApplyFin &f, uint32_t region, uint64_t r0, uint32_t o0, uint32_t nseg, uint32_t len)
+{
+    for (uint32_t j = threadIdx.x; j < nseg; j += APPLY_WG) {
+        const uint32_t mx = seg_acc[j], nz = seg_acc[nseg + j];
+        seg_acc[j] = 0u; seg_acc[nseg + j] = 0u;
+        const uint64_t row = r0 + j, e64 = (uint64_t)(j + 1u) * f.n_refs - o0;
+        const bool whole = (j != 0u || o0 == 0u) && e64 <= len;
+        if (whole) { f.row_max[row] = mx; f.row_nnz[row] = nz; }
+        else { if (mx) atomicMax(&f.row_max[row], mx); if (nz) atomicAdd(&f.row_nnz[row], nz); }
+        if (j == nseg - 1u) f.last_nnz[region] = nz;
+    }
+}
 __device__ __forceinline__ void fin_region_rows(uint4 *reg4, uint32_t *seg_acc, const ApplyFin &f, uint32_t region, uint64_t r0, uint32_t o0, uint32_t nseg, uint32_t len)
 {
     // (seg_acc is all zero on entry: cleared at the kernel's start, and by the loop at the end of this function behind every use; the region's LDS copy
@@ -2368,15 +2381,7 @@ __device__ __forceinline__ void fin_region_rows(uint4 *reg4, uint32_t *seg_acc, 
         }
     }
     __syncthreads();
-    for (uint32_t j = tid; j < nseg; j += APPLY_WG) {
-        const uint32_t mx = seg_acc[j], nz = seg_acc[nseg + j];
-        seg_acc[j] = 0u; seg_acc[nseg + j] = 0u;
-        const uint64_t row = r0 + j, e64 = (uint64_t)(j + 1u) * f.n_refs - o0;
-        const bool whole = (j != 0u || o0 == 0u) && e64 <= len;
-        if (whole) { f.row_max[row] = mx; f.row_nnz[row] = nz; }
-        else { if (mx) atomicMax(&f.row_max[row], mx); if (nz) atomicAdd(&f.row_nnz[row], nz); }
-        if (j == nseg - 1u) f.last_nnz[region] = nz;
-    }
+    fin_region_store(seg_acc, f, region, r0, o0, nseg, len);
 }
 
 template <int MODE>
@@ -2462,6 +2467,14 @@ template <bool WIDE, int MODE> __global__ __launch_bounds__(APPLY_WG) void k_app
     constexpr uint32_t NWV = APPLY_WG / 64, UR = 4;
     __shared__ uint4 reg4[RW / 4];
     __shared__ uint32_t seg_acc[MODE == 1 ? 2 * FIN_SEGS : 2];   // MODE 1: maximum and non-zero count of the region's row segments
+    // MODE 1: every wave queues the cells its adds found at 0 -- each non-zero cell of the region exactly once, as long as none wraps (a wrap raises
+    // ovf_s and the region is rebuilt) -- and the look at the region is a walk over those queues instead of over 64 KB (below)
+    constexpr uint32_t QW = 768;                                 // cells a wave can queue per region (more: the region is looked at piece by piece); two workgroups per CU: 64 + 12 + 2 KB each
+    __shared__ uint16_t cell_q[MODE == 1 ? NWV * QW : 2];
+    __shared__ uint32_t qovf_s[2];                               // by the parity of the workgroup's region count: set during a region's adds, read behind them, cleared a region later
+    uint32_t par = 0;
+    uint32_t qn = 0;                                             // cells in this wave's queue (wave-uniform)
+    uint32_t pf = 0, po01 = 0, po23 = 0;                         // a lane's first adds of the last add4 (a bit each) and their cells, until qflush() queues them
     uint32_t *reg = reinterpret_cast<uint32_t *>(reg4);
     const uint32_t lane = lane_id(), wave = (uint32_t)__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));   // wave-uniform: the runs' borders and sources stay scalar
     const uint32_t f2 = 1u << (bin_shift - REGION_SHIFT);
@@ -2485,17 +2498,19 @@ template <bool WIDE, int MODE> __global__ __launch_bounds__(APPLY_WG) void k_app
     // the four records of a lane's group [p, p + 4), those inside [fa, fe) only.  The four adds leave together and are looked at together: a
     // record outside the run adds 0 to whatever word its bits name (one add at a time behind its own branch, each waiting for its answer,
     // the adds were 77 % of the kernel's cycles at N = 1e10 and 19 .. 34 % elsewhere: tools/r04_apply_phases.sh)
-    auto add4 = [&](uint32_t p, uint2 w, uint32_t fa, uint32_t fe) {
+    // (`on`: MODE 1 calls with all the wave's lanes and says which of them hold a group -- its queue count is wave-uniform state that a call
+    // under a divergent branch would leave stale in the lanes that sat out)
+    auto add4 = [&](uint32_t p, uint2 w, uint32_t fa, uint32_t fe, bool on = true) {
         const uint32_t o[4] = {w.x & 0xFFFFu, w.x >> 16, w.y & 0xFFFFu, w.y >> 16};
         if (exact) {
 #pragma unroll
-            for (uint32_t i = 0; i < 4; ++i) if (p + i >= fa && p + i < fe) add_exact(o[i]);
+            for (uint32_t i = 0; i < 4; ++i) if (on && p + i >= fa && p + i < fe) add_exact(o[i]);
             return;
         }
         // (the valid slots as a 4-bit mask: lo .. hi of the group; p + 4 > fa and p < fe hold for every group that gets here.  The flag is
         // also raised by an add of 0 that meets a cell at 255 -- harmless: the exact pass follows)
         const uint32_t lo = fa > p ? fa - p : 0u, hi = fe - p < 4u ? fe - p : 4u;
-        const uint32_t m = ((1u << hi) - 1u) & (~0u << lo);
+        const uint32_t m = on ? ((1u << hi) - 1u) & (~0u << lo) : 0u;
         uint32_t old[4], sh[4];
 #pragma unroll
         for (uint32_t i = 0; i < 4; ++i) {
@@ -2506,10 +2521,33 @@ template <bool WIDE, int MODE> __global__ __launch_bounds__(APPLY_WG) void k_app
 #pragma unroll
         for (uint32_t i = 0; i < 4; ++i) over |= __builtin_amdgcn_ubfe(old[i], sh[i], 8u) == 255u;
         if (over) ovf_s = 1u;
+        if (MODE == 1) {                                          // first adds to their cells: noted here, queued by qflush() -- the callers' lanes differ, and
+            pf = 0u;                                              // the queue's count is wave-uniform state that must be kept by ALL lanes
+#pragma unroll
+            for (uint32_t i = 0; i < 4; ++i) pf |= (uint32_t)(((m >> i) & 1u) != 0u && __builtin_amdgcn_ubfe(old[i], sh[i], 8u) == 0u) << i;
+            po01 = o[0] | (o[1] << 16); po23 = o[2] | (o[3] << 16);
+        }
+    };
+    // (called by all lanes of the wave, right behind an add4 under its condition)
+    auto qflush = [&]() {
+        if (MODE != 1) return;
+        uint16_t *myq = cell_q + wave * QW;
+#pragma unroll
+        for (uint32_t i = 0; i < 4; ++i) {
+            const bool first = (pf >> i) & 1u;
+            const uint64_t mf = __ballot(first);
+            if (first) { const uint32_t at = qn + rank_in(mf); if (at < QW) myq[at] = (uint16_t)((i & 2u ? po23 : po01) >> (16u * (i & 1u))); }
+            qn += (uint32_t)__popcll(mf);
+        }
+        pf = 0u;
+    };
+    auto add4c = [&](bool on, uint32_t p, uint2 w, uint32_t fa, uint32_t fe) {
+        if (on) add4(p, w, fa, fe);
+        qflush();
     };
     static_assert(UR == 4, "a step's four runs share one pass over their groups 64 .. 79: sixteen lanes each");
     struct Step { uint2 v[UR], v2[UR], vx; uint32_t fa[UR], fe[UR], q[UR], fax, fex, qx; const uint16_t *src[UR]; };
-    if (threadIdx.x == 0) ovf_s = 0u;
+    if (threadIdx.x == 0) { ovf_s = 0u; qovf_s[0] = 0u; qovf_s[1] = 0u; }
     // A workgroup walks regions blockIdx.x, + gridDim.x, ... (two workgroups per CU).  What a region needs before its records
     // can be read -- its bin's tile range, then its index entries -- is fetched while the region before it is worked on: a
     // workgroup per region paid that chain of dependent loads per region (configs[2]: 76 k regions of 1.6 k records each).
@@ -2575,8 +2613,10 @@ template <bool WIDE, int MODE> __global__ __launch_bounds__(APPLY_WG) void k_app
         uint4 nri = make_uint4(0u, 0u, 0u, 0u);
         if (MODE != 0 && more) nri = fin.region_rows[next];
         const bool skip = MODE == 2 && (ri.w >> 31) != 0u;
+        if (MODE == 1 && threadIdx.x == 0) qovf_s[par ^ 1u] = 0u;  // (last read a region ago, set again only behind this region's last barrier)
         if (!skip)
         for (exact = false;; exact = true) {                      // once; twice if a cell passed 255 under the fast adds
+        qn = 0u;
         if (!(MODE == 1 && clean && !exact)) {
             for (uint32_t i = threadIdx.x; i < RW / 4; i += APPLY_WG) reg4[i] = make_uint4(0u, 0u, 0u, 0u);
             __syncthreads();
@@ -2596,14 +2636,14 @@ template <bool WIDE, int MODE> __global__ __launch_bounds__(APPLY_WG) void k_app
                 if (WIDE) {
 #pragma unroll
                     for (uint32_t u = 0; u < UR; ++u)
-                        if (cur.q[u] * 4u < cur.fe[u]) add4(cur.q[u] * 4u, cur.v[u], cur.fa[u], cur.fe[u]);
+                        add4c(cur.q[u] * 4u < cur.fe[u], cur.q[u] * 4u, cur.v[u], cur.fa[u], cur.fe[u]);
                     if (__ballot(cur.qx * 4u < cur.fex)) {
-                        if (cur.qx * 4u < cur.fex) add4(cur.qx * 4u, cur.vx, cur.fax, cur.fex);
+                        add4c(cur.qx * 4u < cur.fex, cur.qx * 4u, cur.vx, cur.fax, cur.fex);
 #pragma unroll
                         for (uint32_t u = 0; u < UR; ++u) {        // runs beyond 320 records (groups from 80 on): loaded here, rare
                             const uint32_t fa = cur.fa[u], fe = cur.fe[u];
                             for (uint32_t q = cur.q[u] + 80u; __ballot(q * 4u < fe); q += 64u)
-                                if (q * 4u < fe) add4(q * 4u, *reinterpret_cast<const uint2 *>(cur.src[u] + (size_t)q * 4u), fa, fe);
+                                { uint2 wq = make_uint2(0u, 0u); if (q * 4u < fe) wq = *reinterpret_cast<const uint2 *>(cur.src[u] + (size_t)q * 4u); add4c(q * 4u < fe, q * 4u, wq, fa, fe); }
                         }
                     }
                 } else {
@@ -2613,7 +2653,7 @@ template <bool WIDE, int MODE> __global__ __launch_bounds__(APPLY_WG) void k_app
                         uint2 w = cur.v[u], w2 = cur.v2[u];
                         const uint32_t fa = cur.fa[u], fe = cur.fe[u];
                         while (__ballot(q * 4u < fe)) {
-                            if (q * 4u < fe) add4(q * 4u, w, fa, fe);
+                            add4c(q * 4u < fe, q * 4u, w, fa, fe);
                             q += 64u;
                             w = w2;
                             if ((q + 64u) * 4u < fe) w2 = *reinterpret_cast<const uint2 *>(cur.src[u] + (size_t)(q + 64u) * 4u);   // (runs beyond 512 records: further groups, loaded here)
@@ -2623,6 +2663,7 @@ template <bool WIDE, int MODE> __global__ __launch_bounds__(APPLY_WG) void k_app
                 AP(4)
             }
         }
+        if (MODE == 1 && qn > QW && lane == 0u) qovf_s[par] = 1u;      // (a wave found more first adds than its queue holds: this region is looked at piece by piece)
         __syncthreads();
         AP(5)
         if (exact || !ovf_s) break;
@@ -2644,7 +2685,31 @@ template <bool WIDE, int MODE> __global__ __launch_bounds__(APPLY_WG) void k_app
             if (!skip) {
                 const uint32_t len = ri.w & 0x7FFFFFFFu;
                 clean = false;
-                if (MODE == 1 && ri.z <= FIN_SEGS && fin.n_refs >= 16u) { fin_region_rows(reg4, seg_acc, fin, region, (uint64_t)ri.x, ri.y, ri.z, len); clean = true; }
+                const bool has_big = fin.big_off && fin.big_off[region + 1u] != fin.big_off[region];
+                if (MODE == 1 && ri.z <= FIN_SEGS && fin.n_refs >= 16u && !exact && !has_big && qovf_s[par] == 0u) {
+                    // the walk over the queued cells: final value of the cell (a byte read), the cell zeroed (a byte store: the LDS copy is left all zero),
+                    // its row segment by one multiplication, two LDS adds -- about 30 instructions per 64 cells against 640 per wave for the look at all pieces
+                    const uint16_t *myq = cell_q + wave * QW;
+                    uint8_t *regb = reinterpret_cast<uint8_t *>(reg4);
+                    const float invf = 1.0f / (float)fin.n_refs;
+                    for (uint32_t i0 = 0; i0 < qn; i0 += 64u) {
+                        const uint32_t i = i0 + lane;
+                        if (i < qn) {
+                            const uint32_t o = myq[i], val = regb[o];
+                            regb[o] = 0;
+                            const uint32_t x0 = ri.y + o;
+                            uint32_t seg = (uint32_t)((float)x0 * invf);
+                            if (seg * fin.n_refs > x0) --seg; else if ((seg + 1u) * fin.n_refs <= x0) ++seg;
+                            if (val) { atomicMax(&seg_acc[seg], val); atomicAdd(&seg_acc[ri.z + seg], 1u); }
+                        }
+                    }
+                    __syncthreads();
+                    fin_region_store(seg_acc, fin, region, (uint64_t)ri.x, ri.y, ri.z, len);
+                    clean = true;
+                }
+                else if (MODE == 1 && ri.z <= FIN_SEGS && fin.n_refs >= 16u) {
+                    fin_region_rows(reg4, seg_acc, fin, region, (uint64_t)ri.x, ri.y, ri.z, len); clean = true;
+                }
                 else fin_region<MODE>(reg4, fin, region, (uint64_t)ri.x, ri.y, ri.z, len);
             }
         } else {
@@ -2674,7 +2739,7 @@ template <bool WIDE, int MODE> __global__ __launch_bounds__(APPLY_WG) void k_app
         AP(6)
         if (!more) break;
         __syncthreads();                                          // (the region's LDS copy has been read: it may be cleared)
-        ri = nri;
+        ri = nri; par ^= 1u;
         AP(7)
         region = next; row0 = nrow0; n_rows = nrow1 - nrow0; a = na; e = ne;
     }
