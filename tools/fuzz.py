@@ -16,7 +16,19 @@ seed0 = int(sys.argv[2]) if len(sys.argv) > 2 else 1
 t_end = time.time() + budget
 it = 0
 t_print = time.time()
-stats = {"cases": 0, "symbols": 0, "binned": 0, "shards": 0, "streams": 0}
+stats = {"cases": 0, "symbols": 0, "binned": 0, "shards": 0, "streams": 0, "p64": 0, "choose_free": 0}
+
+
+def expected_choose(sim, norm, beta):
+    mx = sim.max(axis=1) if sim.shape[1] else np.zeros(sim.shape[0], np.uint8)
+    ok = (mx.astype(np.float32) / np.float32(norm)) > np.float32(beta)
+    off = np.zeros(sim.shape[0] + 1, np.uint64); rows = []
+    for r in range(sim.shape[0]):
+        nzc = np.nonzero(sim[r])[0] if ok[r] else np.zeros(0, np.int64)
+        if len(nzc): rows.append(np.stack([nzc.astype(np.uint32), sim[r][nzc].astype(np.uint32)], axis=1))
+        off[r + 1] = off[r] + len(nzc)
+    return mx, off, (np.concatenate(rows) if rows else np.zeros((0, 2), np.uint32))
+
 while time.time() < t_end:
     it += 1
     rng = np.random.default_rng(seed0 * 100003 + it)
@@ -48,6 +60,15 @@ while time.time() < t_end:
         os.environ["LIME_BIN_LEVELS"] = f"{int(rng.integers(1, 30))},{int(rng.integers(1, 200))}"
     else:
         os.environ.pop("LIME_BIN_LEVELS", None)
+    # round 5: the 64-bit-position partition kernels, the record positions starting at a random base around multiples of 2^32
+    do_choose = path == "bin" and rng.random() < 0.4 and nr <= 20000 and nr * ng > 70000
+    if do_choose: os.environ["LIME_BIN_LEVELS"] = f"1,{int(rng.integers(1, 9))}"        # (a second level wherever the table has two regions)
+    os.environ.pop("LIME_P64_TEST_BASE", None); os.environ.pop("LIME_FORCE_P64", None)
+    p64 = path == "bin" and rng.random() < 0.5
+    if p64:
+        os.environ["LIME_FORCE_P64"] = "1"
+        if rng.random() < 0.7:
+            os.environ["LIME_P64_TEST_BASE"] = str(int(rng.integers(1, 5)) * (1 << 32) - int(rng.integers(0, 2 * n + 64)))
     ctx = lime_amd.Context()
     try:
         gcl, gnc, gml = ctx.detect(lcp, da, nr, alpha)
@@ -85,8 +106,18 @@ while time.time() < t_end:
                 combine_edges(edges)
                 assert tc == nc and np.array_equal(tot, exp), f"shards={ns}: " + tag
                 stats["shards"] += 1
+            if do_choose:                                                      # clusterChoose without the table (forced wherever the layout has a second level)
+                norm, beta = 85, float(rng.choice([0.0, 0.012, 0.03, 0.3]))
+                os.environ["LIME_CHOOSE_FREE"] = "1"; os.environ["LIME_APPLY_WIDE"] = str(int(rng.integers(0, 2)))
+                tl = torch.from_numpy(lcp.view(np.int32)).cuda(); td = torch.from_numpy(da.view(np.int32)).cuda()
+                te = None if e is None else torch.from_numpy(e).cuda()
+                mx, off, prs, st = ctx.fused_choose_dev(tl, td, te, n, nr, ng, alpha, norm, beta)
+                emx, eoff, eprs = expected_choose(exp, norm, beta)
+                assert np.array_equal(mx, emx) and np.array_equal(off, eoff) and np.array_equal(prs, eprs), f"fused_choose beta={beta}: " + tag
+                os.environ.pop("LIME_CHOOSE_FREE"); os.environ.pop("LIME_APPLY_WIDE")
+                stats["choose_free"] += ctx.host_times()["choose_without_table"] > 0
             s, rc = ctx.stats()
-        stats["cases"] += 1; stats["symbols"] += n; stats["binned"] += path == "bin"
+        stats["cases"] += 1; stats["symbols"] += n; stats["binned"] += path == "bin"; stats["p64"] += p64
         if time.time() - t_print > 30:                   # a line now and then: a silent GPU run is taken for hung
             print("fuzz ...", stats, flush=True); t_print = time.time()
     finally:
