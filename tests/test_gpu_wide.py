@@ -279,3 +279,46 @@ def test_first_pass_without_probe_is_binned_and_right(mode, ebwt_on):
         assert ht["probes"] == 0 and ht["repeats"] == 0 and ht["cas_fallbacks"] == 0, ht
     finally:
         c.close()
+
+
+@pytest.mark.parametrize("nr,ng", [(1_000_000, 1000), (1_000_000, 4000)])
+def test_more_than_2_32_records_in_one_pass(nr, ng):
+    """1.9 * 10^10 symbols of the clustered generator on one GPU (152 GB of arrays): 4.4 * 10^9 update records -- more than 32-bit positions hold -- in ONE
+    pass on the binned path: k_part_lines<true> (1 GB table, 477 bins) and k_part<.., true> (4 GB table, 954 bins) with positions whose high word is 1
+    for real.  The table == the table of the compare-and-swap path of the same library (the oracle cannot go there), counters equal, no repeat,
+    no fallback.  Reference: the updates of ClusterBWT_DA.cpp:178-184, 243-248 at the density of real text and the size of configs[4]."""
+    import os
+    import torch
+    import lime_amd
+    torch.cuda.empty_cache()
+    free, total = torch.cuda.mem_get_info()
+    n = 19_000_000_000
+    if free < (8 * n + 2 * nr * ng + 70 * (1 << 30)):
+        pytest.skip(f"needs about {(8 * n + 2 * nr * ng) / 1e9 + 70:.0f} GB of free HBM, {free / 1e9:.0f} GB are free")
+    dev = torch.device("cuda", 0)
+    c = lime_amd.Context()
+    old = os.environ.get("LIME_UPDATE_PATH")
+    os.environ["LIME_UPDATE_PATH"] = "cas"
+    c0 = lime_amd.Context()
+    if old is None:
+        del os.environ["LIME_UPDATE_PATH"]
+    else:
+        os.environ["LIME_UPDATE_PATH"] = old
+    try:
+        lcp = torch.empty(n, dtype=torch.int32, device=dev); da = torch.empty_like(lcp)
+        c.synth_dev(42, 0, n, nr, ng, 16, 1, lcp, da, None)
+        tb = lime_amd.sim_bytes(nr, ng)
+        A = torch.empty(tb, dtype=torch.uint8, device=dev)
+        c.fused_dev(lcp, da, None, n, n, True, nr, ng, 16, A, True)
+        sA, rc = c.stats(); assert rc == 0
+        ht = c.host_times()
+        assert sA.n_updates > (1 << 32), int(sA.n_updates)
+        assert sA.wave_records_max > 0 and not (sA.flags & 128) and ht["repeats"] == 0 and ht["cas_fallbacks"] == 0, (int(sA.flags), ht)
+        T = torch.empty(tb, dtype=torch.uint8, device=dev)
+        c0.fused_dev(lcp, da, None, n, n, True, nr, ng, 16, T, True)
+        sT, rc = c0.stats(); assert rc == 0 and sT.wave_records_max == 0
+        assert (sA.n_clusters, sA.max_len, sA.n_updates) == (sT.n_clusters, sT.max_len, sT.n_updates)
+        assert torch.equal(A, T), int((A != T).sum())
+    finally:
+        c.close(); c0.close()
+        torch.cuda.empty_cache()
