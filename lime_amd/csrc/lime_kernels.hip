@@ -1740,7 +1740,7 @@ __global__ __launch_bounds__(WGS) void k_part(ScanArgs a, const uint64_t *binbas
     constexpr uint32_t PART_WG = WGS, PART_TILE = WGS * PART_PER, PART_BPT = (NB_MAX + WGS - 1) / WGS;   // (shadow the file's constants)
     __shared__ uint4 stage4[PART_TILE / 2];                              // (position in out, record) per slot
     extern __shared__ __attribute__((aligned(8))) uint32_t part_lds[];   // per bin: tile count, cursor (LDS slot), position - slot (P64: two words)
-    __shared__ uint32_t wsum[PART_WG / 64];
+    __shared__ uint32_t wsum[PART_WG / 64], tile_n_s;
     uint2 *stage = reinterpret_cast<uint2 *>(stage4);
     const uint32_t nb = a.n_bins, tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
     uint32_t *cnt = part_lds, *cur = cnt + nb, *delta = cur + nb;
@@ -1758,56 +1758,63 @@ __global__ __launch_bounds__(WGS) void k_part(ScanArgs a, const uint64_t *binbas
     // the producer's segments -- (wave, sub-region): 32-bit records, the cell's high part is the sub-region's number -- as one
     // sequence of tiles
     const uint32_t n_seg = a.prod_waves * a.n_sub, seg0 = blockIdx.x * n_seg;
-    // (the segments' record counts from LDS: fetched from memory when the walk needs them, each tile waited a memory round trip
-    // for the next one's -- 30 % of the kernel's cycles)
-    __shared__ uint32_t segn_s[16u * MAX_SUB];
+    // The producer's records -- its (wave, sub-region) pool segments one after the other, each padded to a multiple of four records (16-byte loads,
+    // segments start on 64-byte lines) -- are ONE stream cut into tiles of PART_TILE (round 5).  Rounds 3-4 cut every segment into tiles of its own:
+    // nothing lost where a segment holds many tiles, but on 10^8-symbol inputs a wave has 800 .. 6000 records and every producer walked 8 partly
+    // filled tiles where 1 .. 6 full ones do (configs[1] binned: k_part 52 of the pass's 280 us; the text workload: 8 tiles of 0.72 instead of 5.8).
+    __shared__ uint32_t segn_s[16u * MAX_SUB], segp_s[16u * MAX_SUB + 1u];
     for (uint32_t i = tid; i < n_seg; i += PART_WG) segn_s[i] = a.wave_cnt[seg0 + i];
     __syncthreads();
-    auto seg_n = [&](uint32_t w) { return segn_s[w]; };
-    struct Tile { uint32_t w, t0, tn, binoff; bool any; };
-    auto tile_at = [&](uint32_t w, uint32_t t0) {
-        Tile t; t.w = w; t.t0 = t0; t.any = w < n_seg; t.tn = 0u; t.binoff = 0u;
-        if (t.any) { const uint32_t n = seg_n(w); t.tn = n - t0 < PART_TILE ? n - t0 : PART_TILE; t.binoff = (w % a.n_sub) << (32u - sh); }
+    if (tid == 0) { uint32_t run = 0; for (uint32_t i = 0; i < n_seg; ++i) { segp_s[i] = run; run += (segn_s[i] + 3u) & ~3u; } segp_s[n_seg] = run; }
+    __syncthreads();
+    const uint32_t l_pad = segp_s[n_seg];                                // padded records of the producer
+    struct Tile { uint32_t v0, w0; bool any; };                          // start in the stream, the segment that holds it
+    auto next_tile = [&](const Tile &c) {
+        Tile t; t.v0 = c.v0 + PART_TILE; t.w0 = c.w0; t.any = t.v0 < l_pad;
+        if (t.any) while (segp_s[t.w0 + 1u] <= t.v0) ++t.w0;
         return t;
     };
-    auto next_tile = [&](const Tile &c) {
-        uint32_t w = c.w, t0 = c.t0 + PART_TILE;
-        if (t0 >= seg_n(w)) { t0 = 0u; ++w; while (w < n_seg && seg_n(w) == 0u) ++w; }
-        return tile_at(w, t0);
-    };
-    // records 4 (j * PART_WG + tid) .. + 3 of the tile: 16-byte loads (segments start on 64-byte lines, tiles are multiples of
-    // four); groups past the tile's end read its last group again (never used: the passes look at tn)
-    auto load_tile = [&](const Tile &t, uint4 (&r)[PART_PER / 4]) {
+    // records 4 (j * PART_WG + tid) .. + 3 of the tile (16-byte loads); meta: per group of four how many of them are records (0 .. 4) and the
+    // number of their sub-region (= high part of the cell), six bits a group
+    auto load_tile = [&](const Tile &t, uint4 (&r)[PART_PER / 4], uint32_t &meta) {
         typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
-        const u32x4 *src = reinterpret_cast<const u32x4 *>(a.pool + (size_t)(seg0 + t.w) * a.cap_w + t.t0);
-        const uint32_t lastq = (t.tn - 1u) >> 2;
+        const bool one = segp_s[t.w0 + 1u] >= t.v0 + PART_TILE;          // the whole tile lies in one segment (the rule where segments are long)
+        meta = 0u;
 #pragma unroll
         for (uint32_t j = 0; j < PART_PER / 4; ++j) {
-            const uint32_t q = j * PART_WG + tid;
-            const u32x4 x = __builtin_nontemporal_load(src + (q < lastq ? q : lastq));
-            r[j] = make_uint4(x.x, x.y, x.z, x.w);
+            const uint32_t v = t.v0 + 4u * (j * PART_WG + tid);
+            r[j] = make_uint4(0u, 0u, 0u, 0u);
+            if (v < l_pad) {
+                uint32_t w = t.w0;
+                if (!one) while (segp_s[w + 1u] <= v) ++w;
+                const uint32_t off = v - segp_s[w], n = segn_s[w], vc = n - off < 4u ? n - off : 4u;
+                const u32x4 x = __builtin_nontemporal_load(reinterpret_cast<const u32x4 *>(a.pool + (size_t)(seg0 + w) * a.cap_w + off));
+                r[j] = make_uint4(x.x, x.y, x.z, x.w);
+                meta |= (vc | ((w % a.n_sub) << 3)) << (6u * j);
+            }
         }
     };
-    auto count_tile = [&](const Tile &t, const uint4 (&r)[PART_PER / 4]) {
+    auto count_tile = [&](const uint4 (&r)[PART_PER / 4], uint32_t meta) {
 #pragma unroll
         for (uint32_t j = 0; j < PART_PER / 4; ++j) {
-            const uint32_t i = 4u * (j * PART_WG + tid);
+            const uint32_t vc = (meta >> (6u * j)) & 7u, bo = ((meta >> (6u * j + 3u)) & 7u) << (32u - sh);
             const uint32_t v[4] = {r[j].x, r[j].y, r[j].z, r[j].w};
 #pragma unroll
-            for (uint32_t k = 0; k < 4; ++k) if (i + k < t.tn) atomicAdd(&cnt[(v[k] >> sh) + t.binoff], 1u);
+            for (uint32_t k = 0; k < 4; ++k) if (k < vc) atomicAdd(&cnt[(v[k] >> sh) + bo], 1u);
         }
     };
-    uint32_t w0 = 0;
-    while (w0 < n_seg && seg_n(w0) == 0u) ++w0;
-    Tile tc = tile_at(w0, 0u);
+    Tile tc; tc.v0 = 0u; tc.w0 = 0u; tc.any = l_pad != 0u;
     if (!tc.any) return;
+    while (segp_s[tc.w0 + 1u] <= tc.v0) ++tc.w0;
     uint4 rv[PART_PER / 4], v4[PART_PER / 4];
-    load_tile(tc, rv);
+    uint32_t mv = 0, m4 = 0;                                             // the groups' meta words of rv / v4
+    load_tile(tc, rv, mv);
 #pragma unroll
     for (uint32_t j = 0; j < PART_PER / 4; ++j) v4[j] = rv[j];
-    count_tile(tc, v4);
+    m4 = mv;
+    count_tile(v4, m4);
     Tile tn_ = next_tile(tc);
-    if (tn_.any) load_tile(tn_, rv);
+    if (tn_.any) load_tile(tn_, rv, mv);
     PP_DECL
     for (;;) {
         // ---- scan of the tile's counts: bin cursors (LDS slots), position - slot per bin; the counters go back to zero
@@ -1830,18 +1837,20 @@ __global__ __launch_bounds__(WGS) void k_part(ScanArgs a, const uint64_t *binbas
                     if (P64) delta64[b0 + k] = (uint64_t)G[k] - run; else delta[b0 + k] = (uint32_t)G[k] - run;
                     G[k] += c[k]; cnt[b0 + k] = 0u; run += c[k];
                 }
+            if (tid == PART_WG - 1u) tile_n_s = run;                     // (the last thread's running sum: the tile's records)
             __syncthreads();
             PP(2)
         }
+        const uint32_t tile_n = tile_n_s;
         // ---- every record to the next slot of its bin, with its final position
 #pragma unroll
         for (uint32_t j = 0; j < PART_PER / 4; ++j) {
-            const uint32_t i = 4u * (j * PART_WG + tid);
+            const uint32_t vc = (m4 >> (6u * j)) & 7u, bo = ((m4 >> (6u * j + 3u)) & 7u) << (32u - sh);
             const uint32_t v[4] = {v4[j].x, v4[j].y, v4[j].z, v4[j].w};
 #pragma unroll
             for (uint32_t k = 0; k < 4; ++k)
-                if (i + k < tc.tn) {
-                    const uint32_t b = (v[k] >> sh) + tc.binoff;
+                if (k < vc) {
+                    const uint32_t b = (v[k] >> sh) + bo;
                     const uint32_t slot = atomicAdd(&cur[b], 1u);
                     if (P64) {
                         const uint64_t p = slot + delta64[b];
@@ -1858,36 +1867,37 @@ __global__ __launch_bounds__(WGS) void k_part(ScanArgs a, const uint64_t *binbas
         if (tnext.any) {
 #pragma unroll
             for (uint32_t j = 0; j < PART_PER / 4; ++j) v4[j] = rv[j];
-            count_tile(tnext, v4);
+            m4 = mv;
+            count_tile(v4, m4);
             tn_ = next_tile(tnext);
-            if (tn_.any) load_tile(tn_, rv);                             // ... and the one after it is on its way (in front of this tile's stores: behind them -- what helps k_part_lines -- configs[2] 468 -> 497 us: here the stores are many requests, and the loads queue behind them)
+            if (tn_.any) load_tile(tn_, rv, mv);                         // ... and the one after it is on its way (in front of this tile's stores: behind them -- what helps k_part_lines -- configs[2] 468 -> 497 us: here the stores are many requests, and the loads queue behind them)
         }
         PP(5)
         // ---- ... while this one leaves LDS, four slots a lane: consecutive positions as one 16-byte store
-        for (uint32_t q = tid; 4u * q < tc.tn; q += PART_WG) {
+        for (uint32_t q = tid; 4u * q < tile_n; q += PART_WG) {
             const uint4 s0 = stage4[2u * q], s1 = stage4[2u * q + 1u];   // (p0, v0, p1, v1), (p2, v2, p3, v3)
             if (P64) {                                                   // the positions' high parts ride in the records' bits above t
                 const uint32_t rm = (tbit << 1) - 1u;
                 const uint64_t h0 = (uint64_t)((s0.y >> sh) >> 1) << 32, h1 = (uint64_t)((s0.w >> sh) >> 1) << 32,
                                h2 = (uint64_t)((s1.y >> sh) >> 1) << 32, h3 = (uint64_t)((s1.w >> sh) >> 1) << 32;
-                if (4u * q + 3u < tc.tn && s1.z == s0.x + 3u && h3 == h0) {
+                if (4u * q + 3u < tile_n && s1.z == s0.x + 3u && h3 == h0) {
                     u32x4u o = {s0.y & rm, s0.w & rm, s1.y & rm, s1.w & rm};
                     *reinterpret_cast<u32x4u *>(out + (h0 | s0.x)) = o;
                 } else {
                     out[h0 | s0.x] = s0.y & rm;
-                    if (4u * q + 1u < tc.tn) out[h1 | s0.z] = s0.w & rm;
-                    if (4u * q + 2u < tc.tn) out[h2 | s1.x] = s1.y & rm;
-                    if (4u * q + 3u < tc.tn) out[h3 | s1.z] = s1.w & rm;
+                    if (4u * q + 1u < tile_n) out[h1 | s0.z] = s0.w & rm;
+                    if (4u * q + 2u < tile_n) out[h2 | s1.x] = s1.y & rm;
+                    if (4u * q + 3u < tile_n) out[h3 | s1.z] = s1.w & rm;
                 }
             } else
-            if (4u * q + 3u < tc.tn && s1.z == s0.x + 3u) {
+            if (4u * q + 3u < tile_n && s1.z == s0.x + 3u) {
                 u32x4u o = {s0.y, s0.w, s1.y, s1.w};
                 *reinterpret_cast<u32x4u *>(out + s0.x) = o;
             } else {
                 out[s0.x] = s0.y;
-                if (4u * q + 1u < tc.tn) out[s0.z] = s0.w;
-                if (4u * q + 2u < tc.tn) out[s1.x] = s1.y;
-                if (4u * q + 3u < tc.tn) out[s1.z] = s1.w;
+                if (4u * q + 1u < tile_n) out[s0.z] = s0.w;
+                if (4u * q + 2u < tile_n) out[s1.x] = s1.y;
+                if (4u * q + 3u < tile_n) out[s1.z] = s1.w;
             }
         }
         PP(6)
@@ -1940,54 +1950,60 @@ __global__ __launch_bounds__(PART_WG) void k_part_lines(ScanArgs a, const uint64
     __syncthreads();
     const uint32_t sh = a.bin_shift, omask = (1u << sh) - 1u, tbit = 1u << sh;
     const uint32_t n_seg = a.prod_waves * a.n_sub, seg0 = blockIdx.x * n_seg;
-    // (the segments' record counts from LDS: fetched from memory when the walk needs them, each tile waited a memory round trip
-    // for the next one's -- 30 % of the kernel's cycles)
-    __shared__ uint32_t segn_s[16u * MAX_SUB];
+    // (the producer's segments as ONE stream cut into tiles, like k_part)
+    __shared__ uint32_t segn_s[16u * MAX_SUB], segp_s[16u * MAX_SUB + 1u];
     for (uint32_t i = tid; i < n_seg; i += PART_WG) segn_s[i] = a.wave_cnt[seg0 + i];
     __syncthreads();
-    auto seg_n = [&](uint32_t w) { return segn_s[w]; };
-    struct Tile { uint32_t w, t0, tn, binoff; bool any; };
-    auto tile_at = [&](uint32_t w, uint32_t t0) {
-        Tile t; t.w = w; t.t0 = t0; t.any = w < n_seg; t.tn = 0u; t.binoff = 0u;
-        if (t.any) { const uint32_t n = seg_n(w); t.tn = n - t0 < PART_TILE ? n - t0 : PART_TILE; t.binoff = (w % a.n_sub) << (32u - sh); }
+    if (tid == 0) { uint32_t run = 0; for (uint32_t i = 0; i < n_seg; ++i) { segp_s[i] = run; run += (segn_s[i] + 3u) & ~3u; } segp_s[n_seg] = run; }
+    __syncthreads();
+    const uint32_t l_pad = segp_s[n_seg];                                // padded records of the producer
+    struct Tile { uint32_t v0, w0; bool any; };                          // start in the stream, the segment that holds it
+    auto next_tile = [&](const Tile &c) {
+        Tile t; t.v0 = c.v0 + PART_TILE; t.w0 = c.w0; t.any = t.v0 < l_pad;
+        if (t.any) while (segp_s[t.w0 + 1u] <= t.v0) ++t.w0;
         return t;
     };
-    auto next_tile = [&](const Tile &c) {
-        uint32_t w = c.w, t0 = c.t0 + PART_TILE;
-        if (t0 >= seg_n(w)) { t0 = 0u; ++w; while (w < n_seg && seg_n(w) == 0u) ++w; }
-        return tile_at(w, t0);
-    };
-    auto load_tile = [&](const Tile &t, uint4 (&r)[PART_PER / 4]) {
+    // records 4 (j * PART_WG + tid) .. + 3 of the tile (16-byte loads); meta: per group of four how many of them are records (0 .. 4) and the
+    // number of their sub-region (= high part of the cell), six bits a group
+    auto load_tile = [&](const Tile &t, uint4 (&r)[PART_PER / 4], uint32_t &meta) {
         typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
-        const u32x4 *src = reinterpret_cast<const u32x4 *>(a.pool + (size_t)(seg0 + t.w) * a.cap_w + t.t0);
-        const uint32_t lastq = (t.tn - 1u) >> 2;
+        const bool one = segp_s[t.w0 + 1u] >= t.v0 + PART_TILE;          // the whole tile lies in one segment (the rule where segments are long)
+        meta = 0u;
 #pragma unroll
         for (uint32_t j = 0; j < PART_PER / 4; ++j) {
-            const uint32_t q = j * PART_WG + tid;
-            const u32x4 x = __builtin_nontemporal_load(src + (q < lastq ? q : lastq));
-            r[j] = make_uint4(x.x, x.y, x.z, x.w);
+            const uint32_t v = t.v0 + 4u * (j * PART_WG + tid);
+            r[j] = make_uint4(0u, 0u, 0u, 0u);
+            if (v < l_pad) {
+                uint32_t w = t.w0;
+                if (!one) while (segp_s[w + 1u] <= v) ++w;
+                const uint32_t off = v - segp_s[w], n = segn_s[w], vc = n - off < 4u ? n - off : 4u;
+                const u32x4 x = __builtin_nontemporal_load(reinterpret_cast<const u32x4 *>(a.pool + (size_t)(seg0 + w) * a.cap_w + off));
+                r[j] = make_uint4(x.x, x.y, x.z, x.w);
+                meta |= (vc | ((w % a.n_sub) << 3)) << (6u * j);
+            }
         }
     };
-    auto count_tile = [&](const Tile &t, const uint4 (&r)[PART_PER / 4]) {
+    auto count_tile = [&](const uint4 (&r)[PART_PER / 4], uint32_t meta) {
 #pragma unroll
         for (uint32_t j = 0; j < PART_PER / 4; ++j) {
-            const uint32_t i = 4u * (j * PART_WG + tid);
+            const uint32_t vc = (meta >> (6u * j)) & 7u, bo = ((meta >> (6u * j + 3u)) & 7u) << (32u - sh);
             const uint32_t v[4] = {r[j].x, r[j].y, r[j].z, r[j].w};
 #pragma unroll
-            for (uint32_t k = 0; k < 4; ++k) if (i + k < t.tn) atomicAdd(&cnt[(v[k] >> sh) + t.binoff], 1u);
+            for (uint32_t k = 0; k < 4; ++k) if (k < vc) atomicAdd(&cnt[(v[k] >> sh) + bo], 1u);
         }
     };
-    uint32_t w0 = 0;
-    while (w0 < n_seg && seg_n(w0) == 0u) ++w0;
-    Tile tc = tile_at(w0, 0u);
+    Tile tc; tc.v0 = 0u; tc.w0 = 0u; tc.any = l_pad != 0u;
     if (!tc.any) return;
+    while (segp_s[tc.w0 + 1u] <= tc.v0) ++tc.w0;
     uint4 rv[PART_PER / 4], v4[PART_PER / 4];
-    load_tile(tc, rv);
+    uint32_t mv = 0, m4 = 0;                                             // the groups' meta words of rv / v4
+    load_tile(tc, rv, mv);
 #pragma unroll
     for (uint32_t j = 0; j < PART_PER / 4; ++j) v4[j] = rv[j];
-    count_tile(tc, v4);
+    m4 = mv;
+    count_tile(v4, m4);
     Tile tn_ = next_tile(tc);
-    if (tn_.any) load_tile(tn_, rv);
+    if (tn_.any) load_tile(tn_, rv, mv);
     __syncthreads();                                                     // the first tile's counts are complete
     PP_DECL
     for (;;) {
@@ -2032,11 +2048,11 @@ __global__ __launch_bounds__(PART_WG) void k_part_lines(ScanArgs a, const uint64
         // ---- every record to the next stage slot of its bin
 #pragma unroll
         for (uint32_t j = 0; j < PART_PER / 4; ++j) {
-            const uint32_t i = 4u * (j * PART_WG + tid);
+            const uint32_t vc = (m4 >> (6u * j)) & 7u, bo = ((m4 >> (6u * j + 3u)) & 7u) << (32u - sh);
             const uint32_t v[4] = {v4[j].x, v4[j].y, v4[j].z, v4[j].w};
 #pragma unroll
             for (uint32_t k = 0; k < 4; ++k)
-                if (i + k < tc.tn) stage[atomicAdd(&cur[(v[k] >> sh) + tc.binoff], 1u)] = (v[k] & omask) | tbit;      // t = 1
+                if (k < vc) stage[atomicAdd(&cur[(v[k] >> sh) + bo], 1u)] = (v[k] & omask) | tbit;      // t = 1
         }
         PP(3)
         __syncthreads();
@@ -2048,7 +2064,8 @@ __global__ __launch_bounds__(PART_WG) void k_part_lines(ScanArgs a, const uint64
         if (tnext.any) {
 #pragma unroll
             for (uint32_t j = 0; j < PART_PER / 4; ++j) v4[j] = rv[j];
-            count_tile(tnext, v4);
+            m4 = mv;
+            count_tile(v4, m4);
         }
         PP(5)
         // ---- a line per 16-lane group: element e of the bin's stream (its carried records, then the tile's) goes to g + e
@@ -2084,7 +2101,7 @@ __global__ __launch_bounds__(PART_WG) void k_part_lines(ScanArgs a, const uint64
         // ---- ... and the tile after it is on its way (behind the stores: by the time its registers are waited for, both are long done)
         if (tnext.any) {
             tn_ = next_tile(tnext);
-            if (tn_.any) load_tile(tn_, rv);
+            if (tn_.any) load_tile(tn_, rv, mv);
         }
         PP(6)
         __syncthreads();                                                 // the lines have been read from the carries and the stage
