@@ -1768,25 +1768,44 @@ __global__ __launch_bounds__(WGS) void k_part(ScanArgs a, const uint64_t *binbas
     if (tid == 0) { uint32_t run = 0; for (uint32_t i = 0; i < n_seg; ++i) { segp_s[i] = run; run += (segn_s[i] + 3u) & ~3u; } segp_s[n_seg] = run; }
     __syncthreads();
     const uint32_t l_pad = segp_s[n_seg];                                // padded records of the producer
-    struct Tile { uint32_t v0, w0; bool any; };                          // start in the stream, the segment that holds it
-    auto next_tile = [&](const Tile &c) {
-        Tile t; t.v0 = c.v0 + PART_TILE; t.w0 = c.w0; t.any = t.v0 < l_pad;
-        if (t.any) while (segp_s[t.w0 + 1u] <= t.v0) ++t.w0;
+    // start in the stream, the segment that holds it; one: the tile's records all lie in that segment (the rule where segments are long: the tile
+    // is then described by two wave-uniform words, tn records from the segment's offset v0 - start on, like rounds 3-4's tiles -- the per-group
+    // meta words below cost the partition of N = 1e10 6 % when every tile used them)
+    struct Tile { uint32_t v0, w0, tn, binoff; bool any, one; };
+    auto tile_at = [&](uint32_t v0, uint32_t w0) {
+        Tile t; t.v0 = v0; t.w0 = w0; t.any = v0 < l_pad; t.one = false; t.tn = 0u; t.binoff = 0u;
+        if (t.any) {
+            while (segp_s[t.w0 + 1u] <= v0) ++t.w0;
+            const uint32_t end = v0 + PART_TILE < l_pad ? v0 + PART_TILE : l_pad;
+            t.one = end <= segp_s[t.w0 + 1u];
+            if (t.one) { const uint32_t left = segn_s[t.w0] - (v0 - segp_s[t.w0]); t.tn = left < PART_TILE ? left : PART_TILE; t.binoff = (t.w0 % a.n_sub) << (32u - sh); }
+        }
         return t;
     };
+    auto next_tile = [&](const Tile &c) { return tile_at(c.v0 + PART_TILE, c.w0); };
     // records 4 (j * PART_WG + tid) .. + 3 of the tile (16-byte loads); meta: per group of four how many of them are records (0 .. 4) and the
     // number of their sub-region (= high part of the cell), six bits a group
     auto load_tile = [&](const Tile &t, uint4 (&r)[PART_PER / 4], uint32_t &meta) {
         typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
-        const bool one = segp_s[t.w0 + 1u] >= t.v0 + PART_TILE;          // the whole tile lies in one segment (the rule where segments are long)
         meta = 0u;
+        if (t.one) {                                                     // (groups past the tile's end read its last group again: never used, the passes look at tn)
+            const u32x4 *src = reinterpret_cast<const u32x4 *>(a.pool + (size_t)(seg0 + t.w0) * a.cap_w + (t.v0 - segp_s[t.w0]));
+            const uint32_t lastq = (t.tn - 1u) >> 2;
+#pragma unroll
+            for (uint32_t j = 0; j < PART_PER / 4; ++j) {
+                const uint32_t q = j * PART_WG + tid;
+                const u32x4 x = __builtin_nontemporal_load(src + (q < lastq ? q : lastq));
+                r[j] = make_uint4(x.x, x.y, x.z, x.w);
+            }
+            return;
+        }
 #pragma unroll
         for (uint32_t j = 0; j < PART_PER / 4; ++j) {
             const uint32_t v = t.v0 + 4u * (j * PART_WG + tid);
             r[j] = make_uint4(0u, 0u, 0u, 0u);
             if (v < l_pad) {
                 uint32_t w = t.w0;
-                if (!one) while (segp_s[w + 1u] <= v) ++w;
+                while (segp_s[w + 1u] <= v) ++w;
                 const uint32_t off = v - segp_s[w], n = segn_s[w], vc = n - off < 4u ? n - off : 4u;
                 const u32x4 x = __builtin_nontemporal_load(reinterpret_cast<const u32x4 *>(a.pool + (size_t)(seg0 + w) * a.cap_w + off));
                 r[j] = make_uint4(x.x, x.y, x.z, x.w);
@@ -1794,7 +1813,17 @@ __global__ __launch_bounds__(WGS) void k_part(ScanArgs a, const uint64_t *binbas
             }
         }
     };
-    auto count_tile = [&](const uint4 (&r)[PART_PER / 4], uint32_t meta) {
+    auto count_tile = [&](const Tile &t, const uint4 (&r)[PART_PER / 4], uint32_t meta) {
+        if (t.one) {
+#pragma unroll
+            for (uint32_t j = 0; j < PART_PER / 4; ++j) {
+                const uint32_t i = 4u * (j * PART_WG + tid);
+                const uint32_t v[4] = {r[j].x, r[j].y, r[j].z, r[j].w};
+#pragma unroll
+                for (uint32_t k = 0; k < 4; ++k) if (i + k < t.tn) atomicAdd(&cnt[(v[k] >> sh) + t.binoff], 1u);
+            }
+            return;
+        }
 #pragma unroll
         for (uint32_t j = 0; j < PART_PER / 4; ++j) {
             const uint32_t vc = (meta >> (6u * j)) & 7u, bo = ((meta >> (6u * j + 3u)) & 7u) << (32u - sh);
@@ -1803,16 +1832,15 @@ __global__ __launch_bounds__(WGS) void k_part(ScanArgs a, const uint64_t *binbas
             for (uint32_t k = 0; k < 4; ++k) if (k < vc) atomicAdd(&cnt[(v[k] >> sh) + bo], 1u);
         }
     };
-    Tile tc; tc.v0 = 0u; tc.w0 = 0u; tc.any = l_pad != 0u;
+    Tile tc = tile_at(0u, 0u);
     if (!tc.any) return;
-    while (segp_s[tc.w0 + 1u] <= tc.v0) ++tc.w0;
     uint4 rv[PART_PER / 4], v4[PART_PER / 4];
     uint32_t mv = 0, m4 = 0;                                             // the groups' meta words of rv / v4
     load_tile(tc, rv, mv);
 #pragma unroll
     for (uint32_t j = 0; j < PART_PER / 4; ++j) v4[j] = rv[j];
     m4 = mv;
-    count_tile(v4, m4);
+    count_tile(tc, v4, m4);
     Tile tn_ = next_tile(tc);
     if (tn_.any) load_tile(tn_, rv, mv);
     PP_DECL
@@ -1845,7 +1873,8 @@ __global__ __launch_bounds__(WGS) void k_part(ScanArgs a, const uint64_t *binbas
         // ---- every record to the next slot of its bin, with its final position
 #pragma unroll
         for (uint32_t j = 0; j < PART_PER / 4; ++j) {
-            const uint32_t vc = (m4 >> (6u * j)) & 7u, bo = ((m4 >> (6u * j + 3u)) & 7u) << (32u - sh);
+            const uint32_t vc = tc.one ? (4u * (j * PART_WG + tid) < tc.tn ? (tc.tn - 4u * (j * PART_WG + tid) < 4u ? tc.tn - 4u * (j * PART_WG + tid) : 4u) : 0u) : (m4 >> (6u * j)) & 7u;
+            const uint32_t bo = tc.one ? tc.binoff : ((m4 >> (6u * j + 3u)) & 7u) << (32u - sh);
             const uint32_t v[4] = {v4[j].x, v4[j].y, v4[j].z, v4[j].w};
 #pragma unroll
             for (uint32_t k = 0; k < 4; ++k)
@@ -1868,7 +1897,7 @@ __global__ __launch_bounds__(WGS) void k_part(ScanArgs a, const uint64_t *binbas
 #pragma unroll
             for (uint32_t j = 0; j < PART_PER / 4; ++j) v4[j] = rv[j];
             m4 = mv;
-            count_tile(v4, m4);
+            count_tile(tnext, v4, m4);
             tn_ = next_tile(tnext);
             if (tn_.any) load_tile(tn_, rv, mv);                         // ... and the one after it is on its way (in front of this tile's stores: behind them -- what helps k_part_lines -- configs[2] 468 -> 497 us: here the stores are many requests, and the loads queue behind them)
         }
@@ -1957,25 +1986,44 @@ __global__ __launch_bounds__(PART_WG) void k_part_lines(ScanArgs a, const uint64
     if (tid == 0) { uint32_t run = 0; for (uint32_t i = 0; i < n_seg; ++i) { segp_s[i] = run; run += (segn_s[i] + 3u) & ~3u; } segp_s[n_seg] = run; }
     __syncthreads();
     const uint32_t l_pad = segp_s[n_seg];                                // padded records of the producer
-    struct Tile { uint32_t v0, w0; bool any; };                          // start in the stream, the segment that holds it
-    auto next_tile = [&](const Tile &c) {
-        Tile t; t.v0 = c.v0 + PART_TILE; t.w0 = c.w0; t.any = t.v0 < l_pad;
-        if (t.any) while (segp_s[t.w0 + 1u] <= t.v0) ++t.w0;
+    // start in the stream, the segment that holds it; one: the tile's records all lie in that segment (the rule where segments are long: the tile
+    // is then described by two wave-uniform words, tn records from the segment's offset v0 - start on, like rounds 3-4's tiles -- the per-group
+    // meta words below cost the partition of N = 1e10 6 % when every tile used them)
+    struct Tile { uint32_t v0, w0, tn, binoff; bool any, one; };
+    auto tile_at = [&](uint32_t v0, uint32_t w0) {
+        Tile t; t.v0 = v0; t.w0 = w0; t.any = v0 < l_pad; t.one = false; t.tn = 0u; t.binoff = 0u;
+        if (t.any) {
+            while (segp_s[t.w0 + 1u] <= v0) ++t.w0;
+            const uint32_t end = v0 + PART_TILE < l_pad ? v0 + PART_TILE : l_pad;
+            t.one = end <= segp_s[t.w0 + 1u];
+            if (t.one) { const uint32_t left = segn_s[t.w0] - (v0 - segp_s[t.w0]); t.tn = left < PART_TILE ? left : PART_TILE; t.binoff = (t.w0 % a.n_sub) << (32u - sh); }
+        }
         return t;
     };
+    auto next_tile = [&](const Tile &c) { return tile_at(c.v0 + PART_TILE, c.w0); };
     // records 4 (j * PART_WG + tid) .. + 3 of the tile (16-byte loads); meta: per group of four how many of them are records (0 .. 4) and the
     // number of their sub-region (= high part of the cell), six bits a group
     auto load_tile = [&](const Tile &t, uint4 (&r)[PART_PER / 4], uint32_t &meta) {
         typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
-        const bool one = segp_s[t.w0 + 1u] >= t.v0 + PART_TILE;          // the whole tile lies in one segment (the rule where segments are long)
         meta = 0u;
+        if (t.one) {                                                     // (groups past the tile's end read its last group again: never used, the passes look at tn)
+            const u32x4 *src = reinterpret_cast<const u32x4 *>(a.pool + (size_t)(seg0 + t.w0) * a.cap_w + (t.v0 - segp_s[t.w0]));
+            const uint32_t lastq = (t.tn - 1u) >> 2;
+#pragma unroll
+            for (uint32_t j = 0; j < PART_PER / 4; ++j) {
+                const uint32_t q = j * PART_WG + tid;
+                const u32x4 x = __builtin_nontemporal_load(src + (q < lastq ? q : lastq));
+                r[j] = make_uint4(x.x, x.y, x.z, x.w);
+            }
+            return;
+        }
 #pragma unroll
         for (uint32_t j = 0; j < PART_PER / 4; ++j) {
             const uint32_t v = t.v0 + 4u * (j * PART_WG + tid);
             r[j] = make_uint4(0u, 0u, 0u, 0u);
             if (v < l_pad) {
                 uint32_t w = t.w0;
-                if (!one) while (segp_s[w + 1u] <= v) ++w;
+                while (segp_s[w + 1u] <= v) ++w;
                 const uint32_t off = v - segp_s[w], n = segn_s[w], vc = n - off < 4u ? n - off : 4u;
                 const u32x4 x = __builtin_nontemporal_load(reinterpret_cast<const u32x4 *>(a.pool + (size_t)(seg0 + w) * a.cap_w + off));
                 r[j] = make_uint4(x.x, x.y, x.z, x.w);
@@ -1983,7 +2031,17 @@ __global__ __launch_bounds__(PART_WG) void k_part_lines(ScanArgs a, const uint64
             }
         }
     };
-    auto count_tile = [&](const uint4 (&r)[PART_PER / 4], uint32_t meta) {
+    auto count_tile = [&](const Tile &t, const uint4 (&r)[PART_PER / 4], uint32_t meta) {
+        if (t.one) {
+#pragma unroll
+            for (uint32_t j = 0; j < PART_PER / 4; ++j) {
+                const uint32_t i = 4u * (j * PART_WG + tid);
+                const uint32_t v[4] = {r[j].x, r[j].y, r[j].z, r[j].w};
+#pragma unroll
+                for (uint32_t k = 0; k < 4; ++k) if (i + k < t.tn) atomicAdd(&cnt[(v[k] >> sh) + t.binoff], 1u);
+            }
+            return;
+        }
 #pragma unroll
         for (uint32_t j = 0; j < PART_PER / 4; ++j) {
             const uint32_t vc = (meta >> (6u * j)) & 7u, bo = ((meta >> (6u * j + 3u)) & 7u) << (32u - sh);
@@ -1992,16 +2050,15 @@ __global__ __launch_bounds__(PART_WG) void k_part_lines(ScanArgs a, const uint64
             for (uint32_t k = 0; k < 4; ++k) if (k < vc) atomicAdd(&cnt[(v[k] >> sh) + bo], 1u);
         }
     };
-    Tile tc; tc.v0 = 0u; tc.w0 = 0u; tc.any = l_pad != 0u;
+    Tile tc = tile_at(0u, 0u);
     if (!tc.any) return;
-    while (segp_s[tc.w0 + 1u] <= tc.v0) ++tc.w0;
     uint4 rv[PART_PER / 4], v4[PART_PER / 4];
     uint32_t mv = 0, m4 = 0;                                             // the groups' meta words of rv / v4
     load_tile(tc, rv, mv);
 #pragma unroll
     for (uint32_t j = 0; j < PART_PER / 4; ++j) v4[j] = rv[j];
     m4 = mv;
-    count_tile(v4, m4);
+    count_tile(tc, v4, m4);
     Tile tn_ = next_tile(tc);
     if (tn_.any) load_tile(tn_, rv, mv);
     __syncthreads();                                                     // the first tile's counts are complete
@@ -2046,6 +2103,16 @@ __global__ __launch_bounds__(PART_WG) void k_part_lines(ScanArgs a, const uint64
             PP(2)
         }
         // ---- every record to the next stage slot of its bin
+        if (tc.one) {
+#pragma unroll
+            for (uint32_t j = 0; j < PART_PER / 4; ++j) {
+                const uint32_t i = 4u * (j * PART_WG + tid);
+                const uint32_t v[4] = {v4[j].x, v4[j].y, v4[j].z, v4[j].w};
+#pragma unroll
+                for (uint32_t k = 0; k < 4; ++k)
+                    if (i + k < tc.tn) stage[atomicAdd(&cur[(v[k] >> sh) + tc.binoff], 1u)] = (v[k] & omask) | tbit;      // t = 1
+            }
+        } else
 #pragma unroll
         for (uint32_t j = 0; j < PART_PER / 4; ++j) {
             const uint32_t vc = (m4 >> (6u * j)) & 7u, bo = ((m4 >> (6u * j + 3u)) & 7u) << (32u - sh);
@@ -2065,7 +2132,7 @@ __global__ __launch_bounds__(PART_WG) void k_part_lines(ScanArgs a, const uint64
 #pragma unroll
             for (uint32_t j = 0; j < PART_PER / 4; ++j) v4[j] = rv[j];
             m4 = mv;
-            count_tile(v4, m4);
+            count_tile(tnext, v4, m4);
         }
         PP(5)
         // ---- a line per 16-lane group: element e of the bin's stream (its carried records, then the tile's) goes to g + e
