@@ -55,6 +55,12 @@ WORKLOADS = {
     # them in clusters, 0.24 table updates per symbol) laid side by side 226 times, every copy with its own reads and genomes
     "text_tiled": dict(n=226 * 442_003, nr=226 * 2000, ng=226 * 3, ebwt=1, mode=-1, tiled=226,
                        what="tests/golden/text_example.npz x 226 copies (real-text cluster statistics; stands in for configs[0])"),
+    # the same arrays with the read ids of all copies spread over the table's rows (r -> 48271 r mod numReads, a bijection): in text_tiled copy c's
+    # reads are the rows 2000 c .. 2000 c + 1999, so the records of neighbouring windows all fall into one or two of the table's 1 MB bins -- a
+    # locality that real collections do not have (read ids follow the input files' order, not the suffix array's) and that the partition kernels pay
+    # for with LDS adds on one word ("Round 5")
+    "text_spread": dict(n=226 * 442_003, nr=226 * 2000, ng=226 * 3, ebwt=1, mode=-1, tiled=226, spread=48271,
+                        what="text_tiled with the copies' read ids spread over all rows (same clusters, same update density)"),
 }
 
 
@@ -183,9 +189,12 @@ def run_pass_series(torch, lime_amd, ldist, wl, n_total, steps, warmup, world, r
         copy = torch.arange(k, device=dev, dtype=torch.int64).repeat_interleave(m)
         dd = d1.repeat(k)
         isr = dd < nr1                                  # copy c: reads c*nr1 .., genomes (after ALL reads) c*ng1 ..
-        da.copy_(torch.where(isr, dd + copy * nr1, k * nr1 + copy * ng1 + (dd - nr1)).to(torch.int32))
+        rid = dd + copy * nr1
+        if wl.get("spread"):
+            rid = (rid * int(wl["spread"])) % (k * nr1)
+        da.copy_(torch.where(isr, rid, k * nr1 + copy * ng1 + (dd - nr1)).to(torch.int32))
         lcp.copy_(l1.repeat(k)); eb.copy_(e1.repeat(k))
-        del l1, d1, e1, copy, dd, isr
+        del l1, d1, e1, copy, dd, isr, rid
     else:
         ctx.synth_dev(SEED, lo, n_avail, wl["nr"], wl["ng"], ALPHA, wl["mode"], lcp, da, eb, stream)
     torch.cuda.synchronize()
@@ -275,7 +284,7 @@ def run_pass_series(torch, lime_amd, ldist, wl, n_total, steps, warmup, world, r
     each.sort()
     res = {"exchange": exchange, "dt": dt, "parts": parts, "cold": cold, "flags": int(s.flags),
            "pass_ms_each": {"n": len(each), "median": each[len(each) // 2], "min": each[0], "max": each[-1]} if each else None, "launches": launches, "n_own": n_own, "n_clusters": int(s.n_clusters), "max_len": int(s.max_len),
-           "updates": int(s.n_updates), "binned": bool(s.wave_records_max > 0), "lcp": lcp, "da": da, "eb": eb}
+           "updates": int(s.n_updates), "binned": bool(s.wave_records_max > 0), "wave_records_max": int(s.wave_records_max), "lcp": lcp, "da": da, "eb": eb}
     ctx.close()
     return res
 
@@ -295,7 +304,8 @@ def summarize(wl, r, n_total, steps):
             "frac_of_hbm_peak": bps * r["n_own"] / scan_ms / 1e6 / HBM_PEAK_GBS if scan_ms else None,
             "pass_ms_avg": pass_ms, "pass_GBps": bps * r["n_own"] / pass_ms / 1e6 if pass_ms else None,
             "pass_frac_of_hbm_peak": bps * r["n_own"] / pass_ms / 1e6 / HBM_PEAK_GBS if pass_ms else None,
-            "parts_ms": r["parts"], "n_clusters": r["n_clusters"], "table_updates": r["updates"]}
+            "parts_ms": r["parts"], "n_clusters": r["n_clusters"], "table_updates": r["updates"],
+            "records_fullest_wave_sub_region": r.get("wave_records_max")}
 
 
 def main():
@@ -414,7 +424,7 @@ def main():
     if not args.no_also:
         also = {}
         if world == 1:
-            for name in ("c2", "c2_clustered", "text_tiled", "n1e10", "c5_shape", "c4_shape", "c5_clustered", "n1e10_clustered"):
+            for name in ("c2", "c2_clustered", "text_tiled", "text_spread", "n1e10", "c5_shape", "c4_shape", "c5_clustered", "n1e10_clustered"):
                 if name == wname:
                     continue
                 w2 = WORKLOADS[name]
