@@ -1682,7 +1682,7 @@ __device__ __forceinline__ void part_scan(const uint32_t *cnt, uint32_t *toff, u
 // out: three barriers a tile.
 typedef uint32_t u32x4u __attribute__((ext_vector_type(4), aligned(4)));   // four words at any 4-byte alignment
 #if defined(LIME_PART_TIMING) || defined(LIME_APPLY_TIMING) || defined(LIME_SORT_TIMING)      // debug builds: cycles of k_part's (k_apply_tiles') phases, summed over the first wave of every workgroup (tools/r04_part_phases.sh, tools/r04_apply_phases.sh)
-__device__ unsigned long long g_part_pt[10];      // [8], [9]: k_part_lines before / behind its tile loop
+__device__ unsigned long long g_part_pt[8];
 extern "C" int lime_debug_part_times(unsigned long long *out)
 {
     int rc = (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_part_pt), sizeof(g_part_pt));
@@ -1730,26 +1730,6 @@ extern "C" int lime_debug_part_times(unsigned long long *out)
 
 // WGS threads and tiles of 16 WGS records: 512 / 8192, or -- few bins: the runs stay long enough -- 256 / 4096 with twice as many
 // workgroups per CU: a tile is a chain of short phases between barriers, and what hides their latencies is other workgroups
-// LDS counter add for a wave whose lanes mostly name the SAME counter: the lanes that share the first active lane's counter are added by that
-// lane in one go and take consecutive values, the others add on their own.  Correct for any mix; used only in tiles whose records crowd into few
-// bins (64 adds on one LDS word take 64 turns: the partition of the text workload -- every copy's reads are neighbouring rows of the table, so
-// the records of neighbouring windows fall into one or two bins -- ran 2.1 x slower than the same records spread over the rows).  All lanes call.
-__device__ __forceinline__ uint32_t lds_add_crowded(uint32_t *arr, uint32_t b, bool on)
-{
-    const uint64_t m_on = __ballot(on);
-    if (!m_on) return 0u;
-    const uint32_t leader = (uint32_t)__builtin_ctzll(m_on);
-    const uint32_t b0 = rl32(b, leader);
-    const bool same = on && b == b0;
-    const uint64_t ms = __ballot(same);
-    uint32_t old = 0u;
-    if (lane_id() == leader) old = atomicAdd(&arr[b0], (uint32_t)__popcll(ms));
-    old = rl32(old, leader);
-    if (same) return old + rank_in(ms);
-    if (on) return atomicAdd(&arr[b], 1u);
-    return 0u;
-}
-
 // P64 (round 5): a pass whose record pool holds 2^32 records or more (N = 1e10 at the update density of real text: 2.4 .. 3.9e9 records) --
 // positions in `out` are 64-bit: the bins' cursors are 64-bit registers, a bin's (position - slot) is a 64-bit word in LDS, and the high part
 // of a slot's position travels through the stage in the record's free bits above t (t is 1 here: a score of t left the scan as t records),
@@ -1760,9 +1740,7 @@ __global__ __launch_bounds__(WGS) void k_part(ScanArgs a, const uint64_t *binbas
     constexpr uint32_t PART_WG = WGS, PART_TILE = WGS * PART_PER, PART_BPT = (NB_MAX + WGS - 1) / WGS;   // (shadow the file's constants)
     __shared__ uint4 stage4[PART_TILE / 2];                              // (position in out, record) per slot
     extern __shared__ __attribute__((aligned(8))) uint32_t part_lds[];   // per bin: tile count, cursor (LDS slot), position - slot (P64: two words)
-    __shared__ uint32_t wsum[PART_WG / 64], tile_n_s, crowd_s[2];
-    uint32_t tile_no = 0;
-    if (threadIdx.x < 2) crowd_s[threadIdx.x] = 0u;
+    __shared__ uint32_t wsum[PART_WG / 64], tile_n_s;
     uint2 *stage = reinterpret_cast<uint2 *>(stage4);
     const uint32_t nb = a.n_bins, tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
     uint32_t *cnt = part_lds, *cur = cnt + nb, *delta = cur + nb;
@@ -1835,18 +1813,7 @@ __global__ __launch_bounds__(WGS) void k_part(ScanArgs a, const uint64_t *binbas
             }
         }
     };
-    auto count_tile = [&](const Tile &t, const uint4 (&r)[PART_PER / 4], uint32_t meta, bool crowded) {
-        if (crowded) {                                                   // (the tile before this one had a bin with a quarter of its records)
-#pragma unroll
-            for (uint32_t j = 0; j < PART_PER / 4; ++j) {
-                const uint32_t vc = t.one ? (4u * (j * PART_WG + tid) < t.tn ? t.tn - 4u * (j * PART_WG + tid) : 0u) : (meta >> (6u * j)) & 7u;
-                const uint32_t bo = t.one ? t.binoff : ((meta >> (6u * j + 3u)) & 7u) << (32u - sh);
-                const uint32_t v[4] = {r[j].x, r[j].y, r[j].z, r[j].w};
-#pragma unroll
-                for (uint32_t k = 0; k < 4; ++k) (void)lds_add_crowded(cnt, (v[k] >> sh) + bo, k < vc);
-            }
-            return;
-        }
+    auto count_tile = [&](const Tile &t, const uint4 (&r)[PART_PER / 4], uint32_t meta) {
         if (t.one) {
 #pragma unroll
             for (uint32_t j = 0; j < PART_PER / 4; ++j) {
@@ -1873,7 +1840,7 @@ __global__ __launch_bounds__(WGS) void k_part(ScanArgs a, const uint64_t *binbas
 #pragma unroll
     for (uint32_t j = 0; j < PART_PER / 4; ++j) v4[j] = rv[j];
     m4 = mv;
-    count_tile(tc, v4, m4, false);
+    count_tile(tc, v4, m4);
     Tile tn_ = next_tile(tc);
     if (tn_.any) load_tile(tn_, rv, mv);
     PP_DECL
@@ -1885,8 +1852,7 @@ __global__ __launch_bounds__(WGS) void k_part(ScanArgs a, const uint64_t *binbas
             __syncthreads();                                             // the counts are complete
             PP(1)
 #pragma unroll
-            for (uint32_t k = 0; k < PART_BPT; ++k) { c[k] = (k < per && b0 + k < nb) ? cnt[b0 + k] : 0u; mine += c[k]; if (c[k] >= PART_TILE / 4u) crowd_s[tile_no & 1u] = 1u; }
-            if (tid == 0) crowd_s[(tile_no + 1u) & 1u] = 0u;             // (read a tile ago, set again a tile from now)
+            for (uint32_t k = 0; k < PART_BPT; ++k) { c[k] = (k < per && b0 + k < nb) ? cnt[b0 + k] : 0u; mine += c[k]; }
             const uint32_t incl = wave_incl_scan(mine);
             if (lane == 63u) wsum[wave] = incl;
             __syncthreads();
@@ -1904,8 +1870,6 @@ __global__ __launch_bounds__(WGS) void k_part(ScanArgs a, const uint64_t *binbas
             PP(2)
         }
         const uint32_t tile_n = tile_n_s;
-        const bool crowded = crowd_s[tile_no & 1u] != 0u;                // a bin holds a quarter of this tile's records: adds on its counters by wave (lds_add_crowded)
-        ++tile_no;
         // ---- every record to the next slot of its bin, with its final position
 #pragma unroll
         for (uint32_t j = 0; j < PART_PER / 4; ++j) {
@@ -1914,16 +1878,14 @@ __global__ __launch_bounds__(WGS) void k_part(ScanArgs a, const uint64_t *binbas
             const uint32_t v[4] = {v4[j].x, v4[j].y, v4[j].z, v4[j].w};
 #pragma unroll
             for (uint32_t k = 0; k < 4; ++k)
-                if (crowded || k < vc) {
+                if (k < vc) {
                     const uint32_t b = (v[k] >> sh) + bo;
-                    const uint32_t slot = crowded ? lds_add_crowded(cur, b, k < vc) : atomicAdd(&cur[b], 1u);
-                    if (k < vc) {
+                    const uint32_t slot = atomicAdd(&cur[b], 1u);
                     if (P64) {
                         const uint64_t p = slot + delta64[b];
                         stage[slot] = make_uint2((uint32_t)p, (v[k] & omask) | tbit | (((uint32_t)(p >> 32) << 1) << sh));
                     } else
                     stage[slot] = make_uint2(slot + delta[b], (v[k] & omask) | tbit);      // t = 1
-                    }
                 }
         }
         PP(3)
@@ -1935,7 +1897,7 @@ __global__ __launch_bounds__(WGS) void k_part(ScanArgs a, const uint64_t *binbas
 #pragma unroll
             for (uint32_t j = 0; j < PART_PER / 4; ++j) v4[j] = rv[j];
             m4 = mv;
-            count_tile(tnext, v4, m4, crowded);
+            count_tile(tnext, v4, m4);
             tn_ = next_tile(tnext);
             if (tn_.any) load_tile(tn_, rv, mv);                         // ... and the one after it is on its way (in front of this tile's stores: behind them -- what helps k_part_lines -- configs[2] 468 -> 497 us: here the stores are many requests, and the loads queue behind them)
         }
@@ -1990,17 +1952,12 @@ constexpr uint32_t PL_CS = 17;                                          // words
 __host__ __device__ inline size_t part_lines_lds(uint32_t nb, bool p64 = false) { return (size_t)nb * (16u + 4u * PL_CS) + ((size_t)PL_TASKS + 2u * nb) * 4u + (p64 ? 4u * (size_t)nb : 0u); }
 
 template <bool P64>           // P64: 64-bit positions in `out` (see k_part): the bins' cursors are 64-bit registers, a line's lanes read the high word from ghi[bin]
-__global__ __launch_bounds__(PART_WG) __attribute__((amdgpu_waves_per_eu(4, 4))) void k_part_lines(ScanArgs a, const uint64_t *binbase, uint32_t *out)   // (two workgroups per CU: 128 registers)
+__global__ __launch_bounds__(PART_WG) void k_part_lines(ScanArgs a, const uint64_t *binbase, uint32_t *out)
 {
-#ifdef LIME_PART_TIMING
-    const uint64_t pk_t0 = __builtin_readcyclecounter();
-#endif
     __shared__ uint4 stage4[PART_TILE / 4];                              // the tile's records, grouped by bin
     extern __shared__ __attribute__((aligned(16))) uint32_t part_lds_al[];
     uint32_t *part_lds = part_lds_al;
-    __shared__ uint32_t wsum[PART_WG / 64], n_tasks_s, crowd_s[2];
-    uint32_t tile_no = 0;
-    if (threadIdx.x < 2) crowd_s[threadIdx.x] = 0u;
+    __shared__ uint32_t wsum[PART_WG / 64], n_tasks_s;
     uint32_t *stage = reinterpret_cast<uint32_t *>(stage4);
     const uint32_t nb = a.n_bins, tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
     // dg[b]: (stage start | carried records << 14 | records to emit << 18, position of the bin's next record in out) -- what a line's lanes need
@@ -2074,18 +2031,7 @@ __global__ __launch_bounds__(PART_WG) __attribute__((amdgpu_waves_per_eu(4, 4)))
             }
         }
     };
-    auto count_tile = [&](const Tile &t, const uint4 (&r)[PART_PER / 4], uint32_t meta, bool crowded) {
-        if (crowded) {                                                   // (the tile before this one had a bin with a quarter of its records)
-#pragma unroll
-            for (uint32_t j = 0; j < PART_PER / 4; ++j) {
-                const uint32_t vc = t.one ? (4u * (j * PART_WG + tid) < t.tn ? t.tn - 4u * (j * PART_WG + tid) : 0u) : (meta >> (6u * j)) & 7u;
-                const uint32_t bo = t.one ? t.binoff : ((meta >> (6u * j + 3u)) & 7u) << (32u - sh);
-                const uint32_t v[4] = {r[j].x, r[j].y, r[j].z, r[j].w};
-#pragma unroll
-                for (uint32_t k = 0; k < 4; ++k) (void)lds_add_crowded(cnt, (v[k] >> sh) + bo, k < vc);
-            }
-            return;
-        }
+    auto count_tile = [&](const Tile &t, const uint4 (&r)[PART_PER / 4], uint32_t meta) {
         if (t.one) {
 #pragma unroll
             for (uint32_t j = 0; j < PART_PER / 4; ++j) {
@@ -2112,13 +2058,10 @@ __global__ __launch_bounds__(PART_WG) __attribute__((amdgpu_waves_per_eu(4, 4)))
 #pragma unroll
     for (uint32_t j = 0; j < PART_PER / 4; ++j) v4[j] = rv[j];
     m4 = mv;
-    count_tile(tc, v4, m4, false);
+    count_tile(tc, v4, m4);
     Tile tn_ = next_tile(tc);
     if (tn_.any) load_tile(tn_, rv, mv);
     __syncthreads();                                                     // the first tile's counts are complete
-#ifdef LIME_PART_TIMING
-    if (threadIdx.x == 64 * LIME_PT_WAVE) atomicAdd(&g_part_pt[8], (unsigned long long)(__builtin_readcyclecounter() - pk_t0));
-#endif
     PP_DECL
     for (;;) {
         uint32_t N[BPT], S[BPT], E[BPT], Cold[BPT];
@@ -2135,7 +2078,6 @@ __global__ __launch_bounds__(PART_WG) __attribute__((amdgpu_waves_per_eu(4, 4)))
                 N[k] = 0u; E[k] = 0u; L[k] = 0u; Cold[k] = C[k];
                 if (k < per && b0 + k < nb) {
                     N[k] = cnt[b0 + k]; cnt[b0 + k] = 0u;
-                    if (N[k] >= PART_TILE / 4u) crowd_s[tile_no & 1u] = 1u;
                     const pos_t end = G[k] + C[k] + N[k], border = end & ~(pos_t)15u;
                     if (border > G[k]) { E[k] = (uint32_t)(border - G[k]); L[k] = (uint32_t)((border >> 4) - (G[k] >> 4)); }
                 }
@@ -2157,26 +2099,11 @@ __global__ __launch_bounds__(PART_WG) __attribute__((amdgpu_waves_per_eu(4, 4)))
                     run += N[k] | (L[k] << 16);
                 }
             if (tid == PART_WG - 1u) n_tasks_s = run >> 16;              // (the last thread's running sum is the total)
-            if (tid == 0) crowd_s[(tile_no + 1u) & 1u] = 0u;             // (read a tile ago, set again a tile from now)
             __syncthreads();
             PP(2)
         }
-        const bool crowded = crowd_s[tile_no & 1u] != 0u;                // a bin holds a quarter of this tile's records: adds on its counters by wave (lds_add_crowded)
-        ++tile_no;
         // ---- every record to the next stage slot of its bin
-        if (crowded) {
-#pragma unroll
-            for (uint32_t j = 0; j < PART_PER / 4; ++j) {
-                const uint32_t vc = tc.one ? (4u * (j * PART_WG + tid) < tc.tn ? tc.tn - 4u * (j * PART_WG + tid) : 0u) : (m4 >> (6u * j)) & 7u;
-                const uint32_t bo = tc.one ? tc.binoff : ((m4 >> (6u * j + 3u)) & 7u) << (32u - sh);
-                const uint32_t v[4] = {v4[j].x, v4[j].y, v4[j].z, v4[j].w};
-#pragma unroll
-                for (uint32_t k = 0; k < 4; ++k) {
-                    const uint32_t slot = lds_add_crowded(cur, (v[k] >> sh) + bo, k < vc);
-                    if (k < vc) stage[slot] = (v[k] & omask) | tbit;
-                }
-            }
-        } else if (tc.one) {
+        if (tc.one) {
 #pragma unroll
             for (uint32_t j = 0; j < PART_PER / 4; ++j) {
                 const uint32_t i = 4u * (j * PART_WG + tid);
@@ -2205,7 +2132,7 @@ __global__ __launch_bounds__(PART_WG) __attribute__((amdgpu_waves_per_eu(4, 4)))
 #pragma unroll
             for (uint32_t j = 0; j < PART_PER / 4; ++j) v4[j] = rv[j];
             m4 = mv;
-            count_tile(tnext, v4, m4, crowded);
+            count_tile(tnext, v4, m4);
         }
         PP(5)
         // ---- a line per 16-lane group: element e of the bin's stream (its carried records, then the tile's) goes to g + e
@@ -2258,17 +2185,10 @@ __global__ __launch_bounds__(PART_WG) __attribute__((amdgpu_waves_per_eu(4, 4)))
         tc = tnext;
     }
     PP_END
-#ifdef LIME_PART_TIMING
-    const uint64_t pk_t1 = __builtin_readcyclecounter();
-#endif
     // ---- the end of the producer's records: what the bins still carry (a last, partial line each)
 #pragma unroll
     for (uint32_t k = 0; k < BPT; ++k)
         if (k < per && b0 + k < nb) for (uint32_t i = 0; i < C[k]; ++i) out[G[k] + i] = cb[(size_t)(b0 + k) * PL_CS + i];
-#ifdef LIME_PART_TIMING
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    if (threadIdx.x == 64 * LIME_PT_WAVE) atomicAdd(&g_part_pt[9], (unsigned long long)(__builtin_readcyclecounter() - pk_t1));
-#endif
 }
 
 // k_part2: second level, one workgroup per bin (bins wider than a region only): the bin's records are counted per
