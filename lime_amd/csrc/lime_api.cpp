@@ -617,10 +617,11 @@ static int fused_dev_impl(lime_ctx *c, const uint32_t *d_lcp, const uint32_t *d_
     if ((rc = timing_mark(c, st))) return rc;
     launch_tile(ebwt, 0, a, c->max_blocks, st);
     if ((rc = timing_mark(c, st))) return rc;
-    launch_resolve(0, a, st);
+    if (!(binned && !c->ablate)) launch_resolve(0, a, st);
     if (binned && !c->ablate) {                          // (timing experiments cut the scan short: nothing to partition)
-        launch_bin_rowscan(c->d_counts, c->d_totals, n_bins, n_prod, st);
-        launch_scan_tiles(c->d_totals, c->d_binbase, n_bins, reinterpret_cast<unsigned long long *>(c->d_binbase + n_bins), st);
+        const bool tiles = bin_shift > REGION_SHIFT && c->by_tiles && !records_only;
+        launch_rowscan_resolve(a, c->d_counts, c->d_totals, n_bins, n_prod, st);      // (the open segments are closed in the same launch)
+        launch_bin_bases(c->d_totals, c->d_binbase, tiles ? c->d_tbase : nullptr, n_bins, st);
         const uint32_t *recs = c->d_recs;
         if (c->p64_test_base && !records_only && (c->by_tiles || bin_shift == REGION_SHIFT)) {      // tests: positions from a base near a multiple of 2^32 on
             launch_add_u64(c->d_binbase, (size_t)n_bins + 1, c->p64_test_base, st);
@@ -633,7 +634,7 @@ static int fused_dev_impl(lime_ctx *c, const uint32_t *d_lcp, const uint32_t *d_
             // (how many records: what the last pass counted per symbol, once one has been read back)
             const double expect = c->density_known ? c->density * (double)n_own : 0.0;
             launch_apply_by_tiles(d_sim, sim_bytes, recs, c->d_binbase, n_bins, bin_shift, c->d_tbase, c->d_tidx,
-                                  reinterpret_cast<uint16_t *>(c->d_pool), expect >= 2e8, st, expect >= 1e8);
+                                  reinterpret_cast<uint16_t *>(c->d_pool), expect >= 2e8, st, expect >= 1e8, !c->p64_test_base);
         } else if (bin_shift > REGION_SHIFT) {            // second level into the (by now free) pool, then regions from there
             uint32_t *recs2 = c->d_pool;
             launch_part2(c->d_recs, c->d_binbase, n_bins, bin_shift, c->d_regbase, recs2, st);

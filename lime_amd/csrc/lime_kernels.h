@@ -121,17 +121,19 @@ uint32_t scan_grid(int ebwt, int mode, int binned, uint32_t n_tiles, uint32_t ma
 // binned updates: after the scan (n_prod = its grid) -- per-bin prefix over the producers and bin totals,
 // records into bins, table regions from bins
 void launch_bin_rowscan(uint32_t *counts, uint32_t *totals, uint32_t n_bins, uint32_t n_prod, hipStream_t st);
+void launch_rowscan_resolve(const ScanArgs &a, uint32_t *counts, uint32_t *totals, uint32_t n_bins, uint32_t n_prod, hipStream_t st);   // launch_bin_rowscan + launch_resolve(0, ..) in one launch
+void launch_bin_bases(const uint32_t *totals, uint64_t *binbase /* n_bins + 1 */, uint32_t *tbase /* n_bins + 1 tiles before each bin, or NULL */, uint32_t n_bins, hipStream_t st);
 void launch_part(const ScanArgs &a, uint32_t n_prod, const uint64_t *binbase, uint32_t *out, hipStream_t st, bool p64 = false);   // p64: the pool holds 2^32 records or more (64-bit positions in `out`)
 void launch_part2(const uint32_t *recs, const uint64_t *binbase, uint32_t n_bins, uint32_t bin_shift, uint64_t *regbase,
                   uint32_t *out, hipStream_t st);
 void launch_apply(uint8_t *sim, size_t sim_bytes, const uint32_t *recs, const uint64_t *regbase, uint32_t bin_shift, hipStream_t st);
 void launch_resolve(int mode, const ScanArgs &a, hipStream_t st);
 void launch_apply_by_tiles(uint8_t *sim, size_t sim_bytes, const uint32_t *recs, const uint64_t *binbase, uint32_t n_bins, uint32_t bin_shift,
-                           uint32_t *tbase, uint16_t *idx, uint16_t *out16, bool many_records, hipStream_t st, bool big_rows = false);   // many_records: about 2e8 and more (a variant of k_apply_tiles); big_rows: about 1e8 records and more (the 16-bit rows written non-temporally)
+                           uint32_t *tbase, uint16_t *idx, uint16_t *out16, bool many_records, hipStream_t st, bool big_rows = false, bool tbase_ready = false);   // tbase_ready: launch_bin_bases filled it   // many_records: about 2e8 and more (a variant of k_apply_tiles); big_rows: about 1e8 records and more (the 16-bit rows written non-temporally)
 // the same in two steps, for clusterChoose without the table: the bins' records sorted into tile rows once (launch_sort_tiles), then
 // k_apply_tiles in mode 1 (row maxima / non-zero counts) and, after the host's pass test, mode 2 (the passing rows' pairs) on the same rows
 void launch_sort_tiles(const uint32_t *recs, const uint64_t *binbase, uint32_t n_bins, uint32_t bin_shift, uint32_t *tbase, uint16_t *idx, uint16_t *out16,
-                       hipStream_t st, bool big_rows);
+                       hipStream_t st, bool big_rows, bool tbase_ready = false);
 void launch_apply_tiles_fin(int mode, size_t sim_bytes, uint32_t bin_shift, const uint32_t *tbase, const uint16_t *idx, const uint16_t *out16, bool many_records,
                             const ApplyFin &fin, hipStream_t st);
 void launch_region_rows(uint32_t n_regions, uint32_t n_refs, uint64_t table_bytes, const uint64_t *row_off /* mode 2; NULL for mode 1 */, void *out /* n_regions x 16 bytes */, hipStream_t st);

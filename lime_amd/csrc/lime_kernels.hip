@@ -1533,10 +1533,10 @@ __global__ __launch_bounds__(256) void k_resolve(ScanArgs a)
 // loop, ClusterLCP.cpp:246-264; EOF closure :244-245) and decides like k_resolve.  Wave 0 first leaves in the shard's
 // edge word what lies before the shard's first head (it belongs to a run of an earlier shard).
 // =========================================================================================
-__global__ __launch_bounds__(256) void k_resolve_open(ScanArgs a)
+__device__ __forceinline__ void resolve_open_body(const ScanArgs &a, uint32_t block, uint32_t n_blocks)
 {
     const uint32_t lane = lane_id();
-    const uint32_t wave = blockIdx.x * 4u + (threadIdx.x >> 6), n_waves = gridDim.x * 4u;
+    const uint32_t wave = block * 4u + (threadIdx.x >> 6), n_waves = n_blocks * 4u;
     // positions [from, n_avail): where the first head is (n_avail: none) and what the positions before it hold
     auto walk = [&](uint64_t from, uint32_t &fl) -> uint64_t {
         for (uint64_t i = from; i < a.n_avail; i += 64u) {
@@ -1574,6 +1574,7 @@ __global__ __launch_bounds__(256) void k_resolve_open(ScanArgs a)
         if (kb < a.big_cap) { a.big[kb].pStart = s; a.big[kb].len = len; }
     }
 }
+__global__ __launch_bounds__(256) void k_resolve_open(ScanArgs a) { resolve_open_body(a, blockIdx.x, gridDim.x); }
 
 // =========================================================================================
 // k_scan_tiles: exclusive prefix sum of the per-tile record counts (one workgroup).
@@ -1635,6 +1636,54 @@ __global__ __launch_bounds__(256) void k_bin_rowscan(uint32_t *counts, uint32_t 
         run += rl32(incl, 63);
     }
     if (lane == 0) totals[b] = run;
+}
+
+// The binned pass's two small launches behind the scan (round 5; they were four: each is 5 us of a pass whose partition takes 19 .. 160 us on the
+// 10^8-symbol workloads): k_rowscan_resolve = k_bin_rowscan in its first blocks + k_resolve_open in 64 more; k_bin_bases = the bins' bases (what
+// k_scan_tiles did with the totals) and, for the second level by tiles, the tiles before each bin (k_tile_bases) by one workgroup.
+constexpr uint32_t RESOLVE_BLOCKS = 64;
+__global__ __launch_bounds__(256) void k_rowscan_resolve(ScanArgs a, uint32_t *counts, uint32_t *totals, uint32_t n_bins, uint32_t n_prod)
+{
+    const uint32_t rb = (n_bins + 3u) / 4u;
+    if (blockIdx.x >= rb) { resolve_open_body(a, blockIdx.x - rb, RESOLVE_BLOCKS); return; }
+    const uint32_t lane = lane_id();
+    const uint32_t b = blockIdx.x * 4u + (threadIdx.x >> 6);
+    if (b >= n_bins) return;
+    uint32_t *row = counts + (size_t)b * n_prod;
+    uint32_t run = 0;
+    for (uint32_t p0 = 0; p0 < n_prod; p0 += 64u) {
+        const uint32_t p = p0 + lane;
+        const uint32_t v = p < n_prod ? row[p] : 0u;
+        const uint32_t incl = wave_incl_scan(v);
+        if (p < n_prod) row[p] = run + incl - v;
+        run += rl32(incl, 63);
+    }
+    if (lane == 0) totals[b] = run;
+}
+__global__ __launch_bounds__(1024) void k_bin_bases(const uint32_t *totals, uint64_t *binbase, uint32_t *tbase, uint32_t n_bins, uint32_t tile)
+{
+    constexpr uint32_t PER = (BIN_MAX + 1023u) / 1024u;
+    __shared__ uint64_t wsum[16];
+    __shared__ uint32_t tsum[16];
+    const uint32_t tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6, i0 = tid * PER;
+    uint32_t v[PER], t[PER];
+    uint64_t mine = 0; uint32_t minet = 0;
+#pragma unroll
+    for (uint32_t k = 0; k < PER; ++k) { v[k] = i0 + k < n_bins ? totals[i0 + k] : 0u; t[k] = (v[k] + tile - 1u) / tile; mine += v[k]; minet += t[k]; }
+    uint64_t x = mine;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) { const uint64_t y = __shfl_up(x, d); if ((int)lane >= d) x += y; }
+    const uint32_t xt = wave_incl_scan(minet);
+    if (lane == 63u) { wsum[wave] = x; tsum[wave] = xt; }
+    __syncthreads();
+    uint64_t run = x - mine; uint32_t runt = xt - minet;
+    for (uint32_t k = 0; k < wave; ++k) { run += wsum[k]; runt += tsum[k]; }
+#pragma unroll
+    for (uint32_t k = 0; k < PER; ++k) {
+        if (i0 + k < n_bins) { binbase[i0 + k] = run; if (tbase) tbase[i0 + k] = runt; }
+        run += v[k]; runt += t[k];
+        if (i0 + k == n_bins - 1u) { binbase[n_bins] = run; if (tbase) tbase[n_bins] = runt; }
+    }
 }
 
 // (bins as wide as a region: the bin bases are the region bases; wider bins go through k_part2 first)
@@ -3265,7 +3314,7 @@ void launch_preload()
     (void)apply_tiles_grid(1u << 20);
     hipFuncAttributes fa;
 #define LIME_PRELOAD(K) (void)hipFuncGetAttributes(&fa, reinterpret_cast<const void *>(K));
-    LIME_PRELOAD(k_resolve_open) LIME_PRELOAD(k_resolve<1>) LIME_PRELOAD(k_emit) LIME_PRELOAD(k_scan_tiles) LIME_PRELOAD(k_bin_rowscan)
+    LIME_PRELOAD(k_resolve_open) LIME_PRELOAD(k_rowscan_resolve) LIME_PRELOAD(k_bin_bases) LIME_PRELOAD(k_resolve<1>) LIME_PRELOAD(k_emit) LIME_PRELOAD(k_scan_tiles) LIME_PRELOAD(k_bin_rowscan)
     LIME_PRELOAD((k_part<PART_WG, BIN_MAX, false>)) LIME_PRELOAD((k_part<PART_WG, BIN_MAX, true>)) LIME_PRELOAD(k_part_lines<false>) LIME_PRELOAD(k_part_lines<true>)
     LIME_PRELOAD(k_tile_bases) LIME_PRELOAD(k_sort_tiles) LIME_PRELOAD((k_apply_tiles<true, 0>)) LIME_PRELOAD(k_apply) LIME_PRELOAD(k_score_big<0>) LIME_PRELOAD(k_score_big<1>)
     LIME_PRELOAD(k_choose) LIME_PRELOAD(k_gather_pairs) LIME_PRELOAD((k_score_list<0, 0>)) LIME_PRELOAD((k_score_list<1, 0>))
@@ -3279,6 +3328,15 @@ uint32_t scan_grid(int ebwt, int mode, int binned, uint32_t n_tiles, uint32_t ma
     if (mode != 0) return scan_grid_of<2, ScanCfg<0, 0>::wg>(k_scan<0, 1, 0>, n_tiles, max_blocks);
     if (binned) return ebwt ? scan_grid_of<4, ScanCfg<1, 1>::wg>(k_scan<1, 0, 1>, n_tiles, max_blocks, probe_shift) : scan_grid_of<3, ScanCfg<0, 1>::wg>(k_scan<0, 0, 1>, n_tiles, max_blocks, probe_shift);
     return ebwt ? scan_grid_of<1, ScanCfg<1, 0>::wg>(k_scan<1, 0, 0>, n_tiles, max_blocks) : scan_grid_of<0, ScanCfg<0, 0>::wg>(k_scan<0, 0, 0>, n_tiles, max_blocks);
+}
+
+void launch_rowscan_resolve(const ScanArgs &a, uint32_t *counts, uint32_t *totals, uint32_t n_bins, uint32_t n_prod, hipStream_t st)
+{
+    hipLaunchKernelGGL(k_rowscan_resolve, dim3((n_bins + 3u) / 4u + RESOLVE_BLOCKS), dim3(256), 0, st, a, counts, totals, n_bins, n_prod);
+}
+void launch_bin_bases(const uint32_t *totals, uint64_t *binbase, uint32_t *tbase, uint32_t n_bins, hipStream_t st)
+{
+    hipLaunchKernelGGL(k_bin_bases, dim3(1), dim3(1024), 0, st, totals, binbase, tbase, n_bins, PART_TILE);
 }
 
 void launch_bin_rowscan(uint32_t *counts, uint32_t *totals, uint32_t n_bins, uint32_t n_prod, hipStream_t st)
@@ -3341,10 +3399,10 @@ void launch_apply(uint8_t *sim, size_t sim_bytes, const uint32_t *recs, const ui
 // second level by tiles (k_sort_tiles + k_apply_tiles).  tbase: n_bins + 1 words; idx: (tiles + n_bins) * (f2 + 1) 16-bit entries;
 // out16: PART_TILE 16-bit records per tile row (tiles_bound() rows at most)
 void launch_sort_tiles(const uint32_t *recs, const uint64_t *binbase, uint32_t n_bins, uint32_t bin_shift, uint32_t *tbase, uint16_t *idx, uint16_t *out16,
-                       hipStream_t st, bool big_rows)
+                       hipStream_t st, bool big_rows, bool tbase_ready)
 {
     if (const char *e = getenv("LIME_SORT_NT")) big_rows = atoi(e) != 0;                     // tests: either kind of row stores on any input
-    hipLaunchKernelGGL(k_tile_bases, dim3(1), dim3(PART_WG), 0, st, binbase, n_bins, tbase);
+    if (!tbase_ready) hipLaunchKernelGGL(k_tile_bases, dim3(1), dim3(PART_WG), 0, st, binbase, n_bins, tbase);
     // enough workgroups to fill the device evenly: about 8 per CU (two are resident at a time)
     const uint32_t per_bin = n_bins >= 2048u ? 1u : (2048u + n_bins - 1u) / n_bins;
     hipLaunchKernelGGL(k_sort_tiles, dim3(n_bins, per_bin), dim3(PART_WG), 0, st, recs, binbase, bin_shift, tbase, idx, out16, big_rows ? 1u : 0u);
@@ -3376,9 +3434,9 @@ void launch_apply_tiles_fin(int mode, size_t sim_bytes, uint32_t bin_shift, cons
 }
 
 void launch_apply_by_tiles(uint8_t *sim, size_t sim_bytes, const uint32_t *recs, const uint64_t *binbase, uint32_t n_bins, uint32_t bin_shift,
-                           uint32_t *tbase, uint16_t *idx, uint16_t *out16, bool many_records, hipStream_t st, bool big_rows)
+                           uint32_t *tbase, uint16_t *idx, uint16_t *out16, bool many_records, hipStream_t st, bool big_rows, bool tbase_ready)
 {
-    launch_sort_tiles(recs, binbase, n_bins, bin_shift, tbase, idx, out16, st, big_rows);
+    launch_sort_tiles(recs, binbase, n_bins, bin_shift, tbase, idx, out16, st, big_rows, tbase_ready);
     const uint32_t n_regions = (uint32_t)((sim_bytes + ((size_t)1 << REGION_SHIFT) - 1) >> REGION_SHIFT);
     const uint32_t grid = apply_tiles_grid(n_regions);
     ApplyFin none; memset(&none, 0, sizeof none);
