@@ -1811,11 +1811,19 @@ __global__ __launch_bounds__(WGS) void k_part(ScanArgs a, const uint64_t *binbas
     // segments start on 64-byte lines) -- are ONE stream cut into tiles of PART_TILE (round 5).  Rounds 3-4 cut every segment into tiles of its own:
     // nothing lost where a segment holds many tiles, but on 10^8-symbol inputs a wave has 800 .. 6000 records and every producer walked 8 partly
     // filled tiles where 1 .. 6 full ones do (configs[1] binned: k_part 52 of the pass's 280 us; the text workload: 8 tiles of 0.72 instead of 5.8).
-    __shared__ uint32_t segn_s[16u * MAX_SUB], segp_s[16u * MAX_SUB + 1u];
-    for (uint32_t i = tid; i < n_seg; i += PART_WG) segn_s[i] = a.wave_cnt[seg0 + i];
+    // (one word per segment: its padded start | the segment's padding, 0 .. 3 records, in the two low bits -- a second array of counts was the 512 bytes
+    // by which k_part_lines<true> at 477 bins no longer fitted a CU twice)
+    __shared__ uint32_t segp_s[16u * MAX_SUB + 1u];
+    for (uint32_t i = tid; i < n_seg; i += PART_WG) segp_s[i] = a.wave_cnt[seg0 + i];
     __syncthreads();
-    if (tid == 0) { uint32_t run = 0; for (uint32_t i = 0; i < n_seg; ++i) { segp_s[i] = run; run += (segn_s[i] + 3u) & ~3u; } segp_s[n_seg] = run; }
+    if (tid == 0) {
+        uint32_t run = 0;
+        for (uint32_t i = 0; i < n_seg; ++i) { const uint32_t n = segp_s[i]; segp_s[i] = run | ((0u - n) & 3u); run += (n + 3u) & ~3u; }
+        segp_s[n_seg] = run;
+    }
     __syncthreads();
+    auto seg_p = [&](uint32_t i) { return segp_s[i] & ~3u; };
+    auto seg_n = [&](uint32_t i) { const uint32_t w = segp_s[i]; return (segp_s[i + 1u] & ~3u) - (w & ~3u) - (w & 3u); };
     const uint32_t l_pad = segp_s[n_seg];                                // padded records of the producer
     // start in the stream, the segment that holds it; one: the tile's records all lie in that segment (the rule where segments are long: the tile
     // is then described by two wave-uniform words, tn records from the segment's offset v0 - start on, like rounds 3-4's tiles -- the per-group
@@ -1824,10 +1832,10 @@ __global__ __launch_bounds__(WGS) void k_part(ScanArgs a, const uint64_t *binbas
     auto tile_at = [&](uint32_t v0, uint32_t w0) {
         Tile t; t.v0 = v0; t.w0 = w0; t.any = v0 < l_pad; t.one = false; t.tn = 0u; t.binoff = 0u;
         if (t.any) {
-            while (segp_s[t.w0 + 1u] <= v0) ++t.w0;
+            while (seg_p(t.w0 + 1u) <= v0) ++t.w0;
             const uint32_t end = v0 + PART_TILE < l_pad ? v0 + PART_TILE : l_pad;
-            t.one = end <= segp_s[t.w0 + 1u];
-            if (t.one) { const uint32_t left = segn_s[t.w0] - (v0 - segp_s[t.w0]); t.tn = left < PART_TILE ? left : PART_TILE; t.binoff = (t.w0 % a.n_sub) << (32u - sh); }
+            t.one = end <= seg_p(t.w0 + 1u);
+            if (t.one) { const uint32_t left = seg_n(t.w0) - (v0 - seg_p(t.w0)); t.tn = left < PART_TILE ? left : PART_TILE; t.binoff = (t.w0 % a.n_sub) << (32u - sh); }
         }
         return t;
     };
@@ -1838,7 +1846,7 @@ __global__ __launch_bounds__(WGS) void k_part(ScanArgs a, const uint64_t *binbas
         typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
         meta = 0u;
         if (t.one) {                                                     // (groups past the tile's end read its last group again: never used, the passes look at tn)
-            const u32x4 *src = reinterpret_cast<const u32x4 *>(a.pool + (size_t)(seg0 + t.w0) * a.cap_w + (t.v0 - segp_s[t.w0]));
+            const u32x4 *src = reinterpret_cast<const u32x4 *>(a.pool + (size_t)(seg0 + t.w0) * a.cap_w + (t.v0 - seg_p(t.w0)));
             const uint32_t lastq = (t.tn - 1u) >> 2;
 #pragma unroll
             for (uint32_t j = 0; j < PART_PER / 4; ++j) {
@@ -1854,8 +1862,8 @@ __global__ __launch_bounds__(WGS) void k_part(ScanArgs a, const uint64_t *binbas
             r[j] = make_uint4(0u, 0u, 0u, 0u);
             if (v < l_pad) {
                 uint32_t w = t.w0;
-                while (segp_s[w + 1u] <= v) ++w;
-                const uint32_t off = v - segp_s[w], n = segn_s[w], vc = n - off < 4u ? n - off : 4u;
+                while (seg_p(w + 1u) <= v) ++w;
+                const uint32_t off = v - seg_p(w), n = seg_n(w), vc = n - off < 4u ? n - off : 4u;
                 const u32x4 x = __builtin_nontemporal_load(reinterpret_cast<const u32x4 *>(a.pool + (size_t)(seg0 + w) * a.cap_w + off));
                 r[j] = make_uint4(x.x, x.y, x.z, x.w);
                 meta |= (vc | ((w % a.n_sub) << 3)) << (6u * j);
@@ -2029,11 +2037,19 @@ __global__ __launch_bounds__(PART_WG) void k_part_lines(ScanArgs a, const uint64
     const uint32_t sh = a.bin_shift, omask = (1u << sh) - 1u, tbit = 1u << sh;
     const uint32_t n_seg = a.prod_waves * a.n_sub, seg0 = blockIdx.x * n_seg;
     // (the producer's segments as ONE stream cut into tiles, like k_part)
-    __shared__ uint32_t segn_s[16u * MAX_SUB], segp_s[16u * MAX_SUB + 1u];
-    for (uint32_t i = tid; i < n_seg; i += PART_WG) segn_s[i] = a.wave_cnt[seg0 + i];
+    // (one word per segment: its padded start | the segment's padding, 0 .. 3 records, in the two low bits -- a second array of counts was the 512 bytes
+    // by which k_part_lines<true> at 477 bins no longer fitted a CU twice)
+    __shared__ uint32_t segp_s[16u * MAX_SUB + 1u];
+    for (uint32_t i = tid; i < n_seg; i += PART_WG) segp_s[i] = a.wave_cnt[seg0 + i];
     __syncthreads();
-    if (tid == 0) { uint32_t run = 0; for (uint32_t i = 0; i < n_seg; ++i) { segp_s[i] = run; run += (segn_s[i] + 3u) & ~3u; } segp_s[n_seg] = run; }
+    if (tid == 0) {
+        uint32_t run = 0;
+        for (uint32_t i = 0; i < n_seg; ++i) { const uint32_t n = segp_s[i]; segp_s[i] = run | ((0u - n) & 3u); run += (n + 3u) & ~3u; }
+        segp_s[n_seg] = run;
+    }
     __syncthreads();
+    auto seg_p = [&](uint32_t i) { return segp_s[i] & ~3u; };
+    auto seg_n = [&](uint32_t i) { const uint32_t w = segp_s[i]; return (segp_s[i + 1u] & ~3u) - (w & ~3u) - (w & 3u); };
     const uint32_t l_pad = segp_s[n_seg];                                // padded records of the producer
     // start in the stream, the segment that holds it; one: the tile's records all lie in that segment (the rule where segments are long: the tile
     // is then described by two wave-uniform words, tn records from the segment's offset v0 - start on, like rounds 3-4's tiles -- the per-group
@@ -2042,10 +2058,10 @@ __global__ __launch_bounds__(PART_WG) void k_part_lines(ScanArgs a, const uint64
     auto tile_at = [&](uint32_t v0, uint32_t w0) {
         Tile t; t.v0 = v0; t.w0 = w0; t.any = v0 < l_pad; t.one = false; t.tn = 0u; t.binoff = 0u;
         if (t.any) {
-            while (segp_s[t.w0 + 1u] <= v0) ++t.w0;
+            while (seg_p(t.w0 + 1u) <= v0) ++t.w0;
             const uint32_t end = v0 + PART_TILE < l_pad ? v0 + PART_TILE : l_pad;
-            t.one = end <= segp_s[t.w0 + 1u];
-            if (t.one) { const uint32_t left = segn_s[t.w0] - (v0 - segp_s[t.w0]); t.tn = left < PART_TILE ? left : PART_TILE; t.binoff = (t.w0 % a.n_sub) << (32u - sh); }
+            t.one = end <= seg_p(t.w0 + 1u);
+            if (t.one) { const uint32_t left = seg_n(t.w0) - (v0 - seg_p(t.w0)); t.tn = left < PART_TILE ? left : PART_TILE; t.binoff = (t.w0 % a.n_sub) << (32u - sh); }
         }
         return t;
     };
@@ -2056,7 +2072,7 @@ __global__ __launch_bounds__(PART_WG) void k_part_lines(ScanArgs a, const uint64
         typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
         meta = 0u;
         if (t.one) {                                                     // (groups past the tile's end read its last group again: never used, the passes look at tn)
-            const u32x4 *src = reinterpret_cast<const u32x4 *>(a.pool + (size_t)(seg0 + t.w0) * a.cap_w + (t.v0 - segp_s[t.w0]));
+            const u32x4 *src = reinterpret_cast<const u32x4 *>(a.pool + (size_t)(seg0 + t.w0) * a.cap_w + (t.v0 - seg_p(t.w0)));
             const uint32_t lastq = (t.tn - 1u) >> 2;
 #pragma unroll
             for (uint32_t j = 0; j < PART_PER / 4; ++j) {
@@ -2072,8 +2088,8 @@ __global__ __launch_bounds__(PART_WG) void k_part_lines(ScanArgs a, const uint64
             r[j] = make_uint4(0u, 0u, 0u, 0u);
             if (v < l_pad) {
                 uint32_t w = t.w0;
-                while (segp_s[w + 1u] <= v) ++w;
-                const uint32_t off = v - segp_s[w], n = segn_s[w], vc = n - off < 4u ? n - off : 4u;
+                while (seg_p(w + 1u) <= v) ++w;
+                const uint32_t off = v - seg_p(w), n = seg_n(w), vc = n - off < 4u ? n - off : 4u;
                 const u32x4 x = __builtin_nontemporal_load(reinterpret_cast<const u32x4 *>(a.pool + (size_t)(seg0 + w) * a.cap_w + off));
                 r[j] = make_uint4(x.x, x.y, x.z, x.w);
                 meta |= (vc | ((w % a.n_sub) << 3)) << (6u * j);

@@ -25,6 +25,15 @@ if "--gate" in sys.argv:
         if r["waves_by_vgpr"] < want_waves: bad.append(f"{name}: {r['vgpr']} VGPRs allow {r['waves_by_vgpr']} waves per SIMD, planned {want_waves}")
         if r["lds"] > 160 * 1024: bad.append(f"{name}: {r['lds']} B of LDS do not fit a CU (one workgroup per CU)")
         if r["sgpr_spill"] > (12 if ebwt else 2): bad.append(f"{name}: {r['sgpr_spill']} SGPR spills")     # (SGPR spills go to VGPR lanes: harmless; EBWT=0: one since the producer groups of round 4)
+    # k_part_lines: two workgroups per CU at the 477 bins of a 1 GB table (N = 1e10), 32- and 64-bit positions -- launch_part's rule
+    # 2 x (part_lines_lds(nb, p64) + static + 512) <= 160 KB; round 5 lost the 64-bit instance to k_part (8.8 against 5.6 ms) over 512 bytes of static LDS
+    for name, r in out.items():
+        if "k_part_linesILb" not in name: continue
+        p64 = "ILb1E" in name
+        nb, tasks, cs = 477, 8192 // 16 + 16, 17
+        dyn = nb * (16 + 4 * cs) + (tasks + 2 * nb) * 4 + (4 * nb if p64 else 0)
+        if 2 * (dyn + r["lds"] + 512) > 160 * 1024: bad.append(f"{name}: {r['lds']} B static + {dyn} B of line buffers at {nb} bins do not fit a CU twice")
+        if r["waves_by_vgpr"] < 4: bad.append(f"{name}: {r['vgpr']} VGPRs: two workgroups of 8 waves do not fit a CU")
     # the v_writelane of the scan's mask words sits in inline assembly with its own wait states (a VALU write of an SGPR / VCC
     # followed at once by a v_writelane reading it took the PREVIOUS value; the compiler's hazard recognizer does not see into the assembly):
     # every v_writelane_b32 must follow an s_nop or another v_writelane directly, and no DPP operation or v_readlane may follow one at once
