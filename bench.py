@@ -289,6 +289,45 @@ def run_pass_series(torch, lime_amd, ldist, wl, n_total, steps, warmup, world, r
     return res
 
 
+def choose_flow(torch, lime_amd, dev):
+    """The device side of the reference's whole ClusterBWT_DA on configs[2]: the scoring pass + clusterChoose (ClusterBWT_DA.cpp:360-452: row
+    maxima, the float test against beta, the surviving (idRef, sim) pairs on the host) through lime_fused_choose_dev, with the table in HBM
+    (pass -> k_choose -> k_gather_pairs) and without it (the second-level kernel keeps row max / nnz and gathers the pairs from LDS).
+    Wall clock of the call, results on the host; min and median of three calls each, alternating."""
+    import time
+    wl = WORKLOADS["c3"]
+    n, nr, ng = wl["n"], wl["nr"], wl["ng"]
+    ctx = lime_amd.Context()
+    lcp = torch.empty(n, dtype=torch.int32, device=dev); da = torch.empty_like(lcp)
+    ctx.synth_dev(SEED, 0, n, nr, ng, ALPHA, wl["mode"], lcp, da, None)
+    res = {"workload": "BASELINE.json configs[2] through lime_fused_choose_dev (norm 85): scan + clusterAnalyze + clusterChoose, row maxima and pairs on the host; "
+                       "beta 0.25: no row of the iid generator passes (the finish is the row maxima); beta 0.02: every row with a cell >= 2 passes, its pairs cross PCIe",
+           "unit": "ms per call (wall clock, host results included)"}
+    keep = os.environ.get("LIME_CHOOSE_FREE")
+    import numpy as np
+    outs = (np.zeros(nr + 1, dtype=np.uint8), np.zeros(nr + 2, dtype=np.uint64))     # the caller's result arrays, as a C caller of the ABI holds them
+    try:
+        for beta in (0.25, 0.02):
+            ms = {"0": [], "1": []}
+            e = res["beta_%g" % beta] = {}
+            for free in ("0", "1") * 4:                  # (the first call of each kind sizes its buffers: dropped)
+                os.environ["LIME_CHOOSE_FREE"] = free
+                torch.cuda.synchronize(); t0 = time.perf_counter()
+                rmx, roff, prs, st = ctx.fused_choose_dev(lcp, da, None, n, nr, ng, ALPHA, 85, beta, out=outs)
+                ms[free].append((time.perf_counter() - t0) * 1e3)
+                e["pairs"] = int(len(prs)); res["n_clusters"] = int(st.n_clusters)
+                del rmx, roff, prs
+            for free, name in (("0", "with_table"), ("1", "without_table")):
+                v = sorted(ms[free][1:])
+                e[name] = {"min": round(v[0], 3), "median": round(v[len(v) // 2], 3), "symbols_per_s": n / (v[len(v) // 2] * 1e-3)}
+            e["speedup_median"] = e["with_table"]["median"] / e["without_table"]["median"]
+    finally:
+        if keep is None: os.environ.pop("LIME_CHOOSE_FREE", None)
+        else: os.environ["LIME_CHOOSE_FREE"] = keep
+    ctx.close(); del lcp, da
+    return res
+
+
 def summarize(wl, r, n_total, steps):
     bps = 8 + wl["ebwt"]
     scan_ms, pass_ms = r["parts"]["scan"], r["parts"]["pass"]
@@ -436,6 +475,11 @@ def main():
                 except Exception as e:
                     also[name] = {"failed": str(e)}
                 torch.cuda.empty_cache()
+            try:
+                also["c3_with_choose"] = choose_flow(torch, lime_amd, dev)
+            except Exception as e:
+                also["c3_with_choose"] = {"failed": str(e)}
+            torch.cuda.empty_cache()
         else:
             r2 = run_pass_series(torch, lime_amd, ldist, wl, n_total, args.steps, args.warmup, world, rank, dev, comm, overlap=True)
             dt2 = comm.max_float(r2["dt"])

@@ -18,6 +18,16 @@ from . import _lib
 from ._lib import Cluster, LimeError, Stats, check  # noqa: F401
 
 
+class _LibBuf:
+    """a host buffer returned by the library (uint32 words), exposed through the array interface and freed with the last array on it"""
+    def __init__(self, lib, ptr, words):
+        self._lib, self._ptr = lib, ptr
+        self.__array_interface__ = {"data": (ptr, False), "shape": (words,), "typestr": "<u4", "version": 3}
+
+    def __del__(self):
+        self._lib.lime_free(C.c_void_p(self._ptr))
+
+
 class Context:
     """One lime_ctx (one device).  `device=None` keeps the current HIP device."""
 
@@ -97,12 +107,14 @@ class Context:
         return mx, nz
 
     def _pairs_out(self, pp, npairs):
+        """the library's pair list as an array WITHOUT a copy (0.7 GB when most of configs[2]'s rows pass: zeroing + copying it cost more than the
+        device side of the call); the buffer goes back to lime_free when the last view of it dies"""
         n = int(npairs.value)
-        out = np.zeros((n, 2), dtype=np.uint32)
-        if n:
-            C.memmove(out.ctypes.data, pp.value, n * 8)
-        self.lib.lime_free(pp)
-        return out
+        if not n or not pp.value:
+            if pp.value:
+                self.lib.lime_free(pp)
+            return np.zeros((0, 2), dtype=np.uint32)
+        return np.asarray(_LibBuf(self.lib, pp.value, 2 * n)).reshape(n, 2)
 
     def score_choose(self, da, ebwt, clusters, n_reads, n_refs, norm, beta, want_sim=False):
         """clusterAnalyze + clusterChoose with the table kept in HBM -> (row_max u8[n_reads],
@@ -131,11 +143,13 @@ class Context:
                                              off.ctypes.data, C.byref(pp), C.byref(npairs), stream))
         return mx[:n_reads], off[:n_reads + 1], self._pairs_out(pp, npairs)
 
-    def fused_choose_dev(self, lcp_t, da_t, ebwt_t, n, n_reads, n_refs, alpha, norm, beta, stream=None):
+    def fused_choose_dev(self, lcp_t, da_t, ebwt_t, n, n_reads, n_refs, alpha, norm, beta, stream=None, out=None):
         """scan + clusterAnalyze + clusterChoose on device-resident arrays, without the table where the binned path serves the pass
         -> (row_max, row_off, pairs, Stats)"""
-        mx = np.zeros(n_reads + 1, dtype=np.uint8)
-        off = np.zeros(n_reads + 2, dtype=np.uint64)
+        if out is None:                                       # out: the caller's (uint8[n_reads + 1], uint64[n_reads + 2]) to fill instead of fresh arrays
+            out = (np.zeros(n_reads + 1, dtype=np.uint8), np.zeros(n_reads + 2, dtype=np.uint64))       # (9 MB of fresh pages at 10^6 reads: 0.5 ms)
+        mx, off = out
+        assert mx.dtype == np.uint8 and off.dtype == np.uint64 and len(mx) >= n_reads + 1 and len(off) >= n_reads + 2
         pp, npairs, s = C.c_void_p(), C.c_uint64(0), Stats()
         check(self.lib.lime_fused_choose_dev(self.h, _ptr(lcp_t), _ptr(da_t), _ptr(ebwt_t), n, n_reads, n_refs, alpha, norm, beta,
                                              mx.ctypes.data, off.ctypes.data, C.byref(pp), C.byref(npairs), C.byref(s), stream))

@@ -48,6 +48,11 @@ struct lime_ctx {
     int device = 0;
     DevStats *d_stats = nullptr;                // followed by the sticky word: passes with a pool overflow not settled by lime_get_stats
     uint32_t *d_sticky = nullptr;
+    // clusterChoose's scratch, kept between calls (round 5: per call four hipMalloc / hipFree pairs, two 4 MB copies into pageable vectors and 10^6
+    // float divisions were 1.3 ms of configs[2]'s 4.3 ms lime_fused_choose_dev): device words for the rows' max / non-zero counts (+ the
+    // table-free finish's region words), pinned host words where they land
+    uint8_t *d_choose = nullptr; size_t choose_cap = 0;
+    void *h_choose = nullptr; size_t h_choose_cap = 0;
     void *h_stats = nullptr;                    // pinned: where read_stats lands the counters (a copy into pageable memory is staged by the runtime: +30 us per call)
     unsigned long long *d_total = nullptr;
     // per-tile scratch (capacity in tiles)
@@ -191,6 +196,8 @@ extern "C" void lime_shutdown(lime_ctx *c)
     (void)hipDeviceSynchronize();
     for (hipEvent_t e : c->ev) (void)hipEventDestroy(e);
     if (c->h_stats) (void)hipHostFree(c->h_stats);
+    if (c->h_choose) (void)hipHostFree(c->h_choose);
+    (void)hipFree(c->d_choose);
     (void)hipFree(c->d_stats); (void)hipFree(c->d_total); (void)hipFree(c->d_summ);
     (void)hipFree(c->d_tile_cnt); (void)hipFree(c->d_tile_off); (void)hipFree(c->d_cross); (void)hipFree(c->d_wmask);
     (void)hipFree(c->d_small); (void)hipFree(c->d_big); (void)hipFree(c->d_out);
@@ -203,6 +210,7 @@ extern "C" void lime_shutdown(lime_ctx *c)
     delete c;
 }
 
+static int d2h_pageable(void *dst, const void *d_src, size_t bytes, hipStream_t st);    // large results into the caller's pageable memory: staged by this library's threads
 static thread_local double g_alloc_ms = 0.0;             // (host time spent in hipFree / hipMalloc by regrow: moved into the ctx's account by its callers)
 template <typename T> static int regrow(T *&p, size_t count)
 {
@@ -1383,7 +1391,7 @@ extern "C" int lime_fused_stream(lime_ctx *c, const uint32_t *lcp, const uint32_
         HIP_TRY(hipStreamSynchronize(pp.comp));
         if ((rc = lime_combine_edges(edges.data(), (uint32_t)n_chunks))) { (void)hipDeviceSynchronize(); return rc; }
     }
-    HIP_TRY(hipMemcpyAsync(sim, ds.p, (size_t)n_reads * n_refs, hipMemcpyDeviceToHost, pp.comp));
+    if ((rc = d2h_pageable(sim, ds.p, (size_t)n_reads * n_refs, pp.comp))) return rc;
     HIP_TRY(hipStreamSynchronize(pp.comp));
     HIP_TRY(hipStreamSynchronize(pp.copy));
     return LIME_OK;
@@ -1661,7 +1669,7 @@ extern "C" int lime_score(lime_ctx *c, const uint32_t *da, const uint8_t *ebwt, 
     DevBuf ds;
     if ((rc = ds.alloc(lime_sim_bytes(n_reads, n_refs)))) return rc;
     if ((rc = score_in_chunks(c, da, ebwt, n, clusters, n_clusters, n_reads, n_refs, (uint8_t *)ds.p))) return rc;
-    HIP_TRY(hipMemcpy(sim, ds.p, (size_t)n_reads * n_refs, hipMemcpyDeviceToHost));
+    if ((rc = d2h_pageable(sim, ds.p, (size_t)n_reads * n_refs, nullptr))) return rc;
     return LIME_OK;
 }
 
@@ -1686,7 +1694,7 @@ extern "C" int lime_fused(lime_ctx *c, const uint32_t *lcp, const uint32_t *da, 
     if (n_clusters) *n_clusters = s.n_clusters;
     if (max_len) *max_len = s.max_len;
     if (rc) return rc;
-    HIP_TRY(hipMemcpy(sim, ds.p, (size_t)n_reads * n_refs, hipMemcpyDeviceToHost));
+    if ((rc = d2h_pageable(sim, ds.p, (size_t)n_reads * n_refs, nullptr))) return rc;
     return LIME_OK;
 }
 
@@ -1707,6 +1715,72 @@ extern "C" int lime_choose(lime_ctx *c, const uint8_t *sim, uint32_t n_reads, ui
     return LIME_OK;
 }
 
+// Device memory -> freshly allocated pageable host memory (the (idRef, sim) lists: 0.7 GB when most of configs[2]'s rows pass): through two pinned
+// slots, the copy of piece k + 1 under the host's copy of piece k by the staging threads.  The runtime's own staged copy does this on one thread,
+// first-touch page faults included: 0.7 GB took 170 ms = 4 GB/s.
+static int d2h_pageable(void *dst, const void *d_src, size_t bytes, hipStream_t st)
+{
+    constexpr size_t SLOT = (size_t)8 << 20, PIECE = (size_t)1 << 20;
+    if (bytes < 4 * SLOT || getenv("LIME_NO_STAGING") || Feeder::pinned(dst)) {     // (pinned destinations: the copy engine writes them directly)
+        HIP_TRY(hipMemcpyAsync(dst, d_src, bytes, hipMemcpyDeviceToHost, st));
+        HIP_TRY(hipStreamSynchronize(st));
+        return LIME_OK;
+    }
+    struct Ring {
+        void *slot[2] = {nullptr, nullptr}; hipEvent_t ev[2] = {nullptr, nullptr};
+        ~Ring() { for (int i = 0; i < 2; ++i) { if (slot[i]) (void)hipHostFree(slot[i]); if (ev[i]) (void)hipEventDestroy(ev[i]); } }
+    } r;
+    for (int i = 0; i < 2; ++i) { HIP_TRY(hipHostMalloc(&r.slot[i], SLOT)); HIP_TRY(hipEventCreateWithFlags(&r.ev[i], hipEventDisableTiming)); }
+    int threads = 8;
+    if (const char *e = getenv("LIME_IO_THREADS")) { const int v = atoi(e); if (v >= 1) threads = v > 64 ? 64 : v; }
+    { const unsigned hw = std::thread::hardware_concurrency(); if (hw && (unsigned)threads > hw) threads = (int)hw; }
+    IoPool pool;
+    if (threads > 1) pool.start(threads);
+    const size_t n_chunks = (bytes + SLOT - 1) / SLOT;
+    auto len_of = [&](size_t k) { return k + 1 < n_chunks ? SLOT : bytes - k * SLOT; };
+    for (size_t k = 0; k <= n_chunks; ++k) {
+        if (k < n_chunks) {
+            HIP_TRY(hipMemcpyAsync(r.slot[k & 1], static_cast<const uint8_t *>(d_src) + k * SLOT, len_of(k), hipMemcpyDeviceToHost, st));
+            HIP_TRY(hipEventRecord(r.ev[k & 1], st));
+        }
+        if (k >= 1) {                                      // (slot (k - 1) & 1 is written again by copy k + 1, issued after this returns)
+            const size_t j = k - 1, len = len_of(j);
+            HIP_TRY(hipEventSynchronize(r.ev[j & 1]));
+            std::vector<IoPool::Task> t;
+            for (size_t o = 0; o < len; o += PIECE)
+                t.push_back({static_cast<uint8_t *>(dst) + j * SLOT + o, static_cast<const uint8_t *>(r.slot[j & 1]) + o, len - o < PIECE ? len - o : PIECE});
+            pool.run(std::move(t));
+        }
+    }
+    return LIME_OK;
+}
+
+static int ensure_choose(lime_ctx *c, size_t dev_bytes, size_t host_bytes, hipStream_t st)
+{
+    int rc;
+    if (dev_bytes > c->choose_cap) {
+        HIP_TRY(hipStreamSynchronize(st)); c->choose_cap = 0;
+        if ((rc = regrow(c->d_choose, dev_bytes))) return rc;
+        c->choose_cap = dev_bytes;
+    }
+    if (host_bytes > c->h_choose_cap) {
+        if (c->h_choose) { (void)hipHostFree(c->h_choose); c->h_choose = nullptr; c->h_choose_cap = 0; }
+        HIP_TRY(hipHostMalloc(&c->h_choose, host_bytes));
+        c->h_choose_cap = host_bytes;
+    }
+    return LIME_OK;
+}
+// the reference's test `float(max) / norm > beta`, in the reference's types (ClusterBWT_DA.cpp:404-406), once for each of the 256 values a row's
+// maximum takes instead of once per read
+static void choose_pass_table(uint32_t norm, float beta, bool pass[256])
+{
+    for (uint32_t v = 0; v < 256u; ++v) {
+        const uint8_t mx = (uint8_t)v;
+        const float top = static_cast<float>(mx) / norm;
+        pass[v] = top > beta;
+    }
+}
+
 // clusterChoose on the device, compact results to the host
 extern "C" int lime_choose_pairs_dev(lime_ctx *c, const uint8_t *d_sim, uint32_t n_reads, uint32_t n_refs,
                                      uint32_t norm, float beta, uint8_t *row_max, uint64_t *row_off,
@@ -1719,21 +1793,23 @@ extern "C" int lime_choose_pairs_dev(lime_ctx *c, const uint8_t *d_sim, uint32_t
     if (!n_reads) return LIME_OK;
     if (misaligned(d_sim, 16)) return fail(LIME_ERR_ARG, "lime_choose_pairs_dev: d_sim must be 16-byte aligned (and lime_sim_bytes() long)");
     hipStream_t st = (hipStream_t)stream;
-    DevBuf dm, dz, doff, dp;
-    if ((rc = dm.alloc(n_reads))) return rc;
-    if ((rc = dz.alloc((size_t)n_reads * 4))) return rc;
-    launch_choose(d_sim, n_reads, n_refs, (uint8_t *)dm.p, (uint32_t *)dz.p, st);
+    DevBuf doff, dp;
+    const size_t nz_off = ((size_t)n_reads + 15u) & ~(size_t)15u;      // row non-zero counts behind the row maxima, in both buffers
+    if ((rc = ensure_choose(c, nz_off + (size_t)n_reads * 4, nz_off + (size_t)n_reads * 4, st))) return rc;
+    launch_choose(d_sim, n_reads, n_refs, c->d_choose, reinterpret_cast<uint32_t *>(c->d_choose + nz_off), st);
     HIP_TRY(hipGetLastError());
-    std::vector<uint32_t> nnz(n_reads);
-    HIP_TRY(hipMemcpyAsync(row_max, dm.p, n_reads, hipMemcpyDeviceToHost, st));
-    HIP_TRY(hipMemcpyAsync(nnz.data(), dz.p, (size_t)n_reads * 4, hipMemcpyDeviceToHost, st));
+    HIP_TRY(hipMemcpyAsync(c->h_choose, c->d_choose, nz_off + (size_t)n_reads * 4, hipMemcpyDeviceToHost, st));
     HIP_TRY(hipStreamSynchronize(st));
-    // the reference's test, in the reference's types (ClusterBWT_DA.cpp:404-406)
+    const uint8_t *hmx = static_cast<const uint8_t *>(c->h_choose);
+    const uint32_t *nnz = reinterpret_cast<const uint32_t *>(hmx + nz_off);
+    bool pass[256];
+    choose_pass_table(norm, beta, pass);
     uint64_t total = 0;
     for (uint32_t r = 0; r < n_reads; ++r) {
-        const float top = static_cast<float>(row_max[r]) / norm;
+        const uint8_t mx = hmx[r];
+        row_max[r] = mx;
         row_off[r] = total;
-        if (top > beta) total += nnz[r];
+        if (pass[mx]) total += nnz[r];
     }
     row_off[n_reads] = total;
     *n_pairs = total;
@@ -1744,9 +1820,7 @@ extern "C" int lime_choose_pairs_dev(lime_ctx *c, const uint8_t *d_sim, uint32_t
     HIP_TRY(hipGetLastError());
     lime_pair_t *h = (lime_pair_t *)malloc((size_t)total * sizeof(lime_pair_t));
     if (!h) return fail(LIME_ERR_NOMEM, "lime_choose_pairs_dev: out of host memory");
-    hipError_t e = hipMemcpyAsync(h, dp.p, (size_t)total * sizeof(lime_pair_t), hipMemcpyDeviceToHost, st);
-    if (e == hipSuccess) e = hipStreamSynchronize(st);
-    if (e != hipSuccess) { free(h); return fail(LIME_ERR_HIP, "hipMemcpy: %s", hipGetErrorString(e)); }
+    if ((rc = d2h_pageable(h, dp.p, (size_t)total * sizeof(lime_pair_t), st))) { free(h); return rc; }
     *pairs = h;
     return LIME_OK;
 }
@@ -1796,17 +1870,19 @@ extern "C" int lime_fused_choose_dev(lime_ctx *c, const uint32_t *d_lcp, const u
     HIP_TRY(hipStreamSynchronize(st));
     if (nb > c->bigrec_cap) return fail(LIME_ERR_NOMEM, "more update records of long clusters (%u) than their list holds (%u)", nb, c->bigrec_cap);
     const uint32_t n_regions = (uint32_t)((sim_bytes + ((size_t)1 << REGION_SHIFT) - 1) >> REGION_SHIFT);
-    DevBuf dmax, dnnz, dlast, drr, bcnt, bcur, boff, bout, doff, dp;
-    if ((rc = dmax.alloc((size_t)n_reads * 4)) || (rc = dnnz.alloc((size_t)n_reads * 4)) || (rc = dlast.alloc((size_t)n_regions * 4)) ||
-        (rc = drr.alloc((size_t)n_regions * 16))) return rc;
-    HIP_TRY(hipMemsetAsync(dmax.p, 0, (size_t)n_reads * 4, st));
-    HIP_TRY(hipMemsetAsync(dnnz.p, 0, (size_t)n_reads * 4, st));
+    DevBuf bcnt, bcur, boff, bout, doff, dp;
+    // the ctx's scratch: [region words 16 R][row max 4 n][row nnz 4 n][last nnz 4 R]; the rows' two arrays come back in one copy
+    const size_t rows_off = (size_t)n_regions * 16, rows_bytes = (size_t)n_reads * 8, last_off = rows_off + rows_bytes;
+    if ((rc = ensure_choose(c, last_off + (size_t)n_regions * 4, rows_bytes, st))) return rc;
+    uint32_t *dmax = reinterpret_cast<uint32_t *>(c->d_choose + rows_off), *dnnz = dmax + n_reads;
+    void *drr = c->d_choose;
+    HIP_TRY(hipMemsetAsync(dmax, 0, rows_bytes, st));
     ApplyFin fin;
     memset(&fin, 0, sizeof fin);
     fin.n_refs = n_refs; fin.table_bytes = (uint64_t)n_reads * n_refs;
-    fin.row_max = (uint32_t *)dmax.p; fin.row_nnz = (uint32_t *)dnnz.p; fin.last_nnz = (uint32_t *)dlast.p;
-    fin.region_rows = (const uint4 *)drr.p;
-    launch_region_rows(n_regions, n_refs, fin.table_bytes, nullptr, drr.p, st);
+    fin.row_max = dmax; fin.row_nnz = dnnz; fin.last_nnz = reinterpret_cast<uint32_t *>(c->d_choose + last_off);
+    fin.region_rows = (const uint4 *)drr;
+    launch_region_rows(n_regions, n_refs, fin.table_bytes, nullptr, drr, st);
     if (nb) {
         if ((rc = bcnt.alloc((size_t)n_regions * 4)) || (rc = bcur.alloc((size_t)n_regions * 4)) || (rc = boff.alloc(((size_t)n_regions + 1) * 8)) ||
             (rc = bout.alloc((size_t)nb * 8))) return rc;
@@ -1818,16 +1894,17 @@ extern "C" int lime_fused_choose_dev(lime_ctx *c, const uint32_t *d_lcp, const u
     launch_sort_tiles(c->d_recs, c->d_binbase, n_bins, bin_shift, c->d_tbase, c->d_tidx, rows, st, expect >= 1e8);
     launch_apply_tiles_fin(1, sim_bytes, bin_shift, c->d_tbase, c->d_tidx, rows, expect >= 2e8, fin, st);
     HIP_TRY(hipGetLastError());
-    std::vector<uint32_t> hm(n_reads), hz(n_reads);
-    HIP_TRY(hipMemcpyAsync(hm.data(), dmax.p, (size_t)n_reads * 4, hipMemcpyDeviceToHost, st));
-    HIP_TRY(hipMemcpyAsync(hz.data(), dnnz.p, (size_t)n_reads * 4, hipMemcpyDeviceToHost, st));
+    HIP_TRY(hipMemcpyAsync(c->h_choose, dmax, rows_bytes, hipMemcpyDeviceToHost, st));
     HIP_TRY(hipStreamSynchronize(st));
+    const uint32_t *hm = static_cast<const uint32_t *>(c->h_choose), *hz = hm + n_reads;
+    bool pass[256];
+    choose_pass_table(norm, beta, pass);                         // the reference's test, in the reference's types (ClusterBWT_DA.cpp:404-406)
     uint64_t total = 0;
-    for (uint32_t r = 0; r < n_reads; ++r) {                     // the reference's test, in the reference's types (ClusterBWT_DA.cpp:404-406)
-        row_max[r] = (uint8_t)hm[r];
-        const float top = static_cast<float>(row_max[r]) / norm;
+    for (uint32_t r = 0; r < n_reads; ++r) {
+        const uint8_t mx = (uint8_t)hm[r];
+        row_max[r] = mx;
         row_off[r] = total;
-        if (top > beta) total += hz[r];
+        if (pass[mx]) total += hz[r];
     }
     row_off[n_reads] = total;
     *n_pairs = total;
@@ -1835,14 +1912,12 @@ extern "C" int lime_fused_choose_dev(lime_ctx *c, const uint32_t *d_lcp, const u
     if ((rc = doff.upload(row_off, ((size_t)n_reads + 1) * 8))) return rc;
     if ((rc = dp.alloc((size_t)total * sizeof(lime_pair_t)))) return rc;
     fin.row_off = (const uint64_t *)doff.p; fin.pairs = (lime_pair_t *)dp.p;
-    launch_region_rows(n_regions, n_refs, fin.table_bytes, fin.row_off, drr.p, st);          // (now with the regions that have nothing to gather marked)
+    launch_region_rows(n_regions, n_refs, fin.table_bytes, fin.row_off, drr, st);          // (now with the regions that have nothing to gather marked)
     launch_apply_tiles_fin(2, sim_bytes, bin_shift, c->d_tbase, c->d_tidx, rows, expect >= 2e8, fin, st);
     HIP_TRY(hipGetLastError());
     lime_pair_t *h = (lime_pair_t *)malloc((size_t)total * sizeof(lime_pair_t));
     if (!h) return fail(LIME_ERR_NOMEM, "lime_fused_choose_dev: out of host memory");
-    hipError_t e = hipMemcpyAsync(h, dp.p, (size_t)total * sizeof(lime_pair_t), hipMemcpyDeviceToHost, st);
-    if (e == hipSuccess) e = hipStreamSynchronize(st);
-    if (e != hipSuccess) { free(h); return fail(LIME_ERR_HIP, "hipMemcpy: %s", hipGetErrorString(e)); }
+    if ((rc = d2h_pageable(h, dp.p, (size_t)total * sizeof(lime_pair_t), st))) { free(h); return rc; }
     *pairs = h;
     return LIME_OK;
 }
@@ -1860,7 +1935,7 @@ extern "C" int lime_score_choose(lime_ctx *c, const uint32_t *da, const uint8_t 
     if ((rc = score_in_chunks(c, da, ebwt, n, clusters, n_clusters, n_reads, n_refs, (uint8_t *)ds.p))) return rc;
     if ((rc = lime_choose_pairs_dev(c, (const uint8_t *)ds.p, n_reads, n_refs, norm, beta, row_max, row_off, pairs,
                                     n_pairs, nullptr))) return rc;
-    if (sim) HIP_TRY(hipMemcpy(sim, ds.p, (size_t)n_reads * n_refs, hipMemcpyDeviceToHost));
+    if (sim && (rc = d2h_pageable(sim, ds.p, (size_t)n_reads * n_refs, nullptr))) return rc;
     return LIME_OK;
 }
 
