@@ -25,7 +25,10 @@ class _LibBuf:
         self.__array_interface__ = {"data": (ptr, False), "shape": (words,), "typestr": "<u4", "version": 3}
 
     def __del__(self):
-        self._lib.lime_free(C.c_void_p(self._ptr))
+        try:
+            self._lib.lime_free(C.c_void_p(self._ptr))
+        except Exception:        # interpreter shutdown: the library handle may be gone before the last array
+            pass
 
 
 class Context:
