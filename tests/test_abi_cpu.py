@@ -146,3 +146,25 @@ def test_scan_resources():
         pytest.skip("no hipcc")
     r = subprocess.run(["make", "-C", os.path.join(ROOT, "lime_amd", "csrc"), "-s", "resources"], capture_output=True, timeout=600)
     assert r.returncode == 0, r.stdout.decode()[-2000:]
+
+
+def test_library_buffers_become_arrays_without_a_copy_and_are_freed_with_the_last_view():
+    """lime_amd.api._LibBuf (the (idRef, sim) lists of clusterChoose come back as the library's own buffer): the array sees the buffer's words,
+    is writable, and lime_free runs exactly once, when the last view dies"""
+    from lime_amd import api
+    libc = C.CDLL(None)
+    libc.malloc.restype = C.c_void_p; libc.malloc.argtypes = [C.c_size_t]; libc.free.argtypes = [C.c_void_p]
+    freed = []
+
+    class Lib:
+        def lime_free(self, p):
+            freed.append(p.value); libc.free(p)
+    ptr = libc.malloc(80)
+    C.memmove(ptr, (C.c_uint32 * 20)(*range(20)), 80)
+    a = np.asarray(api._LibBuf(Lib(), ptr, 20)).reshape(10, 2)
+    assert a.dtype == np.uint32 and a.flags.writeable and a[3, 1] == 7 and a.ctypes.data == ptr
+    b = a[2:4]
+    del a
+    assert not freed and b.sum() == 4 + 5 + 6 + 7
+    del b
+    assert freed == [ptr]

@@ -138,6 +138,11 @@ def test_choose_without_the_table_at_full_size(monkeypatch, shape):
             mx, off, pairs, s = c.fused_choose_dev(lcp, da, eb, n, nr, ng, 16, 85, 0.03)      # max >= 3 passes
             res.append((mx, off, pairs, s.n_updates, s.n_clusters))
         assert c.host_times()["choose_without_table"] == 1
+        # the caller's result arrays (`out=`), dirty on entry: the same rows, and the pair list is the library's buffer itself (no copy)
+        outs = (np.full(nr + 1, 0xAB, dtype=np.uint8), np.full(nr + 2, 0xCDCDCDCD, dtype=np.uint64))
+        mx2, off2, pairs2, _ = c.fused_choose_dev(lcp, da, eb, n, nr, ng, 16, 85, 0.03, out=outs)
+        assert mx2.base is outs[0] and off2.base is outs[1] and pairs2.base is not None
+        assert np.array_equal(mx2, res[1][0]) and np.array_equal(off2, res[1][1]) and np.array_equal(pairs2, res[1][2])
     finally:
         c.close()
     assert res[0][3] == res[1][3] and res[0][4] == res[1][4]
