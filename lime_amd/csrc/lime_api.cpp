@@ -1891,7 +1891,7 @@ extern "C" int lime_fused_choose_dev(lime_ctx *c, const uint32_t *d_lcp, const u
     }
     const double expect = (double)s.n_updates;
     uint16_t *rows = reinterpret_cast<uint16_t *>(c->d_pool);
-    launch_sort_tiles(c->d_recs, c->d_binbase, n_bins, bin_shift, c->d_tbase, c->d_tidx, rows, st, expect >= 1e8);
+    launch_sort_tiles(c->d_recs, c->d_binbase, n_bins, bin_shift, c->d_tbase, c->d_tidx, rows, st, expect >= 1e8);      // (k_tile_bases inside: the pass stopped at the records and numbered no tiles)
     launch_apply_tiles_fin(1, sim_bytes, bin_shift, c->d_tbase, c->d_tidx, rows, expect >= 2e8, fin, st);
     HIP_TRY(hipGetLastError());
     HIP_TRY(hipMemcpyAsync(c->h_choose, dmax, rows_bytes, hipMemcpyDeviceToHost, st));
