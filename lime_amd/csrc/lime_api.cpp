@@ -371,7 +371,10 @@ static bool want_binned(const lime_ctx *c, uint64_t n_own, size_t sim_bytes, int
     // HBM at ~20 G/s while a record costs the later kernels ~7 ps (10^10 symbols: 1 GB table 26.7 ms against 18.4 binned,
     // configs[4]'s 10.3 GB table 31.5 against 20.8, configs[3]'s shape 8.3 against 7.6) -- worth ~0.3 ms of extra launches
     // from about 5 million records on.
-    if (c->density_known) return sim_bytes > (256u << 20) ? c->density * (double)n_own >= 5e6 : c->density >= 0.06;
+    // (round 5, EBWT=1 and a cached table: the compare-and-swap scan runs 12 waves per CU, the record-emitting one 16 -- 0.223 against 0.190 ms
+    // per 10^8 symbols -- and the binned pass's fixed launches are 45 us since two of them were merged: level at 10^8 symbols (0.242 : 0.244 ms),
+    // binned ahead from there on whatever the density -- 2*10^8: 0.414 against 0.44-0.456, tools/r05_c2_paths.sh)
+    if (c->density_known) return sim_bytes > (256u << 20) ? c->density * (double)n_own >= 5e6 : (c->density >= 0.06 || (ebwt && n_own >= 150000000ull));
     // Nothing known yet (a first pass too short for the density probe to pay -- below 2^28 symbols its fixed 0.13 ms is a third to a half of the
     // pass --, or LIME_NO_PROBE): binned.  It is the path that loses little where it loses (configs[1], 0.03 records per symbol: 0.29 against
     // 0.24 ms) and wins much where it wins (the same shape at 0.17: 0.40 against 0.85 ms; text statistics: 0.56 against 4.3 ms); rounds 2-4 took
