@@ -15,8 +15,12 @@ collection of 10^10 symbols (10^6 reads x 1000 genomes, EBWT=0) cut into contigu
 with a read-ahead halo; a step = every rank's pass over its range + the ONE exchange of the path, a reduce-scatter of
 the per-rank uint8 tables (sum modulo 256, by read-row blocks) issued through the C ABI (lime_comm_*: RCCL
 ncclReduceScatter(ncclUint8, ncclSum)); the step ends when the exchange has completed (exposed -- what a single pass
-pays).  `also.overlapped` repeats the series with the exchange of step k running under the scan of step k+1 (two
-table buffers), which is what the four passes of LiME_paired.sh allow.  `--scaling weak` keeps configs[2] per GPU.
+pays).  The same invocation repeats the series three more times: `also.overlapped` (the exchange of step k under the scan of
+step k+1, two table buffers -- what the four passes of LiME_paired.sh allow), `also.sparse_exchange` (owner-partitioned
+exchange of the update records instead of whole tables) and `also.auto` (whichever of the two a probe pass says moves fewer
+bytes); every entry carries the slowest rank's parts of a pass and the exchange's own time, and the line carries RCCL's
+own rank count (ncclCommCount) and the result of the start-up check that its uint8 sum wraps.  `--scaling weak` keeps
+configs[2] per GPU.
 
 Prints ONE JSON line on rank 0 (the driver's contract) with two extra objects:
   roofline     HBM bound: algorithmic bytes (8 or 9 B/symbol x symbols per launch) / average duration of the scan
@@ -127,8 +131,13 @@ def cpu_baseline(wl, lcp_t, da_t, eb_t, n, sample_n, full=True):
         base = os.path.join(td, "S.fasta")
         do_full = full and n <= 1_000_000_000 and n > sample_n
         to_files(base, n if do_full else sample_n)
+        match = None
         if do_full:
             runs["four_threads_whole_workload"] = run(td, base, n, min(4, cores))
+            try:                                       # the reference has just written its outputs for the whole workload: compare them
+                match = reference_outputs_match(td, base, wl, lcp_t, da_t, eb_t, n, 0.25)
+            except Exception as e:
+                match = {"all": False, "failed": str(e)}
             for ext in (".lcp", ".da", ".ebwt"):       # cut the files down to the sample for the other two points
                 if os.path.exists(base + ext):
                     os.truncate(base + ext, sample_n * (1 if ext == ".ebwt" else 4))
@@ -142,7 +151,58 @@ def cpu_baseline(wl, lcp_t, da_t, eb_t, n, sample_n, full=True):
                       "; wall time of the reference's ClusterLCP + ClusterBWT_DA processes (files in page cache; ClusterBWT_DA's wall includes "
                       "allocating/zeroing the table and the single-threaded clusterChoose); the other thread counts ran on the first "
                       f"{sample_n} symbols (runs.*; their fixed table set-up weighs more there: see symbols_per_s_scan_and_analyze)",
-            "nproc": os.cpu_count(), "affinity_cpus": len(aff), "runs": runs}
+            "nproc": os.cpu_count(), "affinity_cpus": len(aff), "runs": runs,
+            # the reference's own output files of that whole-workload run, byte for byte against this library on the same arrays (None: no whole-workload run)
+            "reference_outputs_match": None if match is None else match["all"], "reference_outputs": match}
+
+
+def reference_outputs_match(td, base, wl, lcp_t, da_t, eb_t, n, beta):
+    """The files the reference's programs have just written for the WHOLE workload (cpu_baseline pays for that run anyway) against this
+    library on the same arrays: <base>.out (28 bytes), the .clrs records (the reference's record order is its threads' arrival order,
+    ClusterLCP.cpp:229-235: sorted by pStart first), .res.bin / .res.pos through lime_fused_choose_dev + lime_write_res_bin_pairs with and
+    without the table.  -> dict of booleans + "all"."""
+    import struct
+    import numpy as np
+    import torch
+    import lime_amd
+    from lime_amd import _lib
+    out = {}
+    nr, ng, norm = wl["nr"], wl["ng"], 100 + 1 - ALPHA
+    lib = _lib.load()
+    c = lime_amd.Context()
+    try:
+        ptr, nc, ml = c.detect_dev(lcp_t, da_t, n, n, True, 0, nr, ALPHA)
+        ref_out = open(os.path.join(td, "S.out"), "rb").read()
+        out["out_file"] = struct.pack("<IIIQQ", nr, ng, ALPHA, ml, nc) == ref_out
+        ref = np.fromfile(f"{base}.{ALPHA}.clrs", dtype="<u8").reshape(-1, 2)
+        ok = len(ref) == nc
+        if ok:
+            ref = ref[np.argsort(ref[:, 0], kind="stable")]
+            rec = torch.empty((nc, 2), dtype=torch.int64, device=lcp_t.device)
+            ok = _lib.hip_memcpy_d2d(rec.data_ptr(), ptr, nc * 16) == 0
+            for lo in range(0, nc, 1 << 25):
+                hi = min(nc, lo + (1 << 25))
+                ok = ok and bool(np.array_equal(rec[lo:hi].cpu().numpy().view(np.uint64), ref[lo:hi]))
+            del rec
+        out["clrs_records"] = bool(ok)
+        del ref
+        beta32 = float(np.float32(beta))
+        for free in ("1", "0"):
+            c.set_option("choose_free", free)
+            mx, off, pairs, s = c.fused_choose_dev(lcp_t, da_t, eb_t, n, nr, ng, ALPHA, norm, beta32)
+            mxp = np.zeros(nr + 1, np.uint8); mxp[:nr] = mx
+            offp = np.ascontiguousarray(off, dtype=np.uint64); pb = np.ascontiguousarray(pairs)
+            gb, gp = os.path.join(td, "got.bin"), os.path.join(td, "got.pos")
+            rc = lib.lime_write_res_bin_pairs(gb.encode(), gp.encode(), mxp.ctypes.data, offp.ctypes.data, pb.ctypes.data if len(pb) else None, nr, norm, beta32)
+            same = rc == 0
+            for a, b in ((gb, base + ".res.bin"), (gp, base + ".res.pos")):
+                same = same and os.path.getsize(a) == os.path.getsize(b) and open(a, "rb").read() == open(b, "rb").read()
+            out["res_files_" + ("without_table" if free == "1" else "with_table")] = bool(same)
+            del mx, off, pairs, pb
+    finally:
+        c.close()
+    out["all"] = all(out.values())
+    return out
 
 
 def run_pass_series(torch, lime_amd, ldist, wl, n_total, steps, warmup, world, rank, dev, comm, overlap, exchange="dense"):
@@ -199,6 +259,17 @@ def run_pass_series(torch, lime_amd, ldist, wl, n_total, steps, warmup, world, r
         ctx.synth_dev(SEED, lo, n_avail, wl["nr"], wl["ng"], ALPHA, wl["mode"], lcp, da, eb, stream)
     torch.cuda.synchronize()
     counter = [0]
+    ex_events = []                             # (start, end) around every exchange of the timed steps, on the stream it runs on
+
+    def timed_exchange(fn, on_stream=None):
+        if not ex_timing[0]:
+            return fn()
+        st_ = on_stream if on_stream is not None else torch.cuda.current_stream()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record(st_); r_ = fn(); e1.record(st_)
+        ex_events.append((e0, e1))
+        return r_
+    ex_timing = [False]
 
     def step():
         b = counter[0] % nbuf
@@ -212,7 +283,7 @@ def run_pass_series(torch, lime_amd, ldist, wl, n_total, steps, warmup, world, r
             _s, _rc = ctx.stats(stream)
             if _rc:
                 sys.exit(f"scan failed: rc={_rc}")
-            comm.exchange_records(ctx, wl["nr"], wl["ng"], own_block, stream)
+            timed_exchange(lambda: comm.exchange_records(ctx, wl["nr"], wl["ng"], own_block, stream))
             return
         ctx.fused_dev(lcp, da, eb, n_own, n_avail, hi_halo == n_total, wl["nr"], wl["ng"], ALPHA, sims[b], True, stream)
         if world > 1:
@@ -222,11 +293,11 @@ def run_pass_series(torch, lime_amd, ldist, wl, n_total, steps, warmup, world, r
             if _rc:
                 sys.exit(f"scan failed: rc={_rc}")
             if ex_stream is None:              # exposed: the exchange follows the pass on the same stream
-                comm.reduce_scatter_tables(sims[b], blks[b], blk_bytes, stream)
+                timed_exchange(lambda: comm.reduce_scatter_tables(sims[b], blks[b], blk_bytes, stream))
             else:                              # overlapped: on its own stream, under the next step's scan
                 ev = torch.cuda.Event(); ev.record()
                 ex_stream.wait_event(ev)
-                comm.reduce_scatter_tables(sims[b], blks[b], blk_bytes, ex_stream.cuda_stream)
+                timed_exchange(lambda: comm.reduce_scatter_tables(sims[b], blks[b], blk_bytes, ex_stream.cuda_stream), ex_stream)
                 done[b] = torch.cuda.Event(); done[b].record(ex_stream)
 
     def barrier():
@@ -260,12 +331,15 @@ def run_pass_series(torch, lime_amd, ldist, wl, n_total, steps, warmup, world, r
         step()
     s, rc = ctx.stats(stream)
     ctx.set_timing(True)
+    ex_timing[0] = world > 1
     barrier()
     t0 = time.perf_counter()
     for _ in range(steps):
         step()
     barrier()
     dt = time.perf_counter() - t0
+    ex_timing[0] = False
+    exchange_ms = sum(a.elapsed_time(b) for a, b in ex_events) / len(ex_events) if ex_events else None
     parts, launches = ctx.get_timing_ex()
     # the same passes once more, one at a time (HIP events around each): median and minimum next to the mean of the timed region
     each = []
@@ -282,38 +356,38 @@ def run_pass_series(torch, lime_amd, ldist, wl, n_total, steps, warmup, world, r
         ht = ctx.host_times()
         cold["repeated_passes_after_cold"] = ht["repeats"] - cold["repeated_passes"]
     each.sort()
-    res = {"exchange": exchange, "dt": dt, "parts": parts, "cold": cold, "flags": int(s.flags),
+    res = {"exchange": exchange, "dt": dt, "parts": parts, "exchange_ms": exchange_ms, "cold": cold, "flags": int(s.flags),
            "pass_ms_each": {"n": len(each), "median": each[len(each) // 2], "min": each[0], "max": each[-1]} if each else None, "launches": launches, "n_own": n_own, "n_clusters": int(s.n_clusters), "max_len": int(s.max_len),
            "updates": int(s.n_updates), "binned": bool(s.wave_records_max > 0), "wave_records_max": int(s.wave_records_max), "lcp": lcp, "da": da, "eb": eb}
     ctx.close()
     return res
 
 
-def choose_flow(torch, lime_amd, dev):
-    """The device side of the reference's whole ClusterBWT_DA on configs[2]: the scoring pass + clusterChoose (ClusterBWT_DA.cpp:360-452: row
-    maxima, the float test against beta, the surviving (idRef, sim) pairs on the host) through lime_fused_choose_dev, with the table in HBM
-    (pass -> k_choose -> k_gather_pairs) and without it (the second-level kernel keeps row max / nnz and gathers the pairs from LDS).
+def choose_flow(torch, lime_amd, dev, wname="c3"):
+    """The device side of the reference's whole ClusterBWT_DA: the scoring pass + clusterChoose (ClusterBWT_DA.cpp:360-452: row maxima, the float
+    test against beta, the surviving (idRef, sim) pairs on the host) through lime_fused_choose_dev, with the table in HBM (pass -> k_choose ->
+    k_gather_pairs) and without it (the second-level kernel keeps row max / nnz and gathers the pairs from LDS; option choose_free).
     Wall clock of the call, results on the host; min and median of three calls each, alternating."""
     import time
-    wl = WORKLOADS["c3"]
+    import numpy as np
+    wl = WORKLOADS[wname]
     n, nr, ng = wl["n"], wl["nr"], wl["ng"]
     ctx = lime_amd.Context()
     lcp = torch.empty(n, dtype=torch.int32, device=dev); da = torch.empty_like(lcp)
-    ctx.synth_dev(SEED, 0, n, nr, ng, ALPHA, wl["mode"], lcp, da, None)
-    res = {"workload": "BASELINE.json configs[2] through lime_fused_choose_dev (norm 85): scan + clusterAnalyze + clusterChoose, row maxima and pairs on the host; "
+    eb = torch.empty(n, dtype=torch.uint8, device=dev) if wl["ebwt"] else None
+    ctx.synth_dev(SEED, 0, n, nr, ng, ALPHA, wl["mode"], lcp, da, eb)
+    res = {"workload": f"{wl['what']} through lime_fused_choose_dev (norm 85): scan + clusterAnalyze + clusterChoose, row maxima and pairs on the host; "
                        "beta 0.25: no row of the iid generator passes (the finish is the row maxima); beta 0.02: every row with a cell >= 2 passes, its pairs cross PCIe",
            "unit": "ms per call (wall clock, host results included)"}
-    keep = os.environ.get("LIME_CHOOSE_FREE")
-    import numpy as np
     outs = (np.zeros(nr + 1, dtype=np.uint8), np.zeros(nr + 2, dtype=np.uint64))     # the caller's result arrays, as a C caller of the ABI holds them
     try:
         for beta in (0.25, 0.02):
             ms = {"0": [], "1": []}
             e = res["beta_%g" % beta] = {}
             for free in ("0", "1") * 4:                  # (the first call of each kind sizes its buffers: dropped)
-                os.environ["LIME_CHOOSE_FREE"] = free
+                ctx.set_option("choose_free", free)
                 torch.cuda.synchronize(); t0 = time.perf_counter()
-                rmx, roff, prs, st = ctx.fused_choose_dev(lcp, da, None, n, nr, ng, ALPHA, 85, beta, out=outs)
+                rmx, roff, prs, st = ctx.fused_choose_dev(lcp, da, eb, n, nr, ng, ALPHA, 85, beta, out=outs)
                 ms[free].append((time.perf_counter() - t0) * 1e3)
                 e["pairs"] = int(len(prs)); res["n_clusters"] = int(st.n_clusters)
                 del rmx, roff, prs
@@ -322,9 +396,7 @@ def choose_flow(torch, lime_amd, dev):
                 e[name] = {"min": round(v[0], 3), "median": round(v[len(v) // 2], 3), "symbols_per_s": n / (v[len(v) // 2] * 1e-3)}
             e["speedup_median"] = e["with_table"]["median"] / e["without_table"]["median"]
     finally:
-        if keep is None: os.environ.pop("LIME_CHOOSE_FREE", None)
-        else: os.environ["LIME_CHOOSE_FREE"] = keep
-    ctx.close(); del lcp, da
+        ctx.close(); del lcp, da, eb
     return res
 
 
@@ -334,7 +406,7 @@ def summarize(wl, r, n_total, steps):
     cold = dict(r["cold"]) if r.get("cold") else None
     if cold:
         steady = r["dt"] / steps * 1e3
-        cold["minus_alloc_over_steady"] = (cold["cold_ms"] - cold["alloc_ms"]) / steady if steady else None
+        cold["over_steady"] = cold["cold_ms"] / steady if steady else None      # WITH the allocations (alloc_ms is a part of cold_ms, not taken out)
     return {"workload": describe(wl, n_total, 1), "ms_per_step": r["dt"] / steps * 1e3, "symbols_per_s": n_total * steps / r["dt"],
             "pass_ms_each": r.get("pass_ms_each"), "cold": cold,
             "pass_frac_median": bps * r["n_own"] / r["pass_ms_each"]["median"] / 1e6 / HBM_PEAK_GBS if r.get("pass_ms_each") else None,
@@ -356,7 +428,7 @@ def main():
     ap.add_argument("--scaling", default=None, choices=["strong", "weak"], help="N>1: strong (fixed --n-total, default) or weak (workload per GPU)")
     ap.add_argument("--n-total", type=float, default=None, help="symbols of the whole collection (strong scaling)")
     ap.add_argument("--n", type=float, default=None, help="symbols per GPU (overrides the workload's size)")
-    ap.add_argument("--exchange", default=os.environ.get("LIME_BENCH_EXCHANGE", "dense"), choices=["dense", "sparse", "auto"],
+    ap.add_argument("--exchange", default="dense", choices=["dense", "sparse", "auto"],
                     help="N>1: dense = a uint8 reduce-scatter of whole tables (default); sparse = owner-partitioned exchange of update records; "
                          "auto = whichever moves fewer bytes for this workload (decided from a probe pass)")
     ap.add_argument("--no-cpu", action="store_true", help="skip the cpu_baseline leg")
@@ -364,9 +436,12 @@ def main():
     ap.add_argument("--cpu-sample", type=int, default=200_000_000)
     args = ap.parse_args()
 
-    for var in ("LIME_ABLATE", "LIME_MAX_BLOCKS", "LIME_POOL_DENSITY", "LIME_POOL_SLACK", "LIME_BIN_LEVELS"):
-        if os.environ.get(var):
-            sys.exit(f"bench.py refuses to run with {var} set: it changes what is measured")
+    # The library reads its tuning / test knobs from the environment only under LIME_TEST_HOOKS=1 (lime_init): with that set -- or with another
+    # build of the library (LIME_LIB), or ANY LIME_* variable this script does not know -- what is measured is not the release path
+    allowed = {"LIME_BENCH_BACKEND", "LIME_IO_THREADS"}
+    bad = sorted(k for k in os.environ if k.startswith("LIME_") and k not in allowed)
+    if bad:
+        sys.exit(f"bench.py refuses to run with {', '.join(bad)} set: it could change what is measured")
 
     import torch
     import lime_amd
@@ -386,7 +461,7 @@ def main():
         local = 0
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
-    comm = None
+    comm, comm_info = None, None
     if world > 1:
         import torch.distributed as dist
         if backend == "nccl":
@@ -395,7 +470,8 @@ def main():
         else:
             dist.init_process_group(backend)
             comm = ldist.HostComm(rank, world, dev)
-        comm.check_uint8_sum_wraps()
+        comm.check_uint8_sum_wraps()           # raises if RCCL's uint8 sum does not wrap modulo 256
+        comm_info = {"backend": backend, "world_size": world, "nccl_comm_count": comm.count(), "uint8_sum_wraps": True}
 
     scaling = args.scaling or "strong"         # the series is strong scaling (fixed 10^10 symbols); on one GPU the label says which series the line belongs to
     wname = args.workload or ("c3" if (world == 1 or scaling == "weak") else "n1e10")
@@ -410,6 +486,8 @@ def main():
         dt = comm.max_float(dt)
         n_clusters, max_len = comm.combine_counters(n_clusters, max_len)
 
+    slow_parts = {k_: comm.max_float(float(v_)) for k_, v_ in sorted(r["parts"].items())} if world > 1 else None
+    slow_ex = comm.max_float(float(r.get("exchange_ms") or 0.0)) if world > 1 else None
     out = None
     if rank == 0:
         bps = 8 + wl["ebwt"]
@@ -449,7 +527,7 @@ def main():
                          "pass_ms_avg": pass_ms, "pass_achieved": bps * r["n_own"] / (pass_ms * 1e-3) / 1e9 if pass_ms else None,
                          "pass_frac": bps * r["n_own"] / (pass_ms * 1e-3) / 1e9 / HBM_PEAK_GBS if pass_ms else None,
                          "pass_ms_each": r.get("pass_ms_each"), "cold": r.get("cold"),
-                         "pass_parts_ms": r["parts"]},
+                         "pass_parts_ms": r["parts"], "pass_parts_ms_slowest_rank": slow_parts, "exchange_ms_slowest_rank": slow_ex},
         }
     if world == 1 and rank == 0 and not args.no_cpu:
         try:
@@ -457,8 +535,21 @@ def main():
         except Exception as e:   # a missing baseline must not hide the GPU number
             out["cpu_baseline"] = {"value": None, "unit": "symbols/s", "cores": os.cpu_count(), "kind": "port", "sample": f"failed: {e}"}
     first_exchange = r["exchange"]
+    headline_parts, headline_ex_ms = r["parts"], r.get("exchange_ms")
     del r
-    torch.cuda.empty_cache()
+
+    def make_room(need_bytes):
+        # torch keeps the blocks of the workload before (and reuses them where they fit); they go back to the driver only when the next workload
+        # would not fit beside them.  Not for tidiness: on this platform memory that was freed is CLEARED by the driver inside the next hipMalloc
+        # that gets it, at about 30 GB/s (tools/alloc_bench.hip) -- freeing 90 GB of arrays in front of every workload made the
+        # library's first allocations of the next one take between 1 ms and 5 s (round 5's cold.alloc_ms)
+        free_b, _tot = torch.cuda.mem_get_info()
+        if free_b < need_bytes:
+            torch.cuda.empty_cache()
+            lime_amd.trim_cache()
+
+    def need_of(w):
+        return w["n"] * (8 + w["ebwt"]) + w["nr"] * w["ng"] + int(w["n"] * 0.45 * 8 * 1.7) + (4 << 30)
 
     if not args.no_also:
         also = {}
@@ -468,32 +559,48 @@ def main():
                     continue
                 w2 = WORKLOADS[name]
                 try:
+                    make_room(need_of(w2))
                     k = max(5, args.steps // 2) if w2["n"] >= 10_000_000_000 else 3 if name == "c4_shape" else max(10, args.steps)
                     r2 = run_pass_series(torch, lime_amd, ldist, w2, w2["n"], k, 2, 1, 0, dev, None, overlap=False)
                     also[name] = summarize(w2, r2, w2["n"], k)
                     del r2
                 except Exception as e:
                     also[name] = {"failed": str(e)}
-                torch.cuda.empty_cache()
-            try:
-                also["c3_with_choose"] = choose_flow(torch, lime_amd, dev)
-            except Exception as e:
-                also["c3_with_choose"] = {"failed": str(e)}
-            torch.cuda.empty_cache()
+            # scan + clusterAnalyze + clusterChoose with and without the table: configs[2], and the shape of configs[3] (setB2's 18.8 GB table,
+            # ClusterBWT_DA.cpp:385-443 would scan it single-threaded)
+            for name, key in (("c3", "c3_with_choose"), ("c4_shape", "c4_with_choose")):
+                try:
+                    make_room(need_of(WORKLOADS[name]) + WORKLOADS[name]["nr"] * WORKLOADS[name]["ng"])
+                    also[key] = choose_flow(torch, lime_amd, dev, name)
+                except Exception as e:
+                    also[key] = {"failed": str(e)}
         else:
-            r2 = run_pass_series(torch, lime_amd, ldist, wl, n_total, args.steps, args.warmup, world, rank, dev, comm, overlap=True)
-            dt2 = comm.max_float(r2["dt"])
-            also["overlapped"] = {"what": "the same series with the exchange of step k under the scan of step k+1 (two table buffers)",
-                                  "value": n_total * args.steps / dt2, "ms_per_step": dt2 / args.steps * 1e3}
-            del r2
-            if os.environ.get("LIME_BENCH_SPARSE") == "1" and first_exchange == "dense":
-                r3 = run_pass_series(torch, lime_amd, ldist, wl, n_total, args.steps, args.warmup, world, rank, dev, comm, overlap=False, exchange="sparse")
-                dt3 = comm.max_float(r3["dt"])
-                also["sparse_exchange"] = {"what": "the same series with the owner-partitioned exchange of update records instead of the dense reduce-scatter",
-                                           "value": n_total * args.steps / dt3, "ms_per_step": dt3 / args.steps * 1e3}
-                del r3
+            # N > 1, in this ONE invocation (the driver's scaling run is the only multi-GPU run there is): the dense reduce-scatter exposed (the
+            # headline above), the same overlapped, the owner-partitioned exchange of update records, and whichever of the two a probe pass picks
+            def series(overlap, exchange, what):
+                r_ = run_pass_series(torch, lime_amd, ldist, wl, n_total, args.steps, args.warmup, world, rank, dev, comm, overlap=overlap, exchange=exchange)
+                dt_ = comm.max_float(r_["dt"])
+                e_ = {"what": what, "exchange": r_["exchange"], "value": n_total * args.steps / dt_, "ms_per_step": dt_ / args.steps * 1e3,
+                      "parts_ms_slowest_rank": {k_: comm.max_float(float(v_)) for k_, v_ in sorted(r_["parts"].items())},
+                      "exchange_ms_slowest_rank": comm.max_float(float(r_["exchange_ms"] or 0.0)), "table_updates_rank0": r_["updates"]}
+                del r_
+                torch.cuda.empty_cache()
+                return e_
+            for key, overlap, exch, what in (
+                    ("overlapped", True, "dense", "the dense series with the exchange of step k under the scan of step k+1 (two table buffers)"),
+                    ("sparse_exchange", False, "sparse", "the series with the owner-partitioned exchange of update records instead of the dense reduce-scatter"),
+                    ("auto", False, "auto", "the series with the exchange a probe pass picks (dist.choose_exchange: 4 bytes x the largest update count of a rank against the table's bytes)")):
+                if exch == first_exchange and not overlap:
+                    continue
+                try:
+                    also[key] = series(overlap, exch, what)
+                except Exception as e:
+                    also[key] = {"failed": str(e)}
         if rank == 0:
             out["also"] = also
+    if rank == 0 and world > 1:
+        out["comm"] = comm_info
+        out["roofline"]["exchange_ms_rank0"] = headline_ex_ms
     if rank == 0:
         print(json.dumps(out), flush=True)
     if world > 1:

@@ -93,6 +93,20 @@ const char *lime_version(void);
 int  lime_device_count(void);            /* HIP devices visible to the process (0 if none) */
 int  lime_pick_device(unsigned salt);    /* the device with the most free memory (ties by salt, e.g. the pid): for
                                           * LiME_paired.sh's four concurrent ClusterLCP processes (:44-53) */
+/* Tuning and test knobs of a ctx, by name (value as text; "" = back to the library's own choice where that exists).  None changes a result;
+ * most pick which kernel variant or update path runs.  Not a stable interface -- lime_amd/csrc/lime_api.cpp:set_option is the list:
+ * update_path (cas|bin|auto), bin_levels ("one,two"), pool_density, pool_slack, scan_static_pct, second_level (tiles|sweeps), part_split, no_probe,
+ * probe_min, force_p64, p64_test_base, max_blocks, choose_free, apply_wide, sort_nt, part_lines, no_staging, force_staging, detect_chunk,
+ * score_chunk, force_rccl, io_threads, debug_stats, debug_alloc, poison_cache.
+ * The ENVIRONMENT is read by lime_init only: LIME_IO_THREADS (host staging threads; the reference's `threads` argument, ClusterLCP.cpp:73-84)
+ * always, and -- only when LIME_TEST_HOOKS=1 is set -- a LIME_<KNOB> variable per knob above (tests, experiments).  bench.py refuses to run
+ * under LIME_TEST_HOOKS. */
+int  lime_set_option(lime_ctx *ctx, const char *key, const char *value);
+/* Device blocks of 64 MB and more that the contexts of this process have released (lime_shutdown, scratch that was replaced by a larger block)
+ * stay with the library for the next context instead of going back to the driver: on this platform a hipMalloc that is served from recycled
+ * pages waits while the driver clears them (about 30 GB/s: seconds for a record pool).  At most a quarter of the device's
+ * memory is held; a failed allocation releases it.  lime_trim_cache gives everything back now; returns the bytes released. */
+size_t lime_trim_cache(void);
 
 /* ---- host-pointer API (pageable host arrays; the library stages them through HBM) ------ */
 
@@ -111,7 +125,11 @@ int lime_detect_to_file(lime_ctx *ctx, const uint32_t *lcp, const uint32_t *da, 
 /* The host-pointer entry points take arrays in pageable memory and stage them through pinned buffers on a few host threads.  When an array IS a
  * mapped file (the drop-in programs map fileFasta.lcp / .da / .ebwt / .clrs), registering the mapping lets those threads fill the pinned buffers with
  * pread() from `fd` instead of touching the mapping page by page (ClusterLCP.cpp:100-123 reads with one FILE* per thread).  The library keeps its
- * own duplicate of the descriptor until lime_unregister_file(base). */
+ * own duplicate of the descriptor until lime_unregister_file(base).
+ * Contract: `base` maps the file from offset 0 (byte k of the mapping = byte k of the file), `bytes` is at most the file's size, the caller does
+ * not write through the mapping (MAP_PRIVATE copies would be ignored: the FILE is read), registrations do not overlap, and the range is
+ * unregistered BEFORE it is unmapped -- a stale registration would make a later array at the same address read the old file.  A registration
+ * that breaks the checkable parts of this (size, overlap) is refused with LIME_ERR_ARG. */
 int  lime_register_file(const void *base, size_t bytes, int fd);
 void lime_unregister_file(const void *base);
 
@@ -163,9 +181,12 @@ size_t lime_sim_bytes(uint32_t n_reads, uint32_t n_refs);  /* n_reads*n_refs rou
  * belongs to the shard that owns its first position.  eof != 0: the arrays end at the true
  * end of the collection, so an open run closes at n_avail (ClusterLCP.cpp:244-245).
  * zero_sim != 0: clear d_sim first.  Counters: lime_get_stats.
- * Asynchronous on `stream`, except the FIRST pass on a ctx over 2^24 symbols or more: it is preceded by a sampled
- * density probe (1/64 .. 1/256 of the windows, counted only) that synchronises the stream once -- the update path and the
- * record pool are chosen from what it finds, so that the one pass LiME_paired.sh:62-68 runs lands right. */
+ * Asynchronous on `stream`, except the FIRST pass on a ctx over 2^28 symbols or more (option probe_min, floor 2^24): it is preceded by a
+ * sampled density probe (1/64 .. 1/256 of the windows, counted only) that synchronises the stream once -- the update path and the record pool
+ * are chosen from what it finds, so that the one pass LiME_paired.sh:62-68 runs lands right.  A first pass of fewer symbols runs without the
+ * probe, on the binned update path where the table allows it, with a record pool for 0.45 update records per owned symbol: 2 x 4 bytes x
+ * 0.45 x 1.25 x 1.35 = about 6 bytes of extra HBM per symbol until a pass has measured the density.
+ * Device memory taken on a pass's first call (scratch, record pool) is allocated synchronously: see lime_trim_cache for what that can cost. */
 int lime_fused_dev(lime_ctx *ctx, const uint32_t *d_lcp, const uint32_t *d_da,
                    const uint8_t *d_ebwt, uint64_t n_own, uint64_t n_avail, int eof,
                    uint32_t n_reads, uint32_t n_refs, uint32_t alpha,
@@ -279,6 +300,7 @@ typedef struct lime_comm lime_comm;
 int  lime_comm_unique_id(uint8_t id[LIME_COMM_ID_BYTES]);
 int  lime_comm_init(const uint8_t id[LIME_COMM_ID_BYTES], int rank, int world, lime_comm **out);
 void lime_comm_destroy(lime_comm *comm);
+int  lime_comm_count(lime_comm *comm, int *ranks);   /* ncclCommCount: the ranks RCCL counts in the communicator */
 const char *lime_comm_error(void);
 /* d_sim: world * block_bytes bytes (the table, zero padded); rank r receives block r of the sum in d_block
  * (ncclReduceScatter, ncclUint8, ncclSum).  Asynchronous on `stream`. */

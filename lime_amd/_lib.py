@@ -9,7 +9,9 @@ import ctypes as C
 import os
 
 _DIR = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_DIR, "liblime_hip.so")
+# LIME_LIB: another build of the library (ablation / timing variants of tools/*.sh) -- loaded INSTEAD of the installed one, which those scripts
+# used to overwrite; bench.py refuses to run with it
+LIB_PATH = os.environ.get("LIME_LIB") or os.path.join(_DIR, "liblime_hip.so")
 
 LIME_OK = 0
 ERR_ARG, ERR_HIP, ERR_NOMEM, ERR_MAXLEN, ERR_HALO, ERR_DOCID, ERR_IO = -1, -2, -3, -4, -5, -6, -7
@@ -49,6 +51,8 @@ SYMBOLS = {
     "lime_version": (C.c_char_p, []),
     "lime_device_count": (_i, []),
     "lime_pick_device": (_i, [C.c_uint]),
+    "lime_set_option": (_i, [_vp, C.c_char_p, C.c_char_p]),
+    "lime_trim_cache": (_sz, []),
     "lime_detect": (_i, [_vp, _vp, _vp, _u64, _u32, _u32, _pp, _pu64, _pu64]),
     "lime_detect_to_file": (_i, [_vp, _vp, _vp, _u64, _u32, _u32, C.c_char_p, _pu64, _pu64]),
     "lime_register_file": (_i, [_vp, _sz, _i]),
@@ -84,6 +88,7 @@ SYMBOLS = {
     "lime_comm_unique_id": (_i, [_vp]),
     "lime_comm_init": (_i, [_vp, _i, _i, _pp]),
     "lime_comm_destroy": (None, [_vp]),
+    "lime_comm_count": (_i, [_vp, C.POINTER(_i)]),
     "lime_comm_error": (C.c_char_p, []),
     "lime_comm_reduce_scatter_tables": (_i, [_vp, _vp, _vp, _sz, _vp]),
     "lime_comm_allreduce_tables": (_i, [_vp, _vp, _sz, _vp]),

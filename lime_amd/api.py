@@ -40,6 +40,10 @@ class Context:
         check(self.lib.lime_init(-1 if device is None else int(device), C.byref(h)))
         self.h = h
 
+    def set_option(self, key, value=""):
+        """a tuning / test knob of the ctx by name (lime_set_option; include/lime_hip.h lists them); "" = the library's own choice"""
+        check(self.lib.lime_set_option(self.h, str(key).encode(), str(value).encode()))
+
     def close(self):
         if self.h:
             self.lib.lime_shutdown(self.h)
@@ -243,6 +247,11 @@ def _ptr(t):
     if t is None:
         return None
     return C.c_void_p(t.data_ptr())
+
+
+def trim_cache():
+    """give the device blocks that closed contexts left with the library back to the driver (lime_trim_cache); returns the bytes released"""
+    return int(_lib.load().lime_trim_cache())
 
 
 def sim_bytes(n_reads, n_refs):

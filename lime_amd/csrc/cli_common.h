@@ -47,11 +47,13 @@ static inline int pick_device()
     return lime_pick_device((unsigned)getpid());
 }
 
-// the reference's `threads` argument: here the host threads that stage the files into pinned memory -- at least 8 (the scan is on the GPU; what
-// the host does is move the page cache to the link, about 3 GB/s per thread), more if the caller asks; LIME_IO_THREADS overrides
+// the reference's `threads` argument (ClusterLCP.cpp:73-84: the OpenMP team) is the CPU share the user grants the program: here it is the number of
+// host threads that stage the files into pinned memory (about 3 GB/s each; the scan itself is on the GPU) -- honoured as given, the library caps it
+// at the CPUs the process may run on.  LIME_IO_THREADS, if the user has set it, wins.  (Round 5 forced at least 8: a `threads 1` run on a shared
+// or quota-limited node was oversubscribed -- ADVICE r5.)
 static inline void io_threads_from_argv(int threads)
 {
-    if (threads < 8) threads = 8;
+    if (threads < 1) threads = 1;
     char buf[16]; snprintf(buf, sizeof buf, "%d", threads);
     setenv("LIME_IO_THREADS", buf, 0);
 }

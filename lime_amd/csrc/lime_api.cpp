@@ -11,6 +11,8 @@
 #include <stdlib.h>
 #include <string.h>
 #include <unistd.h>
+#include <sched.h>
+#include <sys/stat.h>
 #include <atomic>
 #include <chrono>
 #include <condition_variable>
@@ -110,6 +112,12 @@ struct lime_ctx {
         double share = 1.0;                 // binned: the part of a wave's records one sub-region was sized for (sub_share)
         bool fell_back = false;             // the binned path was wanted and could not be had (memory): LIME_FLAG_CAS_FALLBACK
     } last;
+    // knobs of lime_set_option that have no other home (all -1 / 0 / false = the library's own choice)
+    int apply_wide = -1, sort_nt = -1, part_lines = -1;     // which variant of k_apply_tiles / of k_sort_tiles' row stores / whether k_part_lines may run
+    int choose_free = -1;                   // lime_fused_choose_dev: 1 = without the table wherever the layout has a second level, 0 = never
+    bool no_staging = false, force_staging = false, force_rccl = false, debug_stats = false;
+    uint64_t detect_chunk = 0, score_chunk = 0;             // symbols per chunk of lime_detect / lime_score* walks (0: by the sources)
+    int io_threads = 0;                     // host threads that stage pageable sources into the pinned ring (0: 8, at most the CPUs this process may use)
     // timing with HIP events on the launch stream: per pass {pass start, scan start, scan end, pass end}
     bool timing = false;
     std::vector<hipEvent_t> ev;
@@ -148,6 +156,134 @@ extern "C" size_t lime_sim_bytes(uint32_t n_reads, uint32_t n_refs)
     return (b + 15u) & ~(size_t)15u;
 }
 
+static std::atomic<bool> g_debug_alloc{false}, g_poison_cache{false};   // "poison_cache" (on under LIME_TEST_HOOKS): a block taken from the cache is filled with 0xA5 -- nothing may rely on what a fresh allocation holds          // lime_set_option "debug_alloc": every device allocation of the library on stderr
+
+// ---- device blocks released by the contexts of this process, kept for the next one -------------------------------------------------
+// Why (measured, tools/alloc_bench.hip, round 6): a hipMalloc on this platform costs 0.04-0.3 ms whatever its size AS LONG AS the driver hands
+// out pages that were never used since they were last cleared; pages that this or another process has written and freed are cleared by the
+// driver INSIDE the hipMalloc that gets them, at 25-35 GB/s -- 2.0 s for 25.8 GB allocated right after the same 25.8 GB were freed, 3.8 s
+// for 12.9 GB after 3 x 32 GB were freed, 6.0 s for 215 GB -- and the allocator does not prefer clean pages.  That is the "1 ms to 5.2 s"
+// of round 5's cold passes (bench.py frees 80-150 GB of arrays between workloads), and a pool that was re-grown by 0.02 % -- free 15.6 GB,
+// allocate 15.6 GB -- paid 4.9 s for it.  So the library never gives a large block back while the process lives: lime_shutdown and regrow put
+// blocks of 64 MB and more here, the next request takes the smallest cached block that is large enough (and at most twice as large), and
+// lime_trim_cache() -- or a failed hipMalloc -- returns them to the driver.  At most a quarter of the device's memory is held.
+namespace {
+struct BlockCache {
+    struct B { void *p; size_t bytes; int dev; };
+    static constexpr size_t MIN = (size_t)64 << 20;
+    std::mutex mu;
+    std::vector<B> idle, out;                               // cached blocks; blocks handed out (their true sizes)
+    void *take(int dev, size_t bytes, size_t *got)
+    {
+        std::lock_guard<std::mutex> g(mu);
+        size_t best = (size_t)-1;
+        for (size_t i = 0; i < idle.size(); ++i)
+            if (idle[i].dev == dev && idle[i].bytes >= bytes && idle[i].bytes / 2 <= bytes && (best == (size_t)-1 || idle[i].bytes < idle[best].bytes)) best = i;
+        if (best == (size_t)-1) return nullptr;
+        const B b = idle[best];
+        idle.erase(idle.begin() + (long)best);
+        out.push_back(b);
+        *got = b.bytes;
+        return b.p;
+    }
+    void note(int dev, void *p, size_t bytes) { if (bytes >= MIN) { std::lock_guard<std::mutex> g(mu); out.push_back(B{p, bytes, dev}); } }
+    // true: the cache keeps p; false: the caller frees it
+    bool give(void *p)
+    {
+        std::lock_guard<std::mutex> g(mu);
+        for (size_t i = 0; i < out.size(); ++i)
+            if (out[i].p == p) {
+                const B b = out[i];
+                out.erase(out.begin() + (long)i);
+                size_t held = b.bytes, total = 0, fr = 0;
+                for (const B &x : idle) if (x.dev == b.dev) held += x.bytes;
+                if (hipMemGetInfo(&fr, &total) != hipSuccess || held > total / 4) return false;
+                idle.push_back(b);
+                return true;
+            }
+        return false;
+    }
+    size_t trim(int dev)                                    // dev < 0: every device
+    {
+        std::vector<B> drop;
+        {
+            std::lock_guard<std::mutex> g(mu);
+            for (size_t i = 0; i < idle.size();) if (dev < 0 || idle[i].dev == dev) { drop.push_back(idle[i]); idle.erase(idle.begin() + (long)i); } else ++i;
+        }
+        int cur = 0; (void)hipGetDevice(&cur);
+        size_t bytes = 0;
+        for (const B &b : drop) { (void)hipSetDevice(b.dev); (void)hipFree(b.p); bytes += b.bytes; }
+        if (!drop.empty()) (void)hipSetDevice(cur);
+        return bytes;
+    }
+};
+BlockCache g_blocks;
+}
+extern "C" size_t lime_trim_cache(void) { return g_blocks.trim(-1); }
+
+static void dev_release(void *p)
+{
+    if (!p) return;
+    if (!g_blocks.give(p)) (void)hipFree(p);
+}
+static hipError_t dev_acquire(void **p, size_t bytes)
+{
+    int dev = 0; (void)hipGetDevice(&dev);
+    size_t got = 0;
+    if (bytes >= BlockCache::MIN && (*p = g_blocks.take(dev, bytes, &got))) {
+        if (g_poison_cache.load(std::memory_order_relaxed)) { (void)hipMemset(*p, 0xA5, got); (void)hipDeviceSynchronize(); }
+        return hipSuccess;
+    }
+    hipError_t e = hipMalloc(p, bytes);
+    if (e == hipErrorOutOfMemory && g_blocks.trim(dev)) { (void)hipGetLastError(); e = hipMalloc(p, bytes); }
+    if (e == hipSuccess) g_blocks.note(dev, *p, bytes);
+    return e;
+}
+// ---- options: every tuning / test knob of the library, by name.  Nothing here changes a result; most change which kernels run.
+static int set_option(lime_ctx *c, const char *key, const char *s)
+{
+    if (!key || !s) return fail(LIME_ERR_ARG, "lime_set_option: NULL argument");
+    auto is = [&](const char *k) { return !strcmp(key, k); };
+    const long v = atol(s);
+    if (is("update_path")) c->upd_pref = !strcmp(s, "cas") ? 0 : !strcmp(s, "bin") ? 1 : -1;
+    else if (is("bin_levels")) {
+        unsigned a1 = 0, a2 = 0;
+        if (!*s) { c->bin_one_level = BIN_ONE_LEVEL; c->bin_two_level = BIN_TWO_LEVEL; c->bin_levels_forced = false; }
+        else if (sscanf(s, "%u,%u", &a1, &a2) == 2 && a1 >= 1 && a2 >= 1 && a1 <= BIN_MAX && a2 <= BIN_MAX) { c->bin_one_level = a1; c->bin_two_level = a2; c->bin_levels_forced = true; }
+        else return fail(LIME_ERR_ARG, "bin_levels: want \"one,two\" with 1 <= one, two <= %u", BIN_MAX);
+    }
+    else if (is("pool_density")) { const double d = atof(s); if (d > 0) { c->pool_density = d; c->pool_density_fixed = true; } }      // tests: force a small pool
+    else if (is("scan_static_pct")) c->scan_static_pct = v >= 0 && v <= 100 ? (int)v : -1;
+    else if (is("second_level")) c->by_tiles = strcmp(s, "sweeps") != 0;
+    else if (is("part_split")) { if (v >= 1 && v <= 16) c->part_split = (uint32_t)v; }
+    else if (is("pool_slack")) { if (v >= 0) c->pool_slack = (uint32_t)v; }
+    else if (is("no_probe")) c->probe = v == 0;
+    else if (is("probe_min")) { const unsigned long long u = strtoull(s, nullptr, 0); c->probe_min = u < (1ull << 24) ? (1ull << 24) : u; }
+    else if (is("force_p64")) c->force_p64 = v != 0;
+    else if (is("p64_test_base")) { c->p64_test_base = strtoull(s, nullptr, 0) & ~15ull; if (c->p64_test_base) c->force_p64 = true; }
+    else if (is("max_blocks")) c->max_blocks = v > 0 ? (uint32_t)v : 0u;
+    else if (is("choose_free")) c->choose_free = *s ? (v != 0) : -1;
+    else if (is("apply_wide")) c->apply_wide = *s ? (v != 0) : -1;
+    else if (is("sort_nt")) c->sort_nt = *s ? (v != 0) : -1;
+    else if (is("part_lines")) c->part_lines = *s ? (v != 0) : -1;
+    else if (is("no_staging")) c->no_staging = v != 0 || !*s;
+    else if (is("force_staging")) c->force_staging = v != 0 || !*s;
+    else if (is("detect_chunk")) c->detect_chunk = strtoull(s, nullptr, 10);
+    else if (is("score_chunk")) c->score_chunk = strtoull(s, nullptr, 10);
+    else if (is("force_rccl")) c->force_rccl = v != 0 || !*s;
+    else if (is("debug_stats")) c->debug_stats = v != 0 || !*s;
+    else if (is("debug_alloc")) g_debug_alloc.store(v != 0 || !*s, std::memory_order_relaxed);
+    else if (is("poison_cache")) g_poison_cache.store(v != 0 || !*s, std::memory_order_relaxed);
+    else if (is("io_threads")) c->io_threads = v >= 1 ? (v > 64 ? 64 : (int)v) : 0;
+    else return fail(LIME_ERR_ARG, "lime_set_option: unknown option \"%s\"", key);
+    return LIME_OK;
+}
+extern "C" int lime_set_option(lime_ctx *c, const char *key, const char *value)
+{
+    if (!c) return fail(LIME_ERR_ARG, "lime_set_option: ctx is NULL");
+    return set_option(c, key, value);
+}
+
 extern "C" int lime_init(int device, lime_ctx **out)
 {
     if (!out) return fail(LIME_ERR_ARG, "lime_init: out is NULL");
@@ -170,21 +306,25 @@ extern "C" int lime_init(int device, lime_ctx **out)
 #ifdef LIME_ABLATE_BUILD
     if (const char *s = getenv("LIME_ABLATE")) c->ablate = atoi(s);
 #endif
-    if (const char *s = getenv("LIME_UPDATE_PATH")) c->upd_pref = !strcmp(s, "cas") ? 0 : !strcmp(s, "bin") ? 1 : -1;
-    if (const char *s = getenv("LIME_BIN_LEVELS")) {
-        unsigned a1 = 0, a2 = 0;
-        if (sscanf(s, "%u,%u", &a1, &a2) == 2 && a1 >= 1 && a2 >= 1 && a1 <= BIN_MAX && a2 <= BIN_MAX) { c->bin_one_level = a1; c->bin_two_level = a2; c->bin_levels_forced = true; }
+    // The environment is read HERE and nowhere else, and only two kinds of variable: LIME_IO_THREADS (a resource limit the user sets, like the
+    // reference's `threads` argument) always; the tuning / test knobs of lime_set_option only when LIME_TEST_HOOKS=1 says that this process is a
+    // test or an experiment (tests/conftest.py sets it; bench.py refuses to run with it).  A release run takes no hidden switch.
+    if (const char *s = getenv("LIME_IO_THREADS")) (void)set_option(c, "io_threads", s);
+    if (const char *h = getenv("LIME_TEST_HOOKS")) if (atoi(h) != 0) {
+        g_poison_cache.store(true, std::memory_order_relaxed);
+        static const char *const hooks[][2] = {
+            {"LIME_UPDATE_PATH", "update_path"}, {"LIME_BIN_LEVELS", "bin_levels"}, {"LIME_POOL_DENSITY", "pool_density"}, {"LIME_SCAN_STATIC_PCT", "scan_static_pct"},
+            {"LIME_SECOND_LEVEL", "second_level"}, {"LIME_PART_SPLIT", "part_split"}, {"LIME_POOL_SLACK", "pool_slack"}, {"LIME_NO_PROBE", "no_probe"},
+            {"LIME_PROBE_MIN", "probe_min"}, {"LIME_FORCE_P64", "force_p64"}, {"LIME_P64_TEST_BASE", "p64_test_base"}, {"LIME_MAX_BLOCKS", "max_blocks"},
+            {"LIME_CHOOSE_FREE", "choose_free"}, {"LIME_APPLY_WIDE", "apply_wide"}, {"LIME_SORT_NT", "sort_nt"}, {"LIME_PART_LINES", "part_lines"},
+            {"LIME_NO_STAGING", "no_staging"}, {"LIME_FORCE_STAGING", "force_staging"}, {"LIME_DETECT_CHUNK", "detect_chunk"}, {"LIME_SCORE_CHUNK", "score_chunk"},
+            {"LIME_FORCE_RCCL", "force_rccl"}, {"LIME_DEBUG_STATS", "debug_stats"}, {"LIME_DEBUG_ALLOC", "debug_alloc"}};
+        for (const auto &hk : hooks)
+            if (const char *s = getenv(hk[0])) {
+                const int rc = set_option(c, hk[1], s);
+                if (rc) { lime_shutdown(c); return fail(rc, "lime_init: %s=%s: %s", hk[0], s, g_err.c_str()); }
+            }
     }
-    if (const char *s = getenv("LIME_POOL_DENSITY")) { const double v = atof(s); if (v > 0) { c->pool_density = v; c->pool_density_fixed = true; } }   // tests: force a small pool
-    if (const char *s = getenv("LIME_SCAN_STATIC_PCT")) { const long v = atol(s); if (v >= 0 && v <= 100) c->scan_static_pct = (int)v; }
-    if (const char *s = getenv("LIME_SECOND_LEVEL")) c->by_tiles = strcmp(s, "sweeps") != 0;
-    if (const char *s = getenv("LIME_PART_SPLIT")) { const long v = atol(s); if (v >= 1 && v <= 16) c->part_split = (uint32_t)v; }
-    if (const char *s = getenv("LIME_POOL_SLACK")) { const long v = atol(s); if (v >= 0) c->pool_slack = (uint32_t)v; }
-    if (const char *s = getenv("LIME_NO_PROBE")) c->probe = atoi(s) == 0;
-    if (const char *s = getenv("LIME_PROBE_MIN")) { const unsigned long long v = strtoull(s, nullptr, 0); c->probe_min = v < (1ull << 24) ? (1ull << 24) : v; }
-    if (const char *s = getenv("LIME_FORCE_P64")) c->force_p64 = atoi(s) != 0;
-    if (const char *s = getenv("LIME_P64_TEST_BASE")) { c->p64_test_base = strtoull(s, nullptr, 0) & ~15ull; if (c->p64_test_base) c->force_p64 = true; }
-    if (const char *s = getenv("LIME_MAX_BLOCKS")) { long v = atol(s); if (v > 0) c->max_blocks = (uint32_t)v; }
     *out = c;
     return LIME_OK;
 }
@@ -197,27 +337,37 @@ extern "C" void lime_shutdown(lime_ctx *c)
     for (hipEvent_t e : c->ev) (void)hipEventDestroy(e);
     if (c->h_stats) (void)hipHostFree(c->h_stats);
     if (c->h_choose) (void)hipHostFree(c->h_choose);
-    (void)hipFree(c->d_choose);
-    (void)hipFree(c->d_stats); (void)hipFree(c->d_total); (void)hipFree(c->d_summ);
-    (void)hipFree(c->d_tile_cnt); (void)hipFree(c->d_tile_off); (void)hipFree(c->d_cross); (void)hipFree(c->d_wmask);
-    (void)hipFree(c->d_small); (void)hipFree(c->d_big); (void)hipFree(c->d_out);
-    (void)hipFree(c->d_big_scratch);
-    (void)hipFree(c->d_pool); (void)hipFree(c->d_recs); (void)hipFree(c->d_wave_cnt); (void)hipFree(c->d_counts);
-    (void)hipFree(c->d_totals); (void)hipFree(c->d_binbase); (void)hipFree(c->d_regbase); (void)hipFree(c->d_tbase); (void)hipFree(c->d_tidx);
+    for (void *p : {(void *)c->d_choose, (void *)c->d_stats, (void *)c->d_total, (void *)c->d_summ, (void *)c->d_tile_cnt, (void *)c->d_tile_off, (void *)c->d_cross,
+                    (void *)c->d_wmask, (void *)c->d_small, (void *)c->d_big, (void *)c->d_out, (void *)c->d_big_scratch, (void *)c->d_pool, (void *)c->d_recs,
+                    (void *)c->d_wave_cnt, (void *)c->d_counts, (void *)c->d_totals, (void *)c->d_binbase, (void *)c->d_regbase, (void *)c->d_tbase, (void *)c->d_tidx})
+        dev_release(p);                                  // (large blocks stay in the process's cache: BlockCache)
     if (c->h_xoff) (void)hipHostFree(c->h_xoff);
     if (c->ev_xoff) (void)hipEventDestroy(c->ev_xoff);
-    (void)hipFree(c->d_bigrec); (void)hipFree(c->d_bigrec_n); (void)hipFree(c->d_xrecs); (void)hipFree(c->d_xrecs2); (void)hipFree(c->d_xoff); (void)hipFree(c->d_xreg);
+    for (void *p : {(void *)c->d_bigrec, (void *)c->d_bigrec_n, (void *)c->d_xrecs, (void *)c->d_xrecs2, (void *)c->d_xoff, (void *)c->d_xreg}) dev_release(p);
     delete c;
 }
 
-static int d2h_pageable(void *dst, const void *d_src, size_t bytes, hipStream_t st);    // large results into the caller's pageable memory: staged by this library's threads
+static int d2h_pageable(const lime_ctx *c, void *dst, const void *d_src, size_t bytes, hipStream_t st);    // large results into the caller's pageable memory: staged by this library's threads
 static thread_local double g_alloc_ms = 0.0;             // (host time spent in hipFree / hipMalloc by regrow: moved into the ctx's account by its callers)
 template <typename T> static int regrow(T *&p, size_t count)
 {
     const auto t0 = std::chrono::steady_clock::now();
-    if (p) { (void)hipFree(p); p = nullptr; }
-    const hipError_t e = hipMalloc(&p, count * sizeof(T));
-    g_alloc_ms += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+    size_t f0 = 0, f1 = 0, tot = 0;
+    const bool dbg = g_debug_alloc.load(std::memory_order_relaxed);
+    if (dbg) (void)hipMemGetInfo(&f0, &tot);
+    const bool had = p != nullptr;
+    if (p) { dev_release(p); p = nullptr; }
+    const auto t1 = std::chrono::steady_clock::now();
+    void *q = nullptr;
+    const hipError_t e = dev_acquire(&q, count * sizeof(T));
+    p = static_cast<T *>(q);
+    const auto t2 = std::chrono::steady_clock::now();
+    g_alloc_ms += std::chrono::duration<double, std::milli>(t2 - t0).count();
+    if (dbg) {
+        (void)hipMemGetInfo(&f1, &tot);
+        fprintf(stderr, "regrow: %.3f GB%s release %.3f ms acquire %.3f ms; free before %.2f after %.2f of %.2f GB\n", (double)(count * sizeof(T)) / 1e9, had ? " (replaces a block)" : "",
+                std::chrono::duration<double, std::milli>(t1 - t0).count(), std::chrono::duration<double, std::milli>(t2 - t1).count(), (double)f0 / 1e9, (double)f1 / 1e9, (double)tot / 1e9);
+    }
     if (e != hipSuccess) { p = nullptr; HIP_TRY(e); }
     return LIME_OK;
 }
@@ -446,11 +596,19 @@ static int ensure_binned(lime_ctx *c, uint64_t n_own, uint32_t n_waves, uint32_t
         const size_t rows_words = ((size_t)tiles_bound(want, n_bins) * row_stride() + 1) / 2;
         if (want < rows_words) want = rows_words;
     }
+    if (want > c->pool_cap && c->pool_cap >= want - want / 5) {
+        // A pool within 20 % of what this pass would ask for is kept: the sizes carry margins of 1.25 x 1.35, a pass that overflows is repeated with
+        // a larger one, and replacing a block costs more than it looks -- the driver clears recycled pages inside hipMalloc at about 30 GB/s (the
+        // 15.6 GB pool of N = 10^10 clustered was re-grown by 0.02 % after the probe's density had been replaced by the measured one: 4.9 s)
+        const uint64_t cw2 = (c->pool_cap / segs) & ~15ull;
+        const size_t want2 = (size_t)cw2 * segs, rows2 = ((size_t)tiles_bound(want2, n_bins) * row_stride() + 1) / 2;
+        if (cw2 >= 16 && want2 <= c->pool_cap && rows2 <= c->pool_cap) { cw = cw2; want = want2; *p64 = c->force_p64 || want >= 0xF0000000ull; }
+    }
     if (want > c->pool_cap) {
         HIP_TRY(hipStreamSynchronize(st));
         c->pool_cap = 0; c->recs_cap = 0;                        // (nothing is there if one of the two cannot be had)
         if ((rc = regrow(c->d_pool, want + 16)) || (rc = regrow(c->d_recs, want + 16))) {      // slack: k_part2 / k_apply read aligned groups of four 4-byte records
-            if (c->d_pool) { (void)hipFree(c->d_pool); c->d_pool = nullptr; }
+            if (c->d_pool) { dev_release(c->d_pool); c->d_pool = nullptr; }
             return rc;
         }
         c->pool_cap = want; c->recs_cap = want;
@@ -490,6 +648,9 @@ static void bin_layout(const lime_ctx *c, size_t sim_bytes, uint32_t *n_bins, ui
 }
 
 static int read_stats(lime_ctx *c, lime_stats_t *s, hipStream_t st, uint32_t *sticky = nullptr);
+// which variant of k_apply_tiles / of k_sort_tiles' row stores a pass of `records` update records takes (lime_set_option "apply_wide" / "sort_nt" force one)
+static bool many_records_of(const lime_ctx *c, double records) { return c->apply_wide >= 0 ? c->apply_wide != 0 : records >= 2e8; }
+static bool big_rows_of(const lime_ctx *c, double records) { return c->sort_nt >= 0 ? c->sort_nt != 0 : records >= 1e8; }
 
 // Update records per owned symbol, estimated from a sample before the first pass on a ctx: the record-emitting scan kernel runs over every
 // 2^ps-th chunk of 16 windows -- spread over the whole collection, on all CUs -- with sub-regions of capacity 0: every update record is counted
@@ -530,7 +691,7 @@ static int density_probe(lime_ctx *c, const uint32_t *d_lcp, const uint32_t *d_d
     if (sampled > n_own) sampled = n_own;
     c->density = (double)s.n_updates / (double)(sampled ? sampled : 1); c->density_known = true;
     c->probe_ms += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count(); ++c->n_probes;
-    if (getenv("LIME_DEBUG_STATS")) fprintf(stderr, "density_probe: every %u-th chunk, %llu symbols, %llu updates -> %.4f records per symbol\n", 1u << ps,
+    if (c->debug_stats) fprintf(stderr, "density_probe: every %u-th chunk, %llu symbols, %llu updates -> %.4f records per symbol\n", 1u << ps,
                                             (unsigned long long)sampled, (unsigned long long)s.n_updates, c->density);
     return LIME_OK;
 }
@@ -609,7 +770,7 @@ static int fused_dev_impl(lime_ctx *c, const uint32_t *d_lcp, const uint32_t *d_
     if (records_only) {                                   // the long clusters' updates leave as records too
         if (!c->d_bigrec) {
             c->bigrec_cap = 16u << 20;
-            HIP_TRY(hipMalloc(&c->d_bigrec, (size_t)c->bigrec_cap * sizeof(uint64_t)));
+            HIP_TRY(dev_acquire((void **)&c->d_bigrec, (size_t)c->bigrec_cap * sizeof(uint64_t)));
             HIP_TRY(hipMalloc(&c->d_bigrec_n, sizeof(uint32_t)));
         }
         HIP_TRY(hipMemsetAsync(c->d_bigrec_n, 0, sizeof(uint32_t), st));
@@ -638,14 +799,14 @@ static int fused_dev_impl(lime_ctx *c, const uint32_t *d_lcp, const uint32_t *d_
             launch_add_u64(c->d_binbase, (size_t)n_bins + 1, c->p64_test_base, st);
             recs = c->d_recs - c->p64_test_base;                   // (an address only: the kernels add positions >= the base to it)
         }
-        launch_part(a, n_prod, c->d_binbase, const_cast<uint32_t *>(recs), st, p64);
+        launch_part(a, n_prod, c->d_binbase, const_cast<uint32_t *>(recs), st, p64, c->part_lines != 0);
         if (records_only) {
             // the records grouped by bin are the result: the owners of the bins build the table (lime_apply_records_dev)
         } else if (bin_shift > REGION_SHIFT && c->by_tiles) {      // second level tile by tile into the (by now free) pool, regions from the tiles' runs
             // (how many records: what the last pass counted per symbol, once one has been read back)
             const double expect = c->density_known ? c->density * (double)n_own : 0.0;
             launch_apply_by_tiles(d_sim, sim_bytes, recs, c->d_binbase, n_bins, bin_shift, c->d_tbase, c->d_tidx,
-                                  reinterpret_cast<uint16_t *>(c->d_pool), expect >= 2e8, st, expect >= 1e8, !c->p64_test_base);
+                                  reinterpret_cast<uint16_t *>(c->d_pool), many_records_of(c, expect), st, big_rows_of(c, expect), !c->p64_test_base);
         } else if (bin_shift > REGION_SHIFT) {            // second level into the (by now free) pool, then regions from there
             uint32_t *recs2 = c->d_pool;
             launch_part2(c->d_recs, c->d_binbase, n_bins, bin_shift, c->d_regbase, recs2, st);
@@ -800,7 +961,7 @@ extern "C" int lime_apply_records_dev(lime_ctx *c, uint32_t n_src, const uint32_
     launch_regroup(d_rx, d_srcoff, n_src, nb, d_dstbase, c->d_xrecs, st);
     if (bin_shift > REGION_SHIFT && c->by_tiles) {
         launch_apply_by_tiles(d_block, (size_t)block_bytes, c->d_xrecs, d_dstbase, nb, bin_shift, c->d_tbase, c->d_tidx,
-                              reinterpret_cast<uint16_t *>(c->d_xrecs2), total >= 200000000ull, st, total >= 100000000ull);
+                              reinterpret_cast<uint16_t *>(c->d_xrecs2), many_records_of(c, (double)total), st, big_rows_of(c, (double)total));
     } else if (bin_shift > REGION_SHIFT) {
         launch_part2(c->d_xrecs, d_dstbase, nb, bin_shift, c->d_xreg, c->d_xrecs2, st);
         HIP_TRY(hipMemcpyAsync(c->d_xreg + n_reg, d_dstbase + nb, sizeof(uint64_t), hipMemcpyDeviceToDevice, st));
@@ -831,7 +992,7 @@ extern "C" int lime_get_stats(lime_ctx *c, lime_stats_t *out, void *stream)
     lime_stats_t s;
     uint32_t unsettled = 0;
     if ((rc = read_stats(c, &s, st, &unsettled))) return rc;
-    if (getenv("LIME_DEBUG_STATS")) fprintf(stderr, "lime_get_stats: flags %u unsettled %u wave_records_max %u n_updates %llu\n", s.flags, unsettled, s.wave_records_max, (unsigned long long)s.n_updates);
+    if (c->debug_stats) fprintf(stderr, "lime_get_stats: flags %u unsettled %u wave_records_max %u n_updates %llu\n", s.flags, unsettled, s.wave_records_max, (unsigned long long)s.n_updates);
     // A pass EARLIER than the last one overflowed its record pool and no lime_get_stats came before the next pass
     // (every pass clears the flags; the sticky word survives): that pass's table is short and cannot be repaired now.
     if (unsettled > ((s.flags & LIME_FLAG_POOL_FULL) ? 1u : 0u)) {
@@ -872,8 +1033,8 @@ extern "C" int lime_get_stats(lime_ctx *c, lime_stats_t *out, void *stream)
             const uint64_t want = (uint64_t)nb + nb / 8u + 4096u;
             if (want > 0xFFFFFFF0ull) return fail(LIME_ERR_NOMEM, "%u update records of long clusters: too many for one shard's list", nb);
             uint64_t *bigger = nullptr;
-            HIP_TRY(hipMalloc(&bigger, (size_t)want * sizeof(uint64_t)));
-            (void)hipFree(c->d_bigrec);
+            HIP_TRY(dev_acquire((void **)&bigger, (size_t)want * sizeof(uint64_t)));
+            dev_release(c->d_bigrec);
             c->d_bigrec = bigger; c->bigrec_cap = (uint32_t)want;
             const bool timing = c->timing; c->timing = false;
             rc = fused_dev_impl(c, l.lcp, l.da, l.ebwt, l.n_own, l.n_avail, l.eof, l.n_reads, l.n_refs, l.alpha, l.sim, l.zero_sim,
@@ -1016,9 +1177,9 @@ static int score_dev_impl(lime_ctx *c, const uint32_t *d_da, const uint8_t *d_eb
         if (binned) {
             launch_bin_rowscan(c->d_counts, c->d_totals, n_bins, blocks, st);
             launch_scan_tiles(c->d_totals, c->d_binbase, n_bins, reinterpret_cast<unsigned long long *>(c->d_binbase + n_bins), st);
-            launch_part(a, blocks, c->d_binbase, c->d_recs, st, p64);
+            launch_part(a, blocks, c->d_binbase, c->d_recs, st, p64, c->part_lines != 0);
             if (bin_shift > REGION_SHIFT) launch_apply_by_tiles(d_sim, sim_bytes, c->d_recs, c->d_binbase, n_bins, bin_shift, c->d_tbase, c->d_tidx,
-                                                                reinterpret_cast<uint16_t *>(c->d_pool), false, st);
+                                                                reinterpret_cast<uint16_t *>(c->d_pool), many_records_of(c, 0.0), st, big_rows_of(c, 0.0));
             else launch_apply(d_sim, sim_bytes, c->d_recs, c->d_binbase, bin_shift, st);
         }
         launch_score_big(ebwt, a, c->d_big_scratch, st);  // (after the table is built: its compare-and-swaps add to it)
@@ -1068,8 +1229,8 @@ extern "C" int lime_synth_dev(lime_ctx *c, uint64_t seed, uint64_t i0, uint64_t 
 namespace {
 struct DevBuf {
     void *p = nullptr;
-    ~DevBuf() { if (p) (void)hipFree(p); }
-    int alloc(size_t bytes) { HIP_TRY(hipMalloc(&p, bytes ? bytes : 16)); return LIME_OK; }
+    ~DevBuf() { if (p) dev_release(p); }                  // (large ones stay in the process's block cache)
+    int alloc(size_t bytes) { HIP_TRY(dev_acquire(&p, bytes ? bytes : 16)); return LIME_OK; }
     int upload(const void *src, size_t bytes) {
         int rc = alloc(bytes + 16); if (rc) return rc;
         if (bytes) HIP_TRY(hipMemcpy(p, src, bytes, hipMemcpyHostToDevice));
@@ -1144,9 +1305,16 @@ bool read_from_file(void *dst, const void *src, size_t len)
 extern "C" int lime_register_file(const void *base, size_t bytes, int fd)
 {
     if (!base || fd < 0) return fail(LIME_ERR_ARG, "lime_register_file: bad argument");
+    // (the contract is in include/lime_hip.h: the mapping shows the file from offset 0, read-only; what can be checked is)
+    struct stat sb;
+    if (fstat(fd, &sb) != 0) return fail(LIME_ERR_IO, "lime_register_file: fstat failed");
+    if ((uint64_t)bytes > (uint64_t)sb.st_size) return fail(LIME_ERR_ARG, "lime_register_file: %zu bytes registered, the file has %lld", bytes, (long long)sb.st_size);
+    std::lock_guard<std::mutex> g(g_files_mu);
+    for (const FileMap &f : g_files)
+        if ((const char *)base < f.base + f.bytes && f.base < (const char *)base + bytes)
+            return fail(LIME_ERR_ARG, "lime_register_file: the range overlaps a registered one (unregister before unmapping)");
     const int own = dup(fd);                               // the caller may close its descriptor
     if (own < 0) return fail(LIME_ERR_IO, "lime_register_file: dup failed");
-    std::lock_guard<std::mutex> g(g_files_mu);
     g_files.push_back(FileMap{(const char *)base, bytes, own});
     return LIME_OK;
 }
@@ -1201,6 +1369,18 @@ struct IoPool {
     }
 };
 
+// host threads that move pageable sources into the pinned ring: what the ctx says (lime_set_option "io_threads": the drop-in programs pass the
+// reference's `threads` argument, LIME_IO_THREADS overrides at lime_init), else 8; never more than the CPUs this process may run on (its
+// affinity mask: a cgroup- or taskset-limited job must not be oversubscribed -- ADVICE r5)
+static int staging_threads(const lime_ctx *c)
+{
+    int t = c && c->io_threads > 0 ? c->io_threads : 8;
+    cpu_set_t set;
+    if (sched_getaffinity(0, sizeof set, &set) == 0) { const int n = CPU_COUNT(&set); if (n >= 1 && t > n) t = n; }
+    else { const unsigned hw = std::thread::hardware_concurrency(); if (hw && (unsigned)t > hw) t = (int)hw; }
+    return t < 1 ? 1 : t;
+}
+
 struct Feeder {
     static constexpr int NS = 3, MAXP = 3;
     void *slot[NS] = {nullptr, nullptr, nullptr};
@@ -1215,9 +1395,9 @@ struct Feeder {
     uint64_t filled = 0, issued = 0; bool stop = false, failed = false;
 
     // would a walk over `total_bytes` of these sources go through the ring?  (the caller picks its chunk size by it)
-    static bool will_stage(bool all_sources_pinned, size_t total_bytes)
+    static bool will_stage(const lime_ctx *c, bool all_sources_pinned, size_t total_bytes)
     {
-        return !all_sources_pinned && !getenv("LIME_NO_STAGING") && (total_bytes >= ((size_t)8 << 20) || getenv("LIME_FORCE_STAGING"));
+        return !all_sources_pinned && !(c && c->no_staging) && (total_bytes >= ((size_t)8 << 20) || (c && c->force_staging));
     }
     static bool pinned(const void *p)
     {
@@ -1227,17 +1407,16 @@ struct Feeder {
         return at.type == hipMemoryTypeHost;
     }
     IoPool pool;
-    int init(size_t bytes_per_chunk, uint64_t chunks, bool all_sources_pinned, std::function<int(uint64_t, Piece *)> d)
+    int init(const lime_ctx *c, size_t bytes_per_chunk, uint64_t chunks, bool all_sources_pinned, std::function<int(uint64_t, Piece *)> d)
     {
         describe = std::move(d); n_chunks = chunks; slot_bytes = bytes_per_chunk;
         // small collections: the ring's set-up (pinned allocations, a thread) costs more than it hides
-        staged = will_stage(all_sources_pinned, bytes_per_chunk * chunks);
+        staged = will_stage(c, all_sources_pinned, bytes_per_chunk * chunks);
         if (!staged) return LIME_OK;
         HIP_TRY(hipGetDevice(&device));
-        // staging threads: LIME_IO_THREADS (the drop-in programs pass their `threads` argument, at least 8), else 8 -- as many as the machine has at most
-        io_threads = 8;
-        if (const char *e = getenv("LIME_IO_THREADS")) { const int v = atoi(e); if (v >= 1) io_threads = v > 64 ? 64 : v; }
-        { const unsigned hw = std::thread::hardware_concurrency(); if (hw && (unsigned)io_threads > hw) io_threads = (int)hw; }
+        // staging threads: the ctx's io_threads (the drop-in programs pass their `threads` argument; LIME_IO_THREADS at lime_init), else 8 -- never more
+        // than the CPUs this process may run on
+        io_threads = staging_threads(c);
         if (io_threads > 1) pool.start(io_threads);
         for (int i = 0; i < NS; ++i) {
             HIP_TRY(hipHostMalloc(&slot[i], slot_bytes + 64, hipHostMallocDefault));
@@ -1316,7 +1495,7 @@ int lime_internal_upload(int n_arr, const void *const *src, void *const *dst, co
     if (n_arr > Feeder::MAXP) return fail(LIME_ERR_ARG, "lime_internal_upload: too many arrays");
     const uint64_t n_chunks = (longest + CH - 1) / CH;
     Feeder feeder;
-    int rc = feeder.init((size_t)n_arr * (CH + 16), n_chunks, pinned, [&](uint64_t k, Piece *pc) {
+    int rc = feeder.init(nullptr, (size_t)n_arr * (CH + 16), n_chunks, pinned, [&](uint64_t k, Piece *pc) {
         int np = 0;
         for (int i = 0; i < n_arr; ++i) {
             const size_t off = (size_t)k * CH;
@@ -1339,7 +1518,7 @@ extern "C" int lime_fused_stream(lime_ctx *c, const uint32_t *lcp, const uint32_
     if (!sim || (n && (!lcp || !da))) return fail(LIME_ERR_ARG, "lime_fused_stream: NULL array");
     if (!n_reads || !n_refs) return fail(LIME_ERR_ARG, "lime_fused_stream: n_reads and n_refs must be > 0");
     const bool src_pinned = Feeder::pinned(lcp) && Feeder::pinned(da) && Feeder::pinned(ebwt);
-    if (!chunk) chunk = Feeder::will_stage(src_pinned, (size_t)n * 9) ? STAGED_CHUNK : STREAM_CHUNK;
+    if (!chunk) chunk = Feeder::will_stage(c, src_pinned, (size_t)n * 9) ? STAGED_CHUNK : STREAM_CHUNK;
     chunk = (chunk + LIME_TILE - 1) / LIME_TILE * LIME_TILE;
     const uint64_t cap = (chunk < n ? chunk : n) + STREAM_HALO;         // elements per device buffer
     Pipe pp;
@@ -1358,7 +1537,7 @@ extern "C" int lime_fused_stream(lime_ctx *c, const uint32_t *lcp, const uint32_
     if ((rc = dedge.alloc((size_t)(n_chunks + 1) * 4))) return rc;
     HIP_TRY(hipMemsetAsync(dedge.p, 0, (size_t)(n_chunks + 1) * 4, pp.comp));
     Feeder feeder;
-    if ((rc = feeder.init(cap * 9 + 64, n_chunks, src_pinned,
+    if ((rc = feeder.init(c, cap * 9 + 64, n_chunks, src_pinned,
                           [&](uint64_t kk, Piece *pc) {
                               const uint64_t lo = kk * chunk, own = n - lo < chunk ? n - lo : chunk;
                               const uint64_t avail = n - lo < own + STREAM_HALO ? n - lo : own + STREAM_HALO;
@@ -1394,7 +1573,7 @@ extern "C" int lime_fused_stream(lime_ctx *c, const uint32_t *lcp, const uint32_
         HIP_TRY(hipStreamSynchronize(pp.comp));
         if ((rc = lime_combine_edges(edges.data(), (uint32_t)n_chunks))) { (void)hipDeviceSynchronize(); return rc; }
     }
-    if ((rc = d2h_pageable(sim, ds.p, (size_t)n_reads * n_refs, pp.comp))) return rc;
+    if ((rc = d2h_pageable(c, sim, ds.p, (size_t)n_reads * n_refs, pp.comp))) return rc;
     HIP_TRY(hipStreamSynchronize(pp.comp));
     HIP_TRY(hipStreamSynchronize(pp.copy));
     return LIME_OK;
@@ -1416,7 +1595,7 @@ static int detect_walk(lime_ctx *c, const uint32_t *lcp, const uint32_t *da, uin
     DevBuf dl[2], dd[2];
     for (int b = 0; b < (n_chunks > 1 ? 2 : 1); ++b) { if ((rc = dl[b].alloc(cap * 4 + 16))) return rc; if ((rc = dd[b].alloc(cap * 4 + 16))) return rc; }
     Feeder feeder;
-    if ((rc = feeder.init(cap * 8 + 64, n_chunks, Feeder::pinned(lcp) && Feeder::pinned(da), [&](uint64_t kk, Piece *pc) {
+    if ((rc = feeder.init(c, cap * 8 + 64, n_chunks, Feeder::pinned(lcp) && Feeder::pinned(da), [&](uint64_t kk, Piece *pc) {
             const uint64_t lo = kk * chunk, own = n - lo < chunk ? n - lo : chunk;
             const uint64_t avail = n - lo < own + STREAM_HALO ? n - lo : own + STREAM_HALO;
             pc[0] = Piece{lcp + lo, (size_t)avail * 4, dl[kk & 1].p}; pc[1] = Piece{da + lo, (size_t)avail * 4, dd[kk & 1].p};
@@ -1450,22 +1629,16 @@ static int detect_walk(lime_ctx *c, const uint32_t *lcp, const uint32_t *da, uin
     return LIME_OK;
 }
 
-static uint64_t detect_chunk(const uint32_t *lcp, const uint32_t *da, uint64_t n)
+static uint64_t detect_chunk(const lime_ctx *c, const uint32_t *lcp, const uint32_t *da, uint64_t n)
 {
-    uint64_t chunk0 = Feeder::will_stage(Feeder::pinned(lcp) && Feeder::pinned(da), (size_t)n * 8) ? STAGED_CHUNK : STREAM_CHUNK;
-    if (const char *e = getenv("LIME_DETECT_CHUNK")) { const uint64_t v = strtoull(e, nullptr, 10); if (v) chunk0 = v; }
-    return chunk0;
+    if (c->detect_chunk) return c->detect_chunk;
+    return Feeder::will_stage(c, Feeder::pinned(lcp) && Feeder::pinned(da), (size_t)n * 8) ? STAGED_CHUNK : STREAM_CHUNK;
 }
 
-extern "C" int lime_detect(lime_ctx *c, const uint32_t *lcp, const uint32_t *da, uint64_t n, uint32_t n_reads,
-                           uint32_t alpha, lime_cluster_t **clusters, uint64_t *n_clusters, uint64_t *max_len)
+// one walk with chunks of `chunk` symbols, the records gathered in host memory (*clusters: malloc'ed, the caller's)
+static int detect_to_host(lime_ctx *c, const uint32_t *lcp, const uint32_t *da, uint64_t n, uint32_t n_reads, uint32_t alpha, uint64_t chunk,
+                          lime_cluster_t **clusters, uint64_t *n_clusters, uint64_t *max_len)
 {
-    int rc = check_ctx(c, "lime_detect"); if (rc) return rc;
-    if (!clusters || !n_clusters || !max_len) return fail(LIME_ERR_ARG, "lime_detect: NULL output");
-    *clusters = nullptr; *n_clusters = 0; *max_len = 0;
-    if (n && (!lcp || !da)) return fail(LIME_ERR_ARG, "lime_detect: NULL array");
-    if (!n) return LIME_OK;
-    const uint64_t chunk0 = detect_chunk(lcp, da, n);
     lime_cluster_t *h = nullptr;
     uint64_t have = 0, room = 0, ml = 0;
     auto sink = [&](const lime_cluster_t *dc, uint64_t cnt, hipStream_t st) -> int {
@@ -1479,16 +1652,27 @@ extern "C" int lime_detect(lime_ctx *c, const uint32_t *lcp, const uint32_t *da,
         have += cnt;
         return LIME_OK;
     };
-    rc = detect_walk(c, lcp, da, n, n_reads, alpha, chunk0, &ml, sink);
-    if (rc == LIME_ERR_HALO && chunk0 < n) {
-        // a run longer than the halo crosses a chunk border.  ClusterLCP itself has no length limit (only
-        // ClusterBWT_DA refuses such a cluster later): redo the whole collection as one chunk
-        have = 0; ml = 0;
-        rc = detect_walk(c, lcp, da, n, n_reads, alpha, n, &ml, sink);
-    }
+    const int rc = detect_walk(c, lcp, da, n, n_reads, alpha, chunk, &ml, sink);
     if (rc) { free(h); return rc; }
     *clusters = h; *n_clusters = have; *max_len = ml;
     return LIME_OK;
+}
+
+extern "C" int lime_detect(lime_ctx *c, const uint32_t *lcp, const uint32_t *da, uint64_t n, uint32_t n_reads,
+                           uint32_t alpha, lime_cluster_t **clusters, uint64_t *n_clusters, uint64_t *max_len)
+{
+    int rc = check_ctx(c, "lime_detect"); if (rc) return rc;
+    if (!clusters || !n_clusters || !max_len) return fail(LIME_ERR_ARG, "lime_detect: NULL output");
+    *clusters = nullptr; *n_clusters = 0; *max_len = 0;
+    if (n && (!lcp || !da)) return fail(LIME_ERR_ARG, "lime_detect: NULL array");
+    if (!n) return LIME_OK;
+    const uint64_t chunk0 = detect_chunk(c, lcp, da, n);
+    rc = detect_to_host(c, lcp, da, n, n_reads, alpha, chunk0, clusters, n_clusters, max_len);
+    if (rc == LIME_ERR_HALO && chunk0 < n)
+        // a run longer than the halo crosses a chunk border.  ClusterLCP itself has no length limit (only
+        // ClusterBWT_DA refuses such a cluster later): redo the whole collection as one chunk
+        rc = detect_to_host(c, lcp, da, n, n_reads, alpha, n, clusters, n_clusters, max_len);
+    return rc;
 }
 
 // lime_detect with the records written to `path` as they come (the .clrs file of ClusterLCP.cpp:229-235, ascending pStart): every chunk's
@@ -1501,10 +1685,14 @@ extern "C" int lime_detect_to_file(lime_ctx *c, const uint32_t *lcp, const uint3
     if (!path || !n_clusters || !max_len) return fail(LIME_ERR_ARG, "lime_detect_to_file: NULL argument");
     *n_clusters = 0; *max_len = 0;
     if (n && (!lcp || !da)) return fail(LIME_ERR_ARG, "lime_detect_to_file: NULL array");
-    const int fd = open(path, O_WRONLY | O_CREAT | O_TRUNC, 0644);
+    // The records go to a temporary file next to `path` that takes its name only when the scan has succeeded: a failure on the way (pinned
+    // memory, a HIP error, a full disk) leaves no truncated .clrs behind for ClusterBWT_DA to read (the reference's fopen "w" +
+    // exit(1) does leave one, ClusterLCP.cpp:95-98 -- not a behaviour to keep)
+    const std::string tmp = std::string(path) + ".tmp." + std::to_string((long)getpid());
+    const int fd = open(tmp.c_str(), O_WRONLY | O_CREAT | O_TRUNC, 0644);
     if (fd < 0) return fail(LIME_ERR_IO, "lime_detect_to_file: cannot create %s", path);
-    if (!n) { close(fd); return LIME_OK; }
-    const uint64_t chunk0 = detect_chunk(lcp, da, n);
+    if (!n) { close(fd); if (rename(tmp.c_str(), path)) { (void)unlink(tmp.c_str()); return fail(LIME_ERR_IO, "lime_detect_to_file: cannot create %s", path); } return LIME_OK; }
+    const uint64_t chunk0 = detect_chunk(c, lcp, da, n);
     const size_t buf_records = (size_t)((chunk0 < n ? chunk0 : n) / 2 + 4096);      // a chunk has at most half as many clusters as positions
     void *pin[2] = {nullptr, nullptr};
     struct Job { int b; uint64_t cnt, at; };
@@ -1521,7 +1709,7 @@ extern "C" int lime_detect_to_file(lime_ctx *c, const uint32_t *lcp, const uint3
     };
     if (hipHostMalloc(&pin[0], buf_records * sizeof(lime_cluster_t), hipHostMallocDefault) != hipSuccess ||
         hipHostMalloc(&pin[1], buf_records * sizeof(lime_cluster_t), hipHostMallocDefault) != hipSuccess) {
-        (void)hipGetLastError(); finish();
+        (void)hipGetLastError(); finish(); (void)unlink(tmp.c_str());
         return fail(LIME_ERR_NOMEM, "lime_detect_to_file: no pinned memory for the record buffers");
     }
     writer = std::thread([&]() {
@@ -1568,14 +1756,16 @@ extern "C" int lime_detect_to_file(lime_ctx *c, const uint32_t *lcp, const uint3
     finish();
     if (!rc && bad_io) rc = fail(LIME_ERR_IO, "lime_detect_to_file: write to %s failed", path);
     if (rc == LIME_ERR_HALO && chunk0 < n) {
-        // (a run longer than the halo across a chunk border: the whole collection as one chunk, through memory)
+        // (a run longer than the halo across a chunk border: the whole collection as ONE chunk, through memory -- directly, not through
+        // lime_detect, whose first walk would repeat the chunked scan that has just failed)
         lime_cluster_t *h = nullptr;
-        if ((rc = lime_detect(c, lcp, da, n, n_reads, alpha, &h, &have, &ml))) return rc;
-        rc = lime_write_clrs(path, h, have);
+        if ((rc = detect_to_host(c, lcp, da, n, n_reads, alpha, n, &h, &have, &ml))) { (void)unlink(tmp.c_str()); return rc; }
+        rc = lime_write_clrs(tmp.c_str(), h, have);
         free(h);
-        if (rc) return fail(LIME_ERR_IO, "lime_detect_to_file: write to %s failed", path);
+        if (rc) { (void)unlink(tmp.c_str()); return fail(LIME_ERR_IO, "lime_detect_to_file: write to %s failed", path); }
     }
-    if (rc) return rc;
+    if (rc) { (void)unlink(tmp.c_str()); return rc; }
+    if (rename(tmp.c_str(), path)) { (void)unlink(tmp.c_str()); return fail(LIME_ERR_IO, "lime_detect_to_file: cannot create %s", path); }
     *n_clusters = have; *max_len = ml;
     return LIME_OK;
 }
@@ -1591,8 +1781,7 @@ static int score_in_chunks(lime_ctx *c, const uint32_t *da, const uint8_t *ebwt,
     HIP_TRY(hipMemset(d_sim, 0, lime_sim_bytes(n_reads, n_refs)));
     HIP_TRY(hipDeviceSynchronize());                      // the chunks below run on streams of their own
     if (!n_clusters) return LIME_OK;
-    uint64_t chunk = Feeder::will_stage(Feeder::pinned(da) && Feeder::pinned(ebwt), (size_t)n * 5) ? STAGED_CHUNK : STREAM_CHUNK;
-    if (const char *e = getenv("LIME_SCORE_CHUNK")) { const uint64_t v = strtoull(e, nullptr, 10); if (v) chunk = v; }
+    uint64_t chunk = c->score_chunk ? c->score_chunk : Feeder::will_stage(c, Feeder::pinned(da) && Feeder::pinned(ebwt), (size_t)n * 5) ? STAGED_CHUNK : STREAM_CHUNK;
     bool sorted = true;
     for (uint64_t i = 0; i < n_clusters; ++i) {
         const lime_cluster_t &q = clusters[i];
@@ -1629,7 +1818,7 @@ static int score_in_chunks(lime_ctx *c, const uint32_t *da, const uint8_t *ebwt,
         if ((rc = dc[b].alloc(max_cl * sizeof(lime_cluster_t)))) return rc;
     }
     Feeder feeder;
-    if ((rc = feeder.init(max_el * 5 + max_cl * sizeof(lime_cluster_t) + 64, plan.size(),
+    if ((rc = feeder.init(c, max_el * 5 + max_cl * sizeof(lime_cluster_t) + 64, plan.size(),
                           Feeder::pinned(da) && Feeder::pinned(ebwt) && Feeder::pinned(cl), [&](uint64_t k, Piece *pc) {
             const Plan &q = plan[k];
             const int b = (int)(k & 1);
@@ -1672,7 +1861,7 @@ extern "C" int lime_score(lime_ctx *c, const uint32_t *da, const uint8_t *ebwt, 
     DevBuf ds;
     if ((rc = ds.alloc(lime_sim_bytes(n_reads, n_refs)))) return rc;
     if ((rc = score_in_chunks(c, da, ebwt, n, clusters, n_clusters, n_reads, n_refs, (uint8_t *)ds.p))) return rc;
-    if ((rc = d2h_pageable(sim, ds.p, (size_t)n_reads * n_refs, nullptr))) return rc;
+    if ((rc = d2h_pageable(c, sim, ds.p, (size_t)n_reads * n_refs, nullptr))) return rc;
     return LIME_OK;
 }
 
@@ -1697,7 +1886,7 @@ extern "C" int lime_fused(lime_ctx *c, const uint32_t *lcp, const uint32_t *da, 
     if (n_clusters) *n_clusters = s.n_clusters;
     if (max_len) *max_len = s.max_len;
     if (rc) return rc;
-    if ((rc = d2h_pageable(sim, ds.p, (size_t)n_reads * n_refs, nullptr))) return rc;
+    if ((rc = d2h_pageable(c, sim, ds.p, (size_t)n_reads * n_refs, nullptr))) return rc;
     return LIME_OK;
 }
 
@@ -1721,10 +1910,10 @@ extern "C" int lime_choose(lime_ctx *c, const uint8_t *sim, uint32_t n_reads, ui
 // Device memory -> freshly allocated pageable host memory (the (idRef, sim) lists: 0.7 GB when most of configs[2]'s rows pass): through two pinned
 // slots, the copy of piece k + 1 under the host's copy of piece k by the staging threads.  The runtime's own staged copy does this on one thread,
 // first-touch page faults included: 0.7 GB took 170 ms = 4 GB/s.
-static int d2h_pageable(void *dst, const void *d_src, size_t bytes, hipStream_t st)
+static int d2h_pageable(const lime_ctx *c, void *dst, const void *d_src, size_t bytes, hipStream_t st)
 {
     constexpr size_t SLOT = (size_t)8 << 20, PIECE = (size_t)1 << 20;
-    if (bytes < 4 * SLOT || getenv("LIME_NO_STAGING") || Feeder::pinned(dst)) {     // (pinned destinations: the copy engine writes them directly)
+    if (bytes < 4 * SLOT || (c && c->no_staging) || Feeder::pinned(dst)) {     // (pinned destinations: the copy engine writes them directly)
         HIP_TRY(hipMemcpyAsync(dst, d_src, bytes, hipMemcpyDeviceToHost, st));
         HIP_TRY(hipStreamSynchronize(st));
         return LIME_OK;
@@ -1734,9 +1923,7 @@ static int d2h_pageable(void *dst, const void *d_src, size_t bytes, hipStream_t 
         ~Ring() { for (int i = 0; i < 2; ++i) { if (slot[i]) (void)hipHostFree(slot[i]); if (ev[i]) (void)hipEventDestroy(ev[i]); } }
     } r;
     for (int i = 0; i < 2; ++i) { HIP_TRY(hipHostMalloc(&r.slot[i], SLOT)); HIP_TRY(hipEventCreateWithFlags(&r.ev[i], hipEventDisableTiming)); }
-    int threads = 8;
-    if (const char *e = getenv("LIME_IO_THREADS")) { const int v = atoi(e); if (v >= 1) threads = v > 64 ? 64 : v; }
-    { const unsigned hw = std::thread::hardware_concurrency(); if (hw && (unsigned)threads > hw) threads = (int)hw; }
+    const int threads = staging_threads(c);
     IoPool pool;
     if (threads > 1) pool.start(threads);
     const size_t n_chunks = (bytes + SLOT - 1) / SLOT;
@@ -1823,7 +2010,7 @@ extern "C" int lime_choose_pairs_dev(lime_ctx *c, const uint8_t *d_sim, uint32_t
     HIP_TRY(hipGetLastError());
     lime_pair_t *h = (lime_pair_t *)malloc((size_t)total * sizeof(lime_pair_t));
     if (!h) return fail(LIME_ERR_NOMEM, "lime_choose_pairs_dev: out of host memory");
-    if ((rc = d2h_pageable(h, dp.p, (size_t)total * sizeof(lime_pair_t), st))) { free(h); return rc; }
+    if ((rc = d2h_pageable(c, h, dp.p, (size_t)total * sizeof(lime_pair_t), st))) { free(h); return rc; }
     *pairs = h;
     return LIME_OK;
 }
@@ -1849,9 +2036,9 @@ extern "C" int lime_fused_choose_dev(lime_ctx *c, const uint32_t *d_lcp, const u
     const bool bin_fits = !(sim_bytes > ((size_t)BIN_MAX << BIN_SHIFT_MAX) || sim_bytes >= (1ull << CELL_BITS) || sim_bytes > ((uint64_t)MAX_SUB << 32));
     uint32_t n_bins = 0, bin_shift = REGION_SHIFT;
     if (bin_fits) bin_layout(c, sim_bytes, &n_bins, &bin_shift);
-    const char *force = getenv("LIME_CHOOSE_FREE");              // tests: 1 = without the table wherever the layout has a second level, 0 = never
+    // (lime_set_option "choose_free": 1 = without the table wherever the layout has a second level, 0 = never)
     bool table_free = bin_fits && c->by_tiles && bin_shift > REGION_SHIFT && n && c->upd_pref != 0 && n_refs < MAX_REFS &&
-                      (force ? atoi(force) != 0 : (n_refs >= 256u && n >= (1u << 24)));
+                      (c->choose_free >= 0 ? c->choose_free != 0 : (n_refs >= 256u && n >= (1u << 24)));
     lime_stats_t s;
     memset(&s, 0, sizeof s);
     if (!table_free) {
@@ -1894,8 +2081,8 @@ extern "C" int lime_fused_choose_dev(lime_ctx *c, const uint32_t *d_lcp, const u
     }
     const double expect = (double)s.n_updates;
     uint16_t *rows = reinterpret_cast<uint16_t *>(c->d_pool);
-    launch_sort_tiles(c->d_recs, c->d_binbase, n_bins, bin_shift, c->d_tbase, c->d_tidx, rows, st, expect >= 1e8);      // (k_tile_bases inside: the pass stopped at the records and numbered no tiles)
-    launch_apply_tiles_fin(1, sim_bytes, bin_shift, c->d_tbase, c->d_tidx, rows, expect >= 2e8, fin, st);
+    launch_sort_tiles(c->d_recs, c->d_binbase, n_bins, bin_shift, c->d_tbase, c->d_tidx, rows, st, big_rows_of(c, expect));      // (k_tile_bases inside: the pass stopped at the records and numbered no tiles)
+    launch_apply_tiles_fin(1, sim_bytes, bin_shift, c->d_tbase, c->d_tidx, rows, many_records_of(c, expect), fin, st);
     HIP_TRY(hipGetLastError());
     HIP_TRY(hipMemcpyAsync(c->h_choose, dmax, rows_bytes, hipMemcpyDeviceToHost, st));
     HIP_TRY(hipStreamSynchronize(st));
@@ -1916,11 +2103,11 @@ extern "C" int lime_fused_choose_dev(lime_ctx *c, const uint32_t *d_lcp, const u
     if ((rc = dp.alloc((size_t)total * sizeof(lime_pair_t)))) return rc;
     fin.row_off = (const uint64_t *)doff.p; fin.pairs = (lime_pair_t *)dp.p;
     launch_region_rows(n_regions, n_refs, fin.table_bytes, fin.row_off, drr, st);          // (now with the regions that have nothing to gather marked)
-    launch_apply_tiles_fin(2, sim_bytes, bin_shift, c->d_tbase, c->d_tidx, rows, expect >= 2e8, fin, st);
+    launch_apply_tiles_fin(2, sim_bytes, bin_shift, c->d_tbase, c->d_tidx, rows, many_records_of(c, expect), fin, st);
     HIP_TRY(hipGetLastError());
     lime_pair_t *h = (lime_pair_t *)malloc((size_t)total * sizeof(lime_pair_t));
     if (!h) return fail(LIME_ERR_NOMEM, "lime_fused_choose_dev: out of host memory");
-    if ((rc = d2h_pageable(h, dp.p, (size_t)total * sizeof(lime_pair_t), st))) { free(h); return rc; }
+    if ((rc = d2h_pageable(c, h, dp.p, (size_t)total * sizeof(lime_pair_t), st))) { free(h); return rc; }
     *pairs = h;
     return LIME_OK;
 }
@@ -1938,7 +2125,7 @@ extern "C" int lime_score_choose(lime_ctx *c, const uint32_t *da, const uint8_t 
     if ((rc = score_in_chunks(c, da, ebwt, n, clusters, n_clusters, n_reads, n_refs, (uint8_t *)ds.p))) return rc;
     if ((rc = lime_choose_pairs_dev(c, (const uint8_t *)ds.p, n_reads, n_refs, norm, beta, row_max, row_off, pairs,
                                     n_pairs, nullptr))) return rc;
-    if (sim && (rc = d2h_pageable(sim, ds.p, (size_t)n_reads * n_refs, nullptr))) return rc;
+    if (sim && (rc = d2h_pageable(c, sim, ds.p, (size_t)n_reads * n_refs, nullptr))) return rc;
     return LIME_OK;
 }
 
@@ -2001,7 +2188,7 @@ extern "C" int lime_score_choose_multi(int n_dev, const int *devices, const uint
     for (auto &t : th) t.join();
     for (int k = 0; k < n_dev; ++k) if (dv[k].rc) { const int rc = dv[k].rc; const std::string e = dv[k].err; cleanup(); return fail(rc, "device %d: %s", devs[k], e.c_str()); }
     int rc = LIME_OK;
-    if (n_dev > 1 || getenv("LIME_FORCE_RCCL")) {
+    if (n_dev > 1 || dv[0].ctx->force_rccl) {
         std::vector<uint8_t *> sims(n_dev), blks(n_dev);
         for (int k = 0; k < n_dev; ++k) { sims[k] = dv[k].sim; blks[k] = dv[k].blkp; }
         if ((rc = lime_internal_reduce_scatter(n_dev, devs.data(), sims.data(), blks.data(), blk))) { cleanup(); return fail(rc, "%s", lime_comm_error()); }

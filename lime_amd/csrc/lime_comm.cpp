@@ -40,6 +40,7 @@ struct Rccl {
     ncclResult_t (*CommInitRank)(ncclComm_t *, int, ncclUniqueId, int) = nullptr;
     ncclResult_t (*CommInitAll)(ncclComm_t *, int, const int *) = nullptr;
     ncclResult_t (*CommDestroy)(ncclComm_t) = nullptr;
+    ncclResult_t (*CommCount)(const ncclComm_t, int *) = nullptr;
     ncclResult_t (*ReduceScatter)(const void *, void *, size_t, int, int, ncclComm_t, hipStream_t) = nullptr;
     ncclResult_t (*AllReduce)(const void *, void *, size_t, int, int, ncclComm_t, hipStream_t) = nullptr;
     ncclResult_t (*AllGather)(const void *, void *, size_t, int, ncclComm_t, hipStream_t) = nullptr;
@@ -69,7 +70,7 @@ int load_rccl()
     if (!h) return cfail(LIME_ERR_HIP, "cannot load librccl: %s", dlerror());
 #define SYM(field, name) if (!(*(void **)(&g_rccl.field) = dlsym(h, name))) return cfail(LIME_ERR_HIP, "librccl lacks %s", name)
     SYM(GetUniqueId, "ncclGetUniqueId"); SYM(CommInitRank, "ncclCommInitRank"); SYM(CommInitAll, "ncclCommInitAll");
-    SYM(CommDestroy, "ncclCommDestroy"); SYM(ReduceScatter, "ncclReduceScatter"); SYM(AllReduce, "ncclAllReduce");
+    SYM(CommDestroy, "ncclCommDestroy"); SYM(CommCount, "ncclCommCount"); SYM(ReduceScatter, "ncclReduceScatter"); SYM(AllReduce, "ncclAllReduce");
     SYM(AllGather, "ncclAllGather"); SYM(Send, "ncclSend"); SYM(Recv, "ncclRecv");
     SYM(GroupStart, "ncclGroupStart"); SYM(GroupEnd, "ncclGroupEnd"); SYM(GetErrorString, "ncclGetErrorString");
 #undef SYM
@@ -126,6 +127,14 @@ extern "C" int lime_comm_init(const uint8_t id[LIME_COMM_ID_BYTES], int rank, in
     ncclResult_t r = g_rccl.CommInitRank(&c->comm, world, u, rank);
     if (r != 0) { delete c; return cfail(LIME_ERR_HIP, "ncclCommInitRank: %s", g_rccl.GetErrorString(r)); }
     *out = c;
+    return LIME_OK;
+}
+
+// ranks RCCL itself counts in the communicator (ncclCommCount): the bench line carries it next to WORLD_SIZE
+extern "C" int lime_comm_count(lime_comm *c, int *ranks)
+{
+    if (!c || !ranks) return cfail(LIME_ERR_ARG, "lime_comm_count: NULL argument");
+    NCCL_TRY(g_rccl.CommCount(c->comm, ranks));
     return LIME_OK;
 }
 

@@ -123,7 +123,7 @@ uint32_t scan_grid(int ebwt, int mode, int binned, uint32_t n_tiles, uint32_t ma
 void launch_bin_rowscan(uint32_t *counts, uint32_t *totals, uint32_t n_bins, uint32_t n_prod, hipStream_t st);
 void launch_rowscan_resolve(const ScanArgs &a, uint32_t *counts, uint32_t *totals, uint32_t n_bins, uint32_t n_prod, hipStream_t st);   // launch_bin_rowscan + launch_resolve(0, ..) in one launch
 void launch_bin_bases(const uint32_t *totals, uint64_t *binbase /* n_bins + 1 */, uint32_t *tbase /* n_bins + 1 tiles before each bin, or NULL */, uint32_t n_bins, hipStream_t st);
-void launch_part(const ScanArgs &a, uint32_t n_prod, const uint64_t *binbase, uint32_t *out, hipStream_t st, bool p64 = false);   // p64: the pool holds 2^32 records or more (64-bit positions in `out`)
+void launch_part(const ScanArgs &a, uint32_t n_prod, const uint64_t *binbase, uint32_t *out, hipStream_t st, bool p64 = false, bool lines_ok = true);   // p64: the pool holds 2^32 records or more (64-bit positions in `out`); lines_ok: k_part_lines may serve layouts it fits
 void launch_part2(const uint32_t *recs, const uint64_t *binbase, uint32_t n_bins, uint32_t bin_shift, uint64_t *regbase,
                   uint32_t *out, hipStream_t st);
 void launch_apply(uint8_t *sim, size_t sim_bytes, const uint32_t *recs, const uint64_t *regbase, uint32_t bin_shift, hipStream_t st);

@@ -3360,7 +3360,7 @@ void launch_bin_rowscan(uint32_t *counts, uint32_t *totals, uint32_t n_bins, uin
     hipLaunchKernelGGL(k_bin_rowscan, dim3((n_bins + 3u) / 4u), dim3(256), 0, st, counts, totals, n_bins, n_prod);
 }
 
-void launch_part(const ScanArgs &a, uint32_t n_prod, const uint64_t *binbase, uint32_t *out, hipStream_t st, bool p64)
+void launch_part(const ScanArgs &a, uint32_t n_prod, const uint64_t *binbase, uint32_t *out, hipStream_t st, bool p64, bool lines_ok)
 {
     static std::atomic<bool> attr_set[MAX_DEV];              // the attribute is per device
     std::atomic<bool> &set = attr_set[cur_device()];
@@ -3370,7 +3370,6 @@ void launch_part(const ScanArgs &a, uint32_t n_prod, const uint64_t *binbase, ui
         set.store(true, std::memory_order_relaxed);
     }
     // whole-line writes (k_part_lines) wherever the bins' line buffers fit the LDS next to the stage; LIME_PART_LINES=0: comparison runs
-    static const bool lines_ok = !(getenv("LIME_PART_LINES") && atoi(getenv("LIME_PART_LINES")) == 0);
     static std::atomic<uint32_t> lines_room[MAX_DEV][2];     // dynamic LDS k_part_lines may ask for on this device (0: not asked yet)
     const size_t lds_lines = part_lines_lds(a.n_bins, p64);
     const void *kl = p64 ? reinterpret_cast<const void *>(k_part_lines<true>) : reinterpret_cast<const void *>(k_part_lines<false>);
@@ -3417,7 +3416,6 @@ void launch_apply(uint8_t *sim, size_t sim_bytes, const uint32_t *recs, const ui
 void launch_sort_tiles(const uint32_t *recs, const uint64_t *binbase, uint32_t n_bins, uint32_t bin_shift, uint32_t *tbase, uint16_t *idx, uint16_t *out16,
                        hipStream_t st, bool big_rows, bool tbase_ready)
 {
-    if (const char *e = getenv("LIME_SORT_NT")) big_rows = atoi(e) != 0;                     // tests: either kind of row stores on any input
     if (!tbase_ready) hipLaunchKernelGGL(k_tile_bases, dim3(1), dim3(PART_WG), 0, st, binbase, n_bins, tbase);
     // enough workgroups to fill the device evenly: about 8 per CU (two are resident at a time)
     const uint32_t per_bin = n_bins >= 2048u ? 1u : (2048u + n_bins - 1u) / n_bins;
@@ -3439,7 +3437,6 @@ void launch_apply_tiles_fin(int mode, size_t sim_bytes, uint32_t bin_shift, cons
 {
     const uint32_t n_regions = (uint32_t)((sim_bytes + ((size_t)1 << REGION_SHIFT) - 1) >> REGION_SHIFT);
     const dim3 grid(apply_tiles_grid(n_regions)), wg(APPLY_WG);
-    if (const char *e = getenv("LIME_APPLY_WIDE")) many_records = atoi(e) != 0;            // tests: either variant on any input
     if (mode == 1) {
         if (many_records) hipLaunchKernelGGL((k_apply_tiles<true, 1>), grid, wg, 0, st, nullptr, sim_bytes, out16, tbase, idx, bin_shift, n_regions, fin);
         else              hipLaunchKernelGGL((k_apply_tiles<false, 1>), grid, wg, 0, st, nullptr, sim_bytes, out16, tbase, idx, bin_shift, n_regions, fin);
@@ -3458,7 +3455,6 @@ void launch_apply_by_tiles(uint8_t *sim, size_t sim_bytes, const uint32_t *recs,
     ApplyFin none; memset(&none, 0, sizeof none);
     // the variant for many records (a step's groups 64 .. 79 in one pass): N = 1e10 (1.2e9 records) 1.09 -> 0.84 ms, configs[4]'s shape (3.2e8)
     // 2.43 -> 2.08; the other one where there are fewer: configs[2] (1.2e8) +3 %, configs[3]'s shape +3 %, text +7 % with the first
-    if (const char *e = getenv("LIME_APPLY_WIDE")) many_records = atoi(e) != 0;            // tests: either variant on any input
     if (many_records) hipLaunchKernelGGL((k_apply_tiles<true, 0>), dim3(grid), dim3(APPLY_WG), 0, st, sim, sim_bytes, out16, tbase, idx, bin_shift, n_regions, none);
     else hipLaunchKernelGGL((k_apply_tiles<false, 0>), dim3(grid), dim3(APPLY_WG), 0, st, sim, sim_bytes, out16, tbase, idx, bin_shift, n_regions, none);
 }

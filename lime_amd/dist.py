@@ -137,6 +137,13 @@ class Comm:
         if not bool((blk == want).all()) or not bool((src == want).all()):
             raise RuntimeError(f"RCCL uint8 sum does not wrap modulo 256: got {int(blk[0])}/{int(src[0])}, want {want}")
 
+    def count(self):
+        """the ranks RCCL counts in the communicator (ncclCommCount)"""
+        import ctypes as C
+        k = C.c_int(0)
+        self._check(self.lib.lime_comm_count(self.h, C.byref(k)))
+        return int(k.value)
+
     def barrier(self):
         import torch.distributed as dist
         dist.barrier(group=self.group)
@@ -215,6 +222,9 @@ class HostComm:
         ctx.apply_records_dev(self.world, rx, srcoff, nb, bin_shift, bt, len(bigs), cell_lo, block_bytes, block_t, stream)
         torch.cuda.synchronize()
         return cell_lo, block_bytes
+
+    def count(self):
+        return self.world                                   # (no RCCL communicator in the rehearsal)
 
     def check_uint8_sum_wraps(self):
         import torch

@@ -9,6 +9,11 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
+# The library reads its tuning / test knobs from the environment only in a process that says it is a test (lime_init, include/lime_hip.h):
+# every LIME_<KNOB> a test sets with monkeypatch.setenv before it creates a Context -- and the drop-in programs the tests start -- depend on it.
+# Under it the library also fills every block it recycles from its process-wide cache with 0xA5: nothing may rely on what a fresh allocation holds.
+os.environ.setdefault("LIME_TEST_HOOKS", "1")
+
 GOLDEN_DIR = os.path.join(ROOT, "tests", "golden")
 GOLDEN_CASES = sorted(os.path.splitext(os.path.basename(p))[0] for p in glob.glob(os.path.join(GOLDEN_DIR, "*.npz"))
                       if not os.path.basename(p).startswith(("classify_", "example_")))   # those: tests/test_classify_cpu.py, tests/test_example_gpu.py
@@ -43,3 +48,17 @@ def golden(request):
     g = load_golden(request.param)
     g["name"] = request.param
     return g
+
+
+@pytest.fixture(scope="module", autouse=True)
+def _trim_block_cache_per_module(request):
+    """contexts leave their large device blocks with the library (lime_trim_cache): hand them back between test modules, so that the
+    full-size tests of a later module find the whole device; within a module the recycling (poisoned under LIME_TEST_HOOKS) is what is tested"""
+    yield
+    try:
+        import torch
+        if torch.cuda.is_available():
+            import lime_amd
+            lime_amd.trim_cache()
+    except Exception:
+        pass

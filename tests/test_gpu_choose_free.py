@@ -122,7 +122,7 @@ def test_choose_without_the_table_wraps_modulo_256(monkeypatch):
 @pytest.mark.parametrize("shape", ["C3", "C2x"])
 def test_choose_without_the_table_at_full_size(monkeypatch, shape):
     """configs[2] (10^9 symbols, 10^6 x 5000, EBWT=0) and a configs[1]-like EBWT=1 pass over a 1.5 GB table: the lists of the call without the
-    table == the lists of table + k_choose + k_gather_pairs (LIME_CHOOSE_FREE=0), for a beta that lets a part of the rows pass"""
+    table == the lists of table + k_choose + k_gather_pairs (option choose_free 0), for a beta that lets a part of the rows pass"""
     import torch
     import lime_amd
     n, nr, ng, ebwt_on, mode = {"C3": (1_000_000_000, 1_000_000, 5000, False, 0), "C2x": (300_000_000, 500_000, 3000, True, 1)}[shape]
@@ -134,7 +134,7 @@ def test_choose_without_the_table_at_full_size(monkeypatch, shape):
     res = []
     try:
         for free in ("1", "0"):
-            monkeypatch.setenv("LIME_CHOOSE_FREE", free)
+            c.set_option("choose_free", free)
             mx, off, pairs, s = c.fused_choose_dev(lcp, da, eb, n, nr, ng, 16, 85, 0.03)      # max >= 3 passes
             res.append((mx, off, pairs, s.n_updates, s.n_clusters))
         assert c.host_times()["choose_without_table"] == 1

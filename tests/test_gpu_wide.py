@@ -201,6 +201,7 @@ def test_full_size_clustered_passes_stay_binned(shape):
     from lime_amd.dist import shard_ranges, combine_edges
     n, nr, ng, ebwt_on = {"n1e10_clustered": (10_000_000_000, 1_000_000, 1000, False), "c5_clustered": (10_000_000_000, 3_000_000, 3423, True)}[shape]
     alpha, dev = 16, torch.device("cuda:0")
+    lime_amd.trim_cache()
     c = lime_amd.Context()
     try:
         lcp = torch.empty(n, dtype=torch.int32, device=dev); da = torch.empty_like(lcp)
@@ -291,6 +292,7 @@ def test_more_than_2_32_records_in_one_pass(nr, ng):
     import torch
     import lime_amd
     torch.cuda.empty_cache()
+    lime_amd.trim_cache()
     free, total = torch.cuda.mem_get_info()
     n = 19_000_000_000
     if free < (8 * n + 2 * nr * ng + 70 * (1 << 30)):
