@@ -3,6 +3,7 @@ declares, fails loudly without a GPU, and its pure host helpers (same source as 
 routines, lime_amd/csrc/lime_device.h) agree with the oracle.  No GPU compute here."""
 import ctypes as C
 import os
+import sys
 import re
 
 import numpy as np
@@ -146,6 +147,34 @@ def test_scan_resources():
         pytest.skip("no hipcc")
     r = subprocess.run(["make", "-C", os.path.join(ROOT, "lime_amd", "csrc"), "-s", "resources"], capture_output=True, timeout=600)
     assert r.returncode == 0, r.stdout.decode()[-2000:]
+
+
+def test_exec_lint_catches_a_shuffle_under_a_condition(tmp_path):
+    """tools/exec_lint.py (part of `make resources`, so test_scan_resources runs it on HEAD): round 5's bug put back into a copy of the kernels --
+    k_apply_tiles<true> fetching its index entries with `lx < nl ? __shfl(a, lx) : 0`, a shuffle the compiler puts under a branch, so that source
+    lanes outside the condition deliver 0 (commit 0b63920 fixed it) -- must fail the lint, in exactly that kernel"""
+    import shutil
+    import subprocess
+    hipcc = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
+    if not os.path.exists(hipcc):
+        pytest.skip("no hipcc")
+    src = open(os.path.join(ROOT, "lime_amd", "csrc", "lime_kernels.hip")).read()
+    fixed = ("            const uint32_t sa = (uint32_t)__shfl((int)a_, (int)(lx & 63u)), se = (uint32_t)__shfl((int)e_, (int)(lx & 63u));\n"
+             "            s.fax = lx < nl_ ? sa : 0u; s.fex = lx < nl_ ? se : 0u;")
+    buggy = "            s.fax = lx < nl_ ? (uint32_t)__shfl((int)a_, (int)lx) : 0u; s.fex = lx < nl_ ? (uint32_t)__shfl((int)e_, (int)lx) : 0u;"
+    assert src.count(fixed) == 1, "the site the test puts the bug back into has moved: update the test"
+    (tmp_path / "lime_kernels.hip").write_text(src.replace(fixed, buggy))
+    asm = tmp_path / "lime_kernels.s"
+    r = subprocess.run([hipcc, "-O3", "-std=c++17", "-fPIC", "-fno-strict-aliasing", "--offload-arch=gfx950", "-Wno-unused-function", "-w",
+                        "-I" + os.path.join(ROOT, "include"), "-I" + os.path.join(ROOT, "lime_amd", "csrc"), "--cuda-device-only", "-S",
+                        "-gline-tables-only", str(tmp_path / "lime_kernels.hip"), "-o", str(asm)], capture_output=True, timeout=600)
+    assert r.returncode == 0, r.stderr.decode()[-2000:]
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "exec_lint.py"), str(asm), "--allow", os.path.join(ROOT, "tools", "exec_lint_allow.txt")],
+                       capture_output=True, timeout=300)
+    out = r.stdout.decode()
+    assert r.returncode == 1 and "EXEC LINT FAILED" in out, out[-2000:]
+    flagged = [ln for ln in out.splitlines() if ln.startswith("  ")]
+    assert flagged and all("k_apply_tiles<1," in ln and "ds_bpermute_b32" in ln for ln in flagged), out[-2000:]
 
 
 def test_library_buffers_become_arrays_without_a_copy_and_are_freed_with_the_last_view():

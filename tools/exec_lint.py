@@ -22,9 +22,12 @@ joins take the longer stack (a loop header inherits the back edge's restrictions
 empty is reported as (kernel, source file:line, mnemonic).  v_readlane / v_readfirstlane / v_writelane are NOT reported: they ignore EXEC and
 move the register as it is (the compiler's SGPR spills use them everywhere).
 
-The allow list (tools/exec_lint_allow.txt) holds the sites that are meant to run that way: `kernel-regex  file:line  count  reason`, count = how
-many reported instructions that (kernel, line) pair may have -- an inlined helper's line stands for all its call sites in a kernel, so a NEW call
-site under a condition raises the count and fails the gate.  Exit code 1 on any site not covered.
+The compiler cannot know that a condition is the same for all 64 lanes (a wave's window number, `while (__ballot(..))`), so code under such a
+condition is reported too: the allow list (tools/exec_lint_allow.txt) holds every site that has been LOOKED AT and is meant to run that way --
+`mangled-kernel-name  file:line  count  reason`, count = how many reported instructions that (kernel, line) pair has.  An inlined helper's line
+(wave_incl_scan, __shfl) stands for all its call sites in a kernel, so a NEW call site under a condition raises the count and fails the gate: a
+ratchet.  `--update` rewrites the list from the code as it stands (counts refreshed, reasons kept, new sites marked UNREVIEWED, which fails the
+gate until a reason has been written).  Exit code 1 on any site not covered.
 """
 import re
 import sys
@@ -119,9 +122,11 @@ def blocks_of(items):
 
 def step(stack, insn):
     """EXEC restriction stack after one instruction"""
+    if "exec" not in insn:
+        return stack
     m = re.match(r"s_\w+_saveexec_b64\s+(\S+?),", insn)
     if m:
-        return stack + (m.group(1),)
+        return stack if m.group(1) in stack else stack + (m.group(1),)      # (a loop's body re-entered: the same save, not a deeper one)
     m = re.match(r"(s_\w+_b64)\s+exec,\s*(\S+?)(?:,\s*(\S+))?$", insn)
     if not m:
         return stack
@@ -134,13 +139,13 @@ def step(stack, insn):
     if op == "s_andn2_b64":
         return stack if other in stack else stack + (other,)
     if op == "s_and_b64":
-        return stack + ("&",)
+        return stack if stack and stack[-1] == "&" else stack + ("&",)      # (once: around a loop the same narrowing comes again and again)
     if op == "s_mov_b64":
         if a == "-1":
             return ()
         if a in stack:
             return stack[:len(stack) - 1 - stack[::-1].index(a)]
-        return stack + (a,)
+        return stack if ("=" + a) in stack else stack + ("=" + a,)
     return stack            # s_xor_b64 exec and anything else: as restricted as before
 
 
@@ -181,37 +186,56 @@ def main():
         allow_path = sys.argv[sys.argv.index("--allow") + 1]
         args = [a for a in args if a != allow_path]
     txt = open(args[0]).read()
-    allow = []
+    allow, head = [], []
     if allow_path:
-        for ln in open(allow_path):
-            ln = ln.strip()
-            if not ln or ln.startswith("#"):
-                continue
-            pat, where, count, reason = ln.split(None, 3)
-            allow.append((re.compile(pat), where, int(count), reason))
+        try:
+            for ln in open(allow_path):
+                t = ln.strip()
+                if not t or t.startswith("#"):
+                    if not allow:
+                        head.append(ln.rstrip("\n"))
+                    continue
+                sym, where, count, reason = t.split(None, 3)
+                allow.append((sym, where, int(count), reason))
+        except FileNotFoundError:
+            pass
     funcs = parse_functions(txt)
     sites = defaultdict(int)
     for sym, items in funcs.items():
         for loc, op, depth in lint_function(items):
             where = "%s:%d" % loc if loc else "?:0"
             sites[(sym, where, op)] += 1
-    per_line = defaultdict(int)
+    per_line, ops_of = defaultdict(int), defaultdict(set)
     for (sym, where, op), n in sites.items():
         per_line[(sym, where)] += n
+        ops_of[(sym, where)].add(op)
+    if "--update" in sys.argv:
+        # the list as the code stands now: counts refreshed, reasons kept where (kernel, line) was listed before, new sites marked UNREVIEWED (the gate
+        # fails on them until somebody has looked at the site and written down why it may run with lanes switched off)
+        known = {(a[0], a[1]): a[3] for a in allow}
+        with open(allow_path, "w") as f:
+            f.write("\n".join(head) + ("\n" if head else ""))
+            for (sym, where), n in sorted(per_line.items()):
+                f.write(f"{sym}  {where}  {n}  {known.get((sym, where), 'UNREVIEWED ' + ', '.join(sorted(ops_of[(sym, where)])))}\n")
+        print(f"{allow_path}: {len(per_line)} site(s) written")
+        return
     bad = []
+    cover = {(a[0], a[1]): a for a in allow}
     for (sym, where), n in sorted(per_line.items()):
-        ok = [a for a in allow if a[0].search(sym) and a[1] == where]
-        cap = sum(a[2] for a in ok)
-        ops = ", ".join(sorted({op for (s2, w2, op) in sites if s2 == sym and w2 == where}))
+        a = cover.get((sym, where))
+        ops = ", ".join(sorted(ops_of[(sym, where)]))
         if "--list" in sys.argv:
             print(f"{demangle_hint(sym):40s} {where:32s} {n:3d}  {ops}   [{sym}]")
-        if n > cap:
-            bad.append(f"{demangle_hint(sym)}: {n} cross-lane operation(s) ({ops}) under a partial EXEC mask at {where}" + (f" (allow list covers {cap})" if cap else "") + f"   [{sym}]")
+        if a is None or n > a[2]:
+            bad.append(f"{demangle_hint(sym)}: {n} cross-lane operation(s) ({ops}) under a partial EXEC mask at {where}" + (f" (the allow list covers {a[2]})" if a else "") + f"   [{sym}]")
+        elif a[3].startswith("UNREVIEWED"):
+            bad.append(f"{demangle_hint(sym)}: the site {where} is in the allow list without a reason (UNREVIEWED)   [{sym}]")
     if bad:
-        print("EXEC LINT FAILED -- cross-lane operations that run with lanes switched off (execute them with all lanes, select afterwards; or, if it is\n"
-              "meant, add the site to tools/exec_lint_allow.txt with the reason):\n  " + "\n  ".join(bad))
+        print("EXEC LINT FAILED -- cross-lane operations that run with lanes switched off (execute them with all lanes and select afterwards; or, if it is\n"
+              "meant, list the site in tools/exec_lint_allow.txt with the reason -- `tools/exec_lint.py FILE.s --allow tools/exec_lint_allow.txt --update` refreshes the counts):\n  " + "\n  ".join(bad))
         sys.exit(1)
-    print(f"exec lint ok ({len(funcs)} functions, {sum(per_line.values())} allowed site(s) under a partial EXEC mask)")
+    stale = [f"{a[0]} {a[1]}" for a in allow if per_line.get((a[0], a[1]), 0) < a[2]]
+    print(f"exec lint ok ({len(funcs)} functions, {sum(per_line.values())} listed cross-lane operation(s) under a possibly partial EXEC mask" + (f"; {len(stale)} entries of the allow list are larger than needed" if stale else "") + ")")
 
 
 if __name__ == "__main__":
