@@ -205,11 +205,14 @@ def reference_outputs_match(td, base, wl, lcp_t, da_t, eb_t, n, beta):
     return out
 
 
-def run_pass_series(torch, lime_amd, ldist, wl, n_total, steps, warmup, world, rank, dev, comm, overlap, exchange="dense"):
-    """K timed steps of the workload on this rank's position range; returns (seconds, per-step parts, stats, n_own)."""
+def run_pass_series(torch, lime_amd, ldist, wl, n_total, steps, warmup, world, rank, dev, comm, overlap, exchange="dense", options=None):
+    """K timed steps of the workload on this rank's position range; returns (seconds, per-step parts, stats, n_own).
+    options: lime_set_option knobs for the series' context (the A/B scripts under tools/; bench.py itself passes none)."""
     lo, hi, hi_halo = ldist.shard_ranges(n_total, world)[rank]
     n_own, n_avail = hi - lo, hi_halo - lo
     ctx = lime_amd.Context(dev.index)
+    for k_, v_ in (options or {}).items():
+        ctx.set_option(k_, v_)
     lcp = torch.empty(n_avail, dtype=torch.int32, device=dev)
     da = torch.empty(n_avail, dtype=torch.int32, device=dev)
     eb = torch.empty(n_avail, dtype=torch.uint8, device=dev) if wl["ebwt"] else None
@@ -538,18 +541,19 @@ def main():
     headline_parts, headline_ex_ms = r["parts"], r.get("exchange_ms")
     del r
 
-    def make_room(need_bytes):
-        # torch keeps the blocks of the workload before (and reuses them where they fit); they go back to the driver only when the next workload
-        # would not fit beside them.  Not for tidiness: on this platform memory that was freed is CLEARED by the driver inside the next hipMalloc
-        # that gets it, at about 30 GB/s (tools/alloc_bench.hip) -- freeing 90 GB of arrays in front of every workload made the
-        # library's first allocations of the next one take between 1 ms and 5 s (round 5's cold.alloc_ms)
+    def make_room(w, extra=0):
+        # torch keeps the blocks of the workload before (and reuses them where they fit) and the library keeps its own (lime_trim_cache); they go back to
+        # the driver only when the next workload would not fit beside them.  Not for tidiness: on this platform memory that was freed is CLEARED by the
+        # driver inside the next hipMalloc that gets it, at about 30 GB/s (tools/alloc_bench.hip) -- freeing 90 GB of arrays in front
+        # of every workload, as rounds 1-5 did, made the library's first allocations of the next one take between 1 ms and 5 s (cold.alloc_ms).
+        # What must be FREE at the driver: the library's record pool + binned records + scratch (16 bytes per expected update record, margins included,
+        # + 0.3 bytes per symbol); torch releases its own cache by itself when one of ITS allocations does not fit
+        dens = 0.25 if (w["mode"] != 0) else 0.13
+        need = int(w["n"] * (dens * 16 + 0.3)) + extra + (2 << 30)
         free_b, _tot = torch.cuda.mem_get_info()
-        if free_b < need_bytes:
+        if free_b < need:
             torch.cuda.empty_cache()
             lime_amd.trim_cache()
-
-    def need_of(w):
-        return w["n"] * (8 + w["ebwt"]) + w["nr"] * w["ng"] + int(w["n"] * 0.45 * 8 * 1.7) + (4 << 30)
 
     if not args.no_also:
         also = {}
@@ -559,7 +563,7 @@ def main():
                     continue
                 w2 = WORKLOADS[name]
                 try:
-                    make_room(need_of(w2))
+                    make_room(w2)
                     k = max(5, args.steps // 2) if w2["n"] >= 10_000_000_000 else 3 if name == "c4_shape" else max(10, args.steps)
                     r2 = run_pass_series(torch, lime_amd, ldist, w2, w2["n"], k, 2, 1, 0, dev, None, overlap=False)
                     also[name] = summarize(w2, r2, w2["n"], k)
@@ -570,7 +574,7 @@ def main():
             # ClusterBWT_DA.cpp:385-443 would scan it single-threaded)
             for name, key in (("c3", "c3_with_choose"), ("c4_shape", "c4_with_choose")):
                 try:
-                    make_room(need_of(WORKLOADS[name]) + WORKLOADS[name]["nr"] * WORKLOADS[name]["ng"])
+                    make_room(WORKLOADS[name], WORKLOADS[name]["nr"] * WORKLOADS[name]["ng"])      # (the with-table finish allocates the table in the library)
                     also[key] = choose_flow(torch, lime_amd, dev, name)
                 except Exception as e:
                     also[key] = {"failed": str(e)}

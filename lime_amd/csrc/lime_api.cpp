@@ -117,6 +117,7 @@ struct lime_ctx {
     int choose_free = -1;                   // lime_fused_choose_dev: 1 = without the table wherever the layout has a second level, 0 = never
     bool no_staging = false, force_staging = false, force_rccl = false, debug_stats = false;
     uint64_t detect_chunk = 0, score_chunk = 0;             // symbols per chunk of lime_detect / lime_score* walks (0: by the sources)
+    uint32_t dense_min = 64;                // k_scan: windows with more accepted clusters list their 2-symbol clusters apart (option dense_min; tests: 0 = every window)
     int io_threads = 0;                     // host threads that stage pageable sources into the pinned ring (0: 8, at most the CPUs this process may use)
     // timing with HIP events on the launch stream: per pass {pass start, scan start, scan end, pass end}
     bool timing = false;
@@ -274,6 +275,7 @@ static int set_option(lime_ctx *c, const char *key, const char *s)
     else if (is("debug_stats")) c->debug_stats = v != 0 || !*s;
     else if (is("debug_alloc")) g_debug_alloc.store(v != 0 || !*s, std::memory_order_relaxed);
     else if (is("poison_cache")) g_poison_cache.store(v != 0 || !*s, std::memory_order_relaxed);
+    else if (is("dense_min")) c->dense_min = *s ? (uint32_t)strtoul(s, nullptr, 0) : 64u;
     else if (is("io_threads")) c->io_threads = v >= 1 ? (v > 64 ? 64 : (int)v) : 0;
     else return fail(LIME_ERR_ARG, "lime_set_option: unknown option \"%s\"", key);
     return LIME_OK;
@@ -318,7 +320,7 @@ extern "C" int lime_init(int device, lime_ctx **out)
             {"LIME_PROBE_MIN", "probe_min"}, {"LIME_FORCE_P64", "force_p64"}, {"LIME_P64_TEST_BASE", "p64_test_base"}, {"LIME_MAX_BLOCKS", "max_blocks"},
             {"LIME_CHOOSE_FREE", "choose_free"}, {"LIME_APPLY_WIDE", "apply_wide"}, {"LIME_SORT_NT", "sort_nt"}, {"LIME_PART_LINES", "part_lines"},
             {"LIME_NO_STAGING", "no_staging"}, {"LIME_FORCE_STAGING", "force_staging"}, {"LIME_DETECT_CHUNK", "detect_chunk"}, {"LIME_SCORE_CHUNK", "score_chunk"},
-            {"LIME_FORCE_RCCL", "force_rccl"}, {"LIME_DEBUG_STATS", "debug_stats"}, {"LIME_DEBUG_ALLOC", "debug_alloc"}};
+            {"LIME_FORCE_RCCL", "force_rccl"}, {"LIME_DENSE_MIN", "dense_min"}, {"LIME_DEBUG_STATS", "debug_stats"}, {"LIME_DEBUG_ALLOC", "debug_alloc"}};
         for (const auto &hk : hooks)
             if (const char *s = getenv(hk[0])) {
                 const int rc = set_option(c, hk[1], s);
@@ -438,6 +440,7 @@ static ScanArgs base_args(lime_ctx *c, const uint32_t *lcp, const uint32_t *da, 
     // 1e8 symbols 1 .. 2 % faster with three quarters of the rounds round-robin (fewer trips to the device-wide counter in a 0.2 ms kernel)
     a.static_pct = c->scan_static_pct >= 0 ? (uint32_t)c->scan_static_pct : (n_avail >= 500000000ull ? 0u : 75u);
     a.ablate = c->ablate;
+    a.dense_min = c->dense_min;
     return a;
 }
 

@@ -706,27 +706,30 @@ __device__ __forceinline__ uint32_t score_lists(LDS &L, UpdQueue &qu, const Scan
     return nupd;
 }
 
-// Clusters of exactly 2 symbols, one lane per cluster: an accepted one holds one read and one genome (never a
-// repeated document), so it is ONE pair -- two documents, one read bit, one compatibility lookup, at most one queue
-// entry per lane (slots from a ballot, no prefix sum).  Real collections are mostly such clusters (98 % in the
-// text-derived fixture): windows with more than 64 clusters score theirs in rounds of their own.
+// Clusters of exactly 2 symbols, one lane per cluster: an accepted one holds one read and one genome (never a repeated document), so it is ONE
+// pair -- two documents, the roles by one compare, one compatibility lookup, at most one queue entry per lane (slots from a ballot, no prefix sum).
+// Real collections are mostly such clusters (98 % in the text-derived fixture, ~245 per window): a dense window lists them apart from the others
+// when it builds its cluster list (round 6: the heads of 2-symbol clusters are bit arithmetic on the chunk's head mask), so a round of them reads
+// 64 positions and scores them -- no length from the staged head bits, no filing of the other clusters in between.
+// (Rounds 3-5 found them inside the rounds over ALL clusters: list entry, 32 head bits, length, classification, then this routine with its read
+// bit from the staged mask: ~140 vector instructions and 11 LDS instructions a round of 64, five rounds a window of text -- half that scan.
+// Scoring them where they lie instead -- mask word by mask word, position 64 j + l on lane l, documents by a conflict-free ds_read2 -- was built
+// and measured in round 6 and is SLOWER: 16 words a window at 24 % of the lanes cost more LDS and vector instructions than 4 full rounds: text
+// scan 0.276 -> 0.285-0.307 ms, profiles/r06_inplace_ab.txt.)
 template <int EBWT, typename LDS>
 __device__ __forceinline__ uint32_t score_len2(LDS &L, const WgTables &T, UpdQueue &qu, const ScanArgs &a, bool on, uint32_t p)
 {
     const uint32_t d0 = L.da[p], d1 = L.da[p + 1u];
-    const uint32_t r0 = ((uint32_t)L.rb[p >> 3] >> (p & 7u)) & 1u;           // position p is the read; else p + 1 is
+    const bool r0 = d0 < a.n_reads;                                          // position p is the read; else p + 1 is
     bool hit = on;
     if (EBWT) hit = hit && ((T.compatb[L.fl[p]] >> T.symidx[L.fl[p + 1u]]) & 1u);
     const uint32_t rd = r0 ? d0 : d1, gd = (r0 ? d1 : d0) - a.n_reads;
-    const bool bad = hit && gd >= a.n_refs;
-    if (__ballot(bad)) { if (bad) atomicOr(&cold(a).stats->flags, LIME_FLAG_DOCID); }
-    hit = hit && !bad;
-    const uint64_t m = __ballot(hit);
+    const uint64_t m = EBWT ? __ballot(hit) : __ballot(on);
     const uint32_t tot = (uint32_t)__popcll(m);
     while (qu.n + tot > qu.cap) drain(qu, a);
     if (hit) {
-        const uint32_t slot = qu.n + (uint32_t)__popcll(m & ((1ull << lane_id()) - 1ull));
-        qu.qr[slot] = rd; qu.qg[slot] = gd | (1u << T_SHIFT);
+        const uint32_t slot = qu.n + rank_in(m);
+        qu.qr[slot] = rd; qu.qg[slot] = gd | (1u << T_SHIFT);               // (document ids are range-checked by the drains, on full waves)
     }
     qu.n += tot;
     return hit ? 1u : 0u;
@@ -1215,10 +1218,10 @@ __global__ __launch_bounds__((ScanCfg<EBWT, BIN>::wg)) __attribute__((amdgpu_wav
                 for (int k = 0; k < (int)PPL / 4; ++k) reinterpret_cast<u32u *>(L.fl)[64 * k + (int)lane] = regs.bv[k];
             uint32_t lane_v = lane;                         // opaque per window: the lane masks below are compared here instead of living in SGPR pairs through the loop
             asm volatile("" : "+v"(lane_v));
-            if (lane_v < HALO) { L.da[WIN + lane] = regs.hd; if (EBWT) L.fl[WIN + lane] = (uint8_t)regs.hb; }
+            if (lane_v < HALO) { L.da[WIN + lane_v] = regs.hd; if (EBWT) L.fl[WIN + lane_v] = (uint8_t)regs.hb; }      // (lane_v: these addresses are recomputed per window, not held through the loop)
             if (lane_v <= WIN / 64) {
-                *reinterpret_cast<u64a *>(&L.hb[8u * lane]) = h;
-                *reinterpret_cast<u64a *>(&L.rb[8u * lane]) = r;
+                *reinterpret_cast<u64a *>(&L.hb[8u * lane_v]) = h;
+                *reinterpret_cast<u64a *>(&L.rb[8u * lane_v]) = r;
             }
             const uint32_t sh = 16u * (lane & 3u);
             hb = (uint32_t)(shfl64(h, (int)(lane >> 2)) >> sh) & 0xFFFFu;
@@ -1310,89 +1313,110 @@ __global__ __launch_bounds__((ScanCfg<EBWT, BIN>::wg)) __attribute__((amdgpu_wav
         if (MODE == 0 && lane == 0) a.tile_cnt[win] = total;
 #endif
         if (MODE == 0) {
-            {
+            // A dense window (more than 64 accepted clusters; real collections: hundreds, 98 % of them of 2 symbols) lists its 2-symbol clusters
+            // apart: such a cluster is an accepted, owned head (c.ah) followed by a non-head and a head -- bits b + 1, b + 2 of the chunk's head
+            // mask, the last two from the next chunk's (behind the last chunk: the read-ahead's).  The other clusters come first in the list,
+            // the 2-symbol ones behind them: listM[total - total2 .. total).
+            const bool defer = total > cold(a).dense_min;                       // (64; tests: 0 = every window)
+            uint32_t m2c = 0, total2 = 0, k2 = 0;
+            if (defer) {                                                        // wave-uniform
+                uint32_t lv = lane;                                             // (opaque per window: the shuffle index is not held through the loop)
+                asm volatile("" : "+v"(lv));
+                const uint32_t nb = (uint32_t)__shfl((int)(c.h & 3u), (int)((lv + 1u) & 63u));
+                const uint32_t h18 = c.h | ((lv == 63u ? H64 & 3u : nb) << 16);
+                m2c = c.ah & ~(h18 >> 1) & (h18 >> 2);
+                const uint32_t cnt2 = (uint32_t)__popc(m2c), incl2 = wave_incl_scan(cnt2);
+                total2 = rl32(incl2, 63);
+                k2 = (total - total2) + (incl2 - cnt2);
+                acc_max = m2c && acc_max < 2u ? 2u : acc_max;
+                {
+                    uint32_t m = c.ah, k = (incl - cnt) - (incl2 - cnt2);
+                    while (__ballot(m != 0u)) {
+                        if (m) {
+                            const uint32_t b = (uint32_t)__builtin_ctz(m);
+                            const bool two = (m2c >> b) & 1u;
+                            L.listM[two ? k2 : k] = (uint16_t)(c0 | b);
+                            k2 += (uint32_t)two; k += (uint32_t)!two;
+                            m &= m - 1u;
+                        }
+                    }
+                }
+            } else {
                 uint32_t m = c.ah, k = incl - cnt;
                 while (__ballot(m != 0u)) {
                     if (m) { L.listM[k++] = (uint16_t)(c0 | (uint32_t)__builtin_ctz(m)); m &= m - 1u; }
                 }
             }
             PT(3)
-            // Rounds of 64 clusters.  Phase 0 reads the positions and takes every cluster's length from the head bits
-            // (the next head after it).  A window with at most 64 clusters scores the short ones (<= 4 symbols) at once;
-            // one with more (real collections: hundreds, 98 % of them of 2 symbols) scores its 2-symbol clusters in
-            // phase 0 -- one pair each -- and files the others (position | (len-1) << 12, over the already consumed head
-            // of the list) for phase 1.  Clusters of 5..SMALL_MAX symbols are filed the same way for the rows routine.
-            uint32_t nM = 0, nD = 0;
-            const bool defer = total > 64u;
+            // Rounds of 64 clusters.  First the 2-symbol clusters of a dense window (listed apart: positions only, one pair each), then the others:
+            // a round reads 64 positions, takes every cluster's length from the head bits (the next head after it), scores the short ones
+            // (<= 4 symbols) at once and files those of 5..SMALL_MAX symbols (position | (len-1) << 12, over the already consumed head of the
+            // list) for the rows routine.
+            uint32_t nM = 0;
+            const uint32_t n_rest = total - total2;
+            if (!ABL(4) && !ABL(10))
+#pragma unroll 1
+            for (uint32_t base = 0; base < total2; base += 64u) {
+                const uint32_t t = base + lane;
+                const bool on = t < total2;
+                const uint32_t p = on ? (uint32_t)L.listM[n_rest + t] & 0xFFFu : 0u;
+                acc_upd += score_len2<EBWT>(L, T, qu, a, on, p);
+            }
             if (!ABL(4))
 #pragma unroll 1
-            for (uint32_t phase = 0; phase < (defer ? 2u : 1u); ++phase) {
-                const uint32_t n_items = phase ? nD : total;
-#pragma unroll 1
-                for (uint32_t base = 0; base < n_items; base += 64u) {
-                    const uint32_t t = base + lane;
-                    const bool on = t < n_items;
-                    const uint32_t item = on ? L.listM[t] : 0u;
-                    uint32_t p = item & 0xFFFu, len = (item >> 12) + 1u;
-                    if (phase == 0u) {
-                        const uint32_t w = bits_at(L.hb, p + 1u);             // head bits of p+1 .. p+32
-                        len = w ? (uint32_t)__builtin_ctz(w) + 1u : 33u;
-                        if (!on) len = 0u;
-                        if (__ballot(len > SMALL_MAX)) {
-                            if (len >= 33u) {                                 // rare: walk the head bytes to the end of the run
-                                uint32_t q = p + 33u, e = WPOS;               // an accepted cluster closes before WPOS
-                                while (q < WPOS) {
-                                    const uint32_t hbq = (uint32_t)L.hb[q >> 3] >> (q & 7u);
-                                    if (hbq) { e = q + (uint32_t)__builtin_ctz(hbq); break; }
-                                    q = (q | 7u) + 1u;
-                                }
-                                len = e - p;
-                                if (len > MID_MAX) {                          // one workgroup per such cluster later
-                                    const uint32_t kk = atomicAdd(&cold(a).stats->n_big, 1u);
-                                    if (kk < cold(a).big_cap) { cold(a).big[kk].pStart = lo + p; cold(a).big[kk].len = len; }
-                                }
+            for (uint32_t base = 0; base < n_rest; base += 64u) {
+                const uint32_t t = base + lane;
+                const bool on = t < n_rest;
+                const uint32_t item = on ? L.listM[t] : 0u;
+                const uint32_t p = item & 0xFFFu;
+                uint32_t len;
+                {
+                    const uint32_t w = bits_at(L.hb, p + 1u);             // head bits of p+1 .. p+32
+                    len = w ? (uint32_t)__builtin_ctz(w) + 1u : 33u;
+                    if (!on) len = 0u;
+                    if (__ballot(len > SMALL_MAX)) {
+                        if (len >= 33u) {                                 // rare: walk the head bytes to the end of the run
+                            uint32_t q = p + 33u, e = WPOS;               // an accepted cluster closes before WPOS
+                            while (q < WPOS) {
+                                const uint32_t hbq = (uint32_t)L.hb[q >> 3] >> (q & 7u);
+                                if (hbq) { e = q + (uint32_t)__builtin_ctz(hbq); break; }
+                                q = (q | 7u) + 1u;
                             }
-                            // SMALL_MAX+1 .. MID_MAX symbols (rare): the whole wave is one lane group on the staged window, one cluster at a time
-                            uint64_t mX = __ballot(len > SMALL_MAX && len <= MID_MAX);
-                            while (mX) {
-                                const uint32_t src = (uint32_t)__builtin_ctzll(mX);
-                                mX &= mX - 1ull;
-                                const uint32_t p0 = rl32(p, src), len0 = rl32(len, src);
-                                const bool hvv = lane < len0;
-                                acc_upd += group_score<EBWT, 64>(a, T, qu, hvv ? L.da[p0 + lane] : 0u, (EBWT && hvv) ? L.fl[p0 + lane] : 0u, len0);
+                            len = e - p;
+                            if (len > MID_MAX) {                          // one workgroup per such cluster later
+                                const uint32_t kk = atomicAdd(&cold(a).stats->n_big, 1u);
+                                if (kk < cold(a).big_cap) { cold(a).big[kk].pStart = lo + p; cold(a).big[kk].len = len; }
                             }
                         }
-                        acc_max = len > acc_max ? len : acc_max;
-                    } else if (!on) len = 0u;
-                    PT(4)
-                    if (ABL(10)) continue;
-                    if (phase == 0u && defer) {
-                        const bool is2 = len == 2u;
-                        acc_upd += score_len2<EBWT>(L, T, qu, a, is2, is2 ? p : 0u);
-                        const bool cD = len > 2u && len <= SMALL_MAX;
-                        const uint64_t mD = __ballot(cD);
-                        if (mD) {
-                            if (cD) L.listM[nD + rank_in(mD)] = (uint16_t)(p | ((len - 1u) << 12));
-                            nD += (uint32_t)__popcll(mD);
+                        // SMALL_MAX+1 .. MID_MAX symbols (rare): the whole wave is one lane group on the staged window, one cluster at a time
+                        uint64_t mX = __ballot(len > SMALL_MAX && len <= MID_MAX);
+                        while (mX) {
+                            const uint32_t src = (uint32_t)__builtin_ctzll(mX);
+                            mX &= mX - 1ull;
+                            const uint32_t p0 = rl32(p, src), len0 = rl32(len, src);
+                            const bool hvv = lane < len0;
+                            acc_upd += group_score<EBWT, 64>(a, T, qu, hvv ? L.da[p0 + lane] : 0u, (EBWT && hvv) ? L.fl[p0 + lane] : 0u, len0);
                         }
-                        continue;
                     }
-                    const bool cM = len > 4u && len <= 8u;                     // rows in groups of 8 lanes, after the rounds
-                    const uint64_t mM = __ballot(cM);
-                    if (mM) {
-                        if (cM) L.listM[nM + rank_in(mM)] = (uint16_t)(p | ((len - 1u) << 12));
-                        nM += (uint32_t)__popcll(mM);
-                    }
-                    const bool cL = len > 8u && len <= SMALL_MAX;              // rare: groups of 16 lanes, at once (the list holds one round's worth)
-                    const uint64_t mL = __ballot(cL);
-                    const bool sm4 = len >= 2u && len <= 4u;
-                    acc_upd += score_small3<EBWT>(L, T, qu, n_dup, a, sm4, sm4 ? p : 0u, sm4 ? len : 0u);
-                    if (mL && !ABL(11)) {
-                        if (cL) L.m_tstart[rank_in(mL)] = (uint16_t)(p | ((len - 1u) << 12));
-                        acc_upd += score_rows3<EBWT, 16>(L, T, qu, n_dup, a, L.m_tstart, (uint32_t)__popcll(mL));
-                    }
-                    PT(5)
+                    acc_max = len > acc_max ? len : acc_max;
                 }
+                PT(4)
+                if (ABL(10)) continue;
+                const bool cM = len > 4u && len <= 8u;                     // rows in groups of 8 lanes, after the rounds
+                const uint64_t mM = __ballot(cM);
+                if (mM) {
+                    if (cM) L.listM[nM + rank_in(mM)] = (uint16_t)(p | ((len - 1u) << 12));
+                    nM += (uint32_t)__popcll(mM);
+                }
+                const bool cL = len > 8u && len <= SMALL_MAX;              // rare: groups of 16 lanes, at once (the list holds one round's worth)
+                const uint64_t mL = __ballot(cL);
+                const bool sm4 = len >= 2u && len <= 4u;
+                acc_upd += score_small3<EBWT>(L, T, qu, n_dup, a, sm4, sm4 ? p : 0u, sm4 ? len : 0u);
+                if (mL && !ABL(11)) {
+                    if (cL) L.m_tstart[rank_in(mL)] = (uint16_t)(p | ((len - 1u) << 12));
+                    acc_upd += score_rows3<EBWT, 16>(L, T, qu, n_dup, a, L.m_tstart, (uint32_t)__popcll(mL));
+                }
+                PT(5)
             }
             if (nM && !ABL(10) && !ABL(11) && !ABL(4)) acc_upd += score_rows3<EBWT, 8>(L, T, qu, n_dup, a, L.listM, nM);
             if (n_dup >= ScanLds::NDUP / 2u) acc_upd += dup_flush<EBWT>(L, n_dup, a, T, qu);

@@ -12,6 +12,7 @@ pytestmark = pytest.mark.gpu
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 BIN = os.path.join(ROOT, "lime_amd", "bin")
+GOLDEN_FIRST = "edges"                    # (the golden case whose turn also runs the synthetic part of test_dense_windows_...)
 
 
 @pytest.fixture(scope="module")
@@ -670,6 +671,57 @@ def test_dense_small_clusters(ctx, period, n):
         sim, gnc, gml = ctx.fused(lcp, da, e, nr, ng, 16)
         assert (gnc, gml) == (nc, ml)
         assert np.array_equal(sim, exp)
+
+
+@pytest.mark.parametrize("dense_min", ["0", "3", "64", "4294967295"])
+@pytest.mark.parametrize("path", ["cas", "bin"])
+def test_dense_windows_list_their_two_symbol_clusters_apart(monkeypatch, golden, dense_min, path):
+    """Round 6: a window with more than dense_min accepted clusters (64) splits its cluster list -- the 2-symbol clusters, found by bit arithmetic
+    on the chunks' head masks with the next chunk's / the read-ahead's first two bits, behind the others -- and scores them in rounds of their
+    own.  Every golden vector of the reference with the split in EVERY window (0), from 4 clusters on, at the default and never, both update
+    paths, both builds; then runs of period 2 .. 5 (2-symbol clusters back to back, up to 512 per window) whose data ends at every offset of
+    a window and of a 16-position chunk, cut into position-range shards at places inside such runs (ownership of the cluster at the cut)."""
+    import torch
+    import lime_amd
+    monkeypatch.setenv("LIME_UPDATE_PATH", path)
+    c = lime_amd.Context()
+    try:
+        c.set_option("dense_min", dense_min)
+        g = golden
+        for ebwt_on, key in ((True, "sim_e1"), (False, "sim_e0")):
+            sim, nc, ml = c.fused(g["lcp"], g["da"], g["ebwt"] if ebwt_on else None, g["n_reads"], g["n_refs"], g["alpha"])
+            assert nc == len(g["clrs"]) and np.array_equal(sim, g[key]), (g["name"], dense_min, path, ebwt_on)
+        if g["name"] != GOLDEN_FIRST:
+            return
+        rng = np.random.default_rng(77)
+        nr = ng = 2000
+        for period in (2, 3, 5):
+            for n in (1024, 1025, 1039, 1040, 2047, 2050, 3000 + period):
+                lcp = np.full(n, 20, np.uint32); lcp[::period] = 0
+                if period == 3:
+                    lcp[1::6] = 0                              # 1- and 2-symbol segments alternate: heads at b, b + 1 and b, b + 2 patterns
+                da = np.where(rng.random(n) < 0.5, rng.integers(0, nr, n), nr + rng.integers(0, ng, n)).astype(np.uint32)
+                eb = rng.choice(np.frombuffer(b"ACGTNR\x00$", np.uint8), n).astype(np.uint8)
+                cl, nc, ml = O.detect(lcp, da, nr, 16)
+                for e in (eb, None):
+                    exp = O.score(da, e, cl, nr, ng)
+                    sim, gnc, gml = c.fused(lcp, da, e, nr, ng, 16)
+                    assert (gnc, gml) == (nc, ml) and np.array_equal(sim, exp), (period, n, dense_min, path, e is None)
+                # two shards cut inside the runs: the cluster at the cut belongs to the shard of its head
+                tl = torch.from_numpy(lcp.view(np.int32)).cuda(); td = torch.from_numpy(da.view(np.int32)).cuda(); te = torch.from_numpy(eb).cuda()
+                exp = O.score(da, eb, cl, nr, ng)
+                for cut in (504, 1016, 1024, 1032):           # (multiples of 8: a shard's arrays start 16-byte aligned, ebwt 8)
+                    if cut >= n:
+                        continue
+                    acc = torch.zeros(lime_sim_bytes(nr, ng), dtype=torch.uint8, device="cuda")
+                    tot = 0
+                    for lo, hi in ((0, cut), (cut, n)):
+                        c.fused_dev(tl[lo:], td[lo:], te[lo:], hi - lo, n - lo, True, nr, ng, 16, acc, lo == 0)
+                        s, rc = c.stats(); assert rc == 0
+                        tot += s.n_clusters
+                    assert tot == nc and np.array_equal(acc[:nr * ng].cpu().numpy().reshape(nr, ng), exp), (period, n, cut, dense_min, path)
+    finally:
+        c.close()
 
 
 @pytest.mark.gpu
