@@ -434,6 +434,8 @@ def main():
     ap.add_argument("--exchange", default="dense", choices=["dense", "sparse", "auto"],
                     help="N>1: dense = a uint8 reduce-scatter of whole tables (default); sparse = owner-partitioned exchange of update records; "
                          "auto = whichever moves fewer bytes for this workload (decided from a probe pass)")
+    ap.add_argument("--no-probe", action="store_true", help="profiling runs only (tools/profile.sh): no sampled density probe in front of the first pass -- it is a "
+                    "short launch of the same k_scan instance and would pull the kernel's average in a trace 5 %% below that of a pass")
     ap.add_argument("--no-cpu", action="store_true", help="skip the cpu_baseline leg")
     ap.add_argument("--no-also", action="store_true", help="skip the secondary workloads")
     ap.add_argument("--cpu-sample", type=int, default=200_000_000)
@@ -483,7 +485,8 @@ def main():
         n_total = int(args.n_total or wl["n"])
     else:
         n_total = int(args.n or wl["n"]) * world
-    r = run_pass_series(torch, lime_amd, ldist, wl, n_total, args.steps, args.warmup, world, rank, dev, comm, overlap=False, exchange=args.exchange)
+    r = run_pass_series(torch, lime_amd, ldist, wl, n_total, args.steps, args.warmup, world, rank, dev, comm, overlap=False, exchange=args.exchange,
+                        options={"no_probe": "1"} if args.no_probe else None)
     dt, n_clusters, max_len = r["dt"], r["n_clusters"], r["max_len"]
     if world > 1:
         dt = comm.max_float(dt)

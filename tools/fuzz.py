@@ -4,6 +4,7 @@ the GPU box.  Shapes, generator parameters, cluster-length regimes, update paths
 drawn at random; stops at the first difference with a description that reproduces it.  Not part of the test suite
 (time-boxed soak); the fixed cases it found nothing beyond are in tests/."""
 import os, sys, time
+os.environ["LIME_TEST_HOOKS"] = "1"           # the library reads its LIME_<KNOB> variables only in a process that says it is a test (lime_init)
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np
 import torch
@@ -70,6 +71,9 @@ while time.time() < t_end:
         if rng.random() < 0.7:
             os.environ["LIME_P64_TEST_BASE"] = str(int(rng.integers(1, 5)) * (1 << 32) - int(rng.integers(0, 2 * n + 64)))
     ctx = lime_amd.Context()
+    dense_min = str(rng.choice([0, 3, 64, 64, 4294967295]))           # round 6: from how many clusters on a window lists its 2-symbol clusters apart
+    ctx.set_option("dense_min", dense_min)
+    desc += f" dense_min={dense_min}"
     try:
         gcl, gnc, gml = ctx.detect(lcp, da, nr, alpha)
         assert (gnc, gml) == (nc, ml) and np.array_equal(gcl, cl), "detect: " + desc
@@ -108,13 +112,13 @@ while time.time() < t_end:
                 stats["shards"] += 1
             if do_choose:                                                      # clusterChoose without the table (forced wherever the layout has a second level)
                 norm, beta = 85, float(rng.choice([0.0, 0.012, 0.03, 0.3]))
-                os.environ["LIME_CHOOSE_FREE"] = "1"; os.environ["LIME_APPLY_WIDE"] = str(int(rng.integers(0, 2)))
+                ctx.set_option("choose_free", "1"); ctx.set_option("apply_wide", str(int(rng.integers(0, 2))))
                 tl = torch.from_numpy(lcp.view(np.int32)).cuda(); td = torch.from_numpy(da.view(np.int32)).cuda()
                 te = None if e is None else torch.from_numpy(e).cuda()
                 mx, off, prs, st = ctx.fused_choose_dev(tl, td, te, n, nr, ng, alpha, norm, beta)
                 emx, eoff, eprs = expected_choose(exp, norm, beta)
                 assert np.array_equal(mx, emx) and np.array_equal(off, eoff) and np.array_equal(prs, eprs), f"fused_choose beta={beta}: " + tag
-                os.environ.pop("LIME_CHOOSE_FREE"); os.environ.pop("LIME_APPLY_WIDE")
+                ctx.set_option("choose_free", ""); ctx.set_option("apply_wide", "")
                 stats["choose_free"] += ctx.host_times()["choose_without_table"] > 0
             s, rc = ctx.stats()
         stats["cases"] += 1; stats["symbols"] += n; stats["binned"] += path == "bin"; stats["p64"] += p64

@@ -5,9 +5,9 @@
 # 0 = everything (rows, repeats, 17-64, record drains).
 export TMPDIR=/tmp
 export LIME_NO_PROBE=1
-cp lime_amd/liblime_hip.so /tmp/lib_keep.so; cp ${1:-variants/lib_abl.so} lime_amd/liblime_hip.so
+export LIME_LIB=$PWD/${1:-variants/lib_abl.so} LIME_TEST_HOOKS=1      # (round 6: the variant is LOADED instead of copied over the installed library -- ADVICE r5)
 for k in 1 3 4 10 11 0; do
   echo "== ablate=$k"
   LIME_ABLATE=$k C3_PATHS=bin bash tools/pmc_c3.sh "SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_INSTS_LDS SQ_INSTS_VALU SQ_ACTIVE_INST_LDS SQ_BUSY_CYCLES SQ_WAIT_INST_LDS SQ_WAVE_CYCLES" 'k_scan<'
 done
-cp /tmp/lib_keep.so lime_amd/liblime_hip.so
+# (nothing to restore)

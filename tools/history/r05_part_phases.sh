@@ -1,7 +1,7 @@
 #!/bin/bash
 # tools/r05_part_phases.sh -- k_part_lines: absolute cycles of wave 0 per phase and per tile, text-like (1e8 symbols, clustered, 306 MB table) against 2e9 iid symbols with a 1 GB table
 # (variants/lib_ppt.so: -DLIME_PART_TIMING)
-cp lime_amd/liblime_hip.so /tmp/lib_keep.so; cp variants/lib_ppt.so lime_amd/liblime_hip.so
+export LIME_LIB=$PWD/variants/lib_ppt.so LIME_TEST_HOOKS=1      # (round 6: the variant is LOADED, not copied over the installed library -- ADVICE r5)
 for shape in "100000000 452000 678 1 1" "2000000000 1000000 1000 0 0"; do
 set -- $shape
 LIME_NO_PROBE=1 C3_PATHS=bin C3_N=$1 C3_NR=$2 C3_NG=$3 C3_EBWT=$4 C3_MODE=$5 python3 - <<'PY'
@@ -25,4 +25,4 @@ print("   before the tile loop %.0f cycles per workgroup and pass, behind it %.0
 print("   " + "; ".join("%s %.1f%% (%.0f/tile)" % (n, 100.0 * x / tot, x / 512 / passes / tiles_per_wg) for n, x in zip(names, v) if x))
 PY
 done
-cp /tmp/lib_keep.so lime_amd/liblime_hip.so
+# (nothing to restore)
