@@ -1362,7 +1362,7 @@ __global__ __launch_bounds__((ScanCfg<EBWT, BIN>::wg)) __attribute__((amdgpu_wav
                 const uint32_t p = on ? (uint32_t)L.listM[n_rest + t] & 0xFFFu : 0u;
                 acc_upd += score_len2<EBWT>(L, T, qu, a, on, p);
             }
-            if (!ABL(4))
+            if (!ABL(4) && !ABL(12))
 #pragma unroll 1
             for (uint32_t base = 0; base < n_rest; base += 64u) {
                 const uint32_t t = base + lane;
