@@ -590,8 +590,7 @@ def main():
                 e_ = {"what": what, "exchange": r_["exchange"], "value": n_total * args.steps / dt_, "ms_per_step": dt_ / args.steps * 1e3,
                       "parts_ms_slowest_rank": {k_: comm.max_float(float(v_)) for k_, v_ in sorted(r_["parts"].items())},
                       "exchange_ms_slowest_rank": comm.max_float(float(r_["exchange_ms"] or 0.0)), "table_updates_rank0": r_["updates"]}
-                del r_
-                torch.cuda.empty_cache()
+                del r_                                  # (its blocks stay with torch: the next series asks for the same sizes)
                 return e_
             for key, overlap, exch, what in (
                     ("overlapped", True, "dense", "the dense series with the exchange of step k under the scan of step k+1 (two table buffers)"),
