@@ -187,6 +187,7 @@ struct BlockCache {
         *got = b.bytes;
         return b.p;
     }
+    bool tracked(const void *p) { std::lock_guard<std::mutex> g(mu); for (const B &b : out) if (b.p == p) return true; return false; }
     void note(int dev, void *p, size_t bytes) { if (bytes >= MIN) { std::lock_guard<std::mutex> g(mu); out.push_back(B{p, bytes, dev}); } }
     // true: the cache keeps p; false: the caller frees it
     bool give(void *p)
@@ -225,6 +226,9 @@ extern "C" size_t lime_trim_cache(void) { return g_blocks.trim(-1); }
 static void dev_release(void *p)
 {
     if (!p) return;
+    // (hipFree waits for the device before a block goes back; a block that goes to the cache instead can be handed out again at once, so it waits the
+    // same way: on the success paths everything that used the block has been waited for anyway, on an error path work on it may still be queued)
+    if (g_blocks.tracked(p)) (void)hipDeviceSynchronize();
     if (!g_blocks.give(p)) (void)hipFree(p);
 }
 static hipError_t dev_acquire(void **p, size_t bytes)

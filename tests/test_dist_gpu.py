@@ -165,6 +165,7 @@ def test_rccl_calls_through_the_c_abi_on_one_rank():
         dev = torch.device("cuda", 0)
         comm = ldist.Comm(0, 1, dev)
         comm.check_uint8_sum_wraps()
+        assert comm.count() == 1                                     # ncclCommCount through the C ABI
         assert comm.combine_counters(123, 45) == (123, 45)
         src = torch.arange(4096, dtype=torch.int32, device=dev).to(torch.uint8)
         out = torch.zeros(4096, dtype=torch.uint8, device=dev)

@@ -92,6 +92,7 @@ torch.cuda.set_device(local); dev = torch.device("cuda", local)
 dist.init_process_group("nccl", device_id=dev)
 comm = ldist.Comm(rank, world, dev)                              # RCCL through the C ABI, one rank per GPU
 comm.check_uint8_sum_wraps()
+assert comm.count() == world                                         # ncclCommCount: RCCL sees every rank
 n, nr, ng = 3_000_001, 9000, 130
 lcp, da, eb = O.synth(41, 0, n, nr, ng, 16, 1)
 for k in range(1, world):
