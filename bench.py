@@ -511,7 +511,9 @@ def main():
                     pass_traffic = t.get("pass_hbm_bytes")
             except Exception:
                 traffic = None
-        kname = f"lime::k_scan<{wl['ebwt']}, 0, {1 if r['binned'] else 0}>"
+        # which instance of the scan ran: <E, 0, 0> compare-and-swap; binned: <E, 0, 2> where the scorers write finished records (tables of one or two
+        # 4 GB sub-regions), <E, 0, 1> through the update queue (larger tables)
+        kname = f"lime::k_scan<{wl['ebwt']}, 0, {(2 if lime_amd.sim_bytes(wl['nr'], wl['ng']) <= (2 << 32) else 1) if r['binned'] else 0}>"
         out = {
             "metric": "eBWT symbols/s processed (ClusterLCP+ClusterBWT_DA)", "value": n_total * args.steps / dt, "unit": "symbols/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3,

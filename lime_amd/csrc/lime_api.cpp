@@ -117,6 +117,7 @@ struct lime_ctx {
     int choose_free = -1;                   // lime_fused_choose_dev: 1 = without the table wherever the layout has a second level, 0 = never
     bool no_staging = false, force_staging = false, force_rccl = false, debug_stats = false;
     uint64_t detect_chunk = 0, score_chunk = 0;             // symbols per chunk of lime_detect / lime_score* walks (0: by the sources)
+    bool no_direct = false;                 // binned updates through the update queue (k_scan<., 0, 1>) even for tables of one or two sub-regions (option no_direct: comparison runs, tests)
     uint32_t dense_min = 64;                // k_scan: windows with more accepted clusters list their 2-symbol clusters apart (option dense_min; tests: 0 = every window)
     int io_threads = 0;                     // host threads that stage pageable sources into the pinned ring (0: 8, at most the CPUs this process may use)
     // timing with HIP events on the launch stream: per pass {pass start, scan start, scan end, pass end}
@@ -279,6 +280,7 @@ static int set_option(lime_ctx *c, const char *key, const char *s)
     else if (is("debug_stats")) c->debug_stats = v != 0 || !*s;
     else if (is("debug_alloc")) g_debug_alloc.store(v != 0 || !*s, std::memory_order_relaxed);
     else if (is("poison_cache")) g_poison_cache.store(v != 0 || !*s, std::memory_order_relaxed);
+    else if (is("no_direct")) c->no_direct = v != 0 || !*s;
     else if (is("dense_min")) c->dense_min = *s ? (uint32_t)strtoul(s, nullptr, 0) : 64u;
     else if (is("io_threads")) c->io_threads = v >= 1 ? (v > 64 ? 64 : (int)v) : 0;
     else return fail(LIME_ERR_ARG, "lime_set_option: unknown option \"%s\"", key);
@@ -324,7 +326,7 @@ extern "C" int lime_init(int device, lime_ctx **out)
             {"LIME_PROBE_MIN", "probe_min"}, {"LIME_FORCE_P64", "force_p64"}, {"LIME_P64_TEST_BASE", "p64_test_base"}, {"LIME_MAX_BLOCKS", "max_blocks"},
             {"LIME_CHOOSE_FREE", "choose_free"}, {"LIME_APPLY_WIDE", "apply_wide"}, {"LIME_SORT_NT", "sort_nt"}, {"LIME_PART_LINES", "part_lines"},
             {"LIME_NO_STAGING", "no_staging"}, {"LIME_FORCE_STAGING", "force_staging"}, {"LIME_DETECT_CHUNK", "detect_chunk"}, {"LIME_SCORE_CHUNK", "score_chunk"},
-            {"LIME_FORCE_RCCL", "force_rccl"}, {"LIME_DENSE_MIN", "dense_min"}, {"LIME_DEBUG_STATS", "debug_stats"}, {"LIME_DEBUG_ALLOC", "debug_alloc"}};
+            {"LIME_FORCE_RCCL", "force_rccl"}, {"LIME_DENSE_MIN", "dense_min"}, {"LIME_NO_DIRECT", "no_direct"}, {"LIME_DEBUG_STATS", "debug_stats"}, {"LIME_DEBUG_ALLOC", "debug_alloc"}};
         for (const auto &hk : hooks)
             if (const char *s = getenv(hk[0])) {
                 const int rc = set_option(c, hk[1], s);
@@ -445,6 +447,7 @@ static ScanArgs base_args(lime_ctx *c, const uint32_t *lcp, const uint32_t *da, 
     a.static_pct = c->scan_static_pct >= 0 ? (uint32_t)c->scan_static_pct : (n_avail >= 500000000ull ? 0u : 75u);
     a.ablate = c->ablate;
     a.dense_min = c->dense_min;
+    a.no_direct = c->no_direct ? 1u : 0u;
     return a;
 }
 
@@ -555,6 +558,9 @@ static uint32_t part_prod_waves(const lime_ctx *c, int ebwt, uint32_t n_bins)
     }
     return best;
 }
+
+// which record-emitting scan serves a pass: 2 = the scorers write finished records (tables of one or two sub-regions), 1 = through the update queue
+static int bin_mode(const lime_ctx *c, uint32_t n_sub) { return (n_sub <= 2u && !c->no_direct) ? 2 : 1; }
 
 static double sizing_density(const lime_ctx *c)
 {
@@ -671,10 +677,10 @@ static int density_probe(lime_ctx *c, const uint32_t *d_lcp, const uint32_t *d_d
     const int ebwt = d_ebwt != nullptr;
     const uint32_t n_tiles = (uint32_t)((n_avail + WIN - 1) / WIN);
     const uint32_t ps = n_own < (1ull << 30) ? 6u : n_own < (1ull << 32) ? 7u : 8u;
-    const uint32_t grid = scan_grid(ebwt, 0, 1, n_tiles, c->max_blocks, ps);
     uint32_t n_bins = 0, bin_shift = REGION_SHIFT;
     bin_layout(c, sim_bytes, &n_bins, &bin_shift);
     const uint32_t n_sub = (uint32_t)((sim_bytes + 0xFFFFFFFFull) >> 32), wpw = scan_waves_per_wg(ebwt, 0);
+    const uint32_t grid = scan_grid(ebwt, 0, bin_mode(c, n_sub), n_tiles, c->max_blocks, ps);
     const uint32_t prod_waves = part_prod_waves(c, ebwt, n_bins), n_prod = grid * (wpw / prod_waves);
     g_alloc_ms = 0.0;
     rc = ensure_bin_counters(c, (size_t)grid * wpw * n_sub, (size_t)n_bins * n_prod, st);
@@ -743,9 +749,9 @@ static int fused_dev_impl(lime_ctx *c, const uint32_t *d_lcp, const uint32_t *d_
     bool p64 = false, fell_back = false;
     const double share = sub_share(sim_bytes);
     if (binned) {
-        grid = scan_grid(ebwt, 0, 1, n_tiles, c->max_blocks);
         bin_layout(c, sim_bytes, &n_bins, &bin_shift);
         n_sub = (uint32_t)((sim_bytes + 0xFFFFFFFFull) >> 32);
+        grid = scan_grid(ebwt, 0, bin_mode(c, n_sub), n_tiles, c->max_blocks);
         prod_waves = part_prod_waves(c, ebwt, n_bins);
         n_prod = grid * (scan_waves_per_wg(ebwt, 0) / prod_waves);
         g_alloc_ms = 0.0;

@@ -91,6 +91,7 @@ struct ScanArgs {
     uint32_t *tile_cnt; uint64_t *tile_off; CrossRec *cross; lime_cluster_t *out;   // detect only
     WinMasks *wmask;                             // detect only: count pass -> emit pass
     uint32_t *edge;                              // LIME_EDGE_* word of this shard (default: &stats->edge)
+    uint32_t no_direct;                          // binned updates: 1 = through the update queue (k_scan<., 0, 1>) even where the scorers could write the records themselves (option no_direct: comparison runs, tests)
     uint32_t dense_min;                          // k_scan: a window with more accepted clusters than this lists its 2-symbol clusters apart (64)
     uint32_t probe_shift;                        // density probe (lime_api.cpp): only every 2^probe_shift-th chunk of a workgroup's wave count of windows is scanned; 0 = a pass
     uint32_t *dyn; uint32_t n_static, static_pct;           // k_scan: rounds of round-robin window chunks before the chunks come from the counter dyn[0] (dyn[1]: workgroups done; both are left at 0); set by the launch wrapper from static_pct

@@ -260,10 +260,24 @@ struct UpdQueue { uint32_t *qr, *qg; uint32_t n, cap;
     // them per table bin in the workgroup's LDS histogram; no table access from the scan at all
     bool binned = false; uint32_t *out = nullptr; lds_vu32 *sub_n = nullptr; uint32_t *hist = nullptr;   // out: the wave's n_sub sub-regions; sub_n: records in each (LDS)
     uint32_t *lbuf = nullptr; lds_vu32 *lfill = nullptr;   // one or two sub-regions: finished records wait here (LBUF per sub-region, lfill[s] of them) until they fill 64-byte lines
+    // direct mode (round 6; k_scan<.,0,2>: tables of one or two sub-regions): the scorers write FINISHED 4-byte records -- qr[] holds sub-region 0's, qg[]
+    // sub-region 1's, n / n1 of them -- and a flush stores their whole 64-byte lines; no queue entry is looked at twice
+    bool direct = false;
+    uint32_t n1 = 0, base0 = 0, base1 = 0;                 // records waiting in qg[]; records stored so far per sub-region (wave-uniform)
+    uint32_t sub_rb = 0xFFFFFFFFu, sub_gb = 0;             // where sub-region 1 begins (read, genome); sub_rb = ~0: one sub-region
+    __device__ __forceinline__ bool two() const { return sub_rb != 0xFFFFFFFFu; }
+    uint32_t bad = 0;                                      // per lane: a genome index beyond the table was met (LIME_FLAG_DOCID at the next flush)
 #ifdef LIME_PHASE_TIMING
     uint64_t t_drain = 0; uint32_t n_drain = 0;
 #endif
 };
+
+// The wave's region of the record pool (n_sub sub-regions of cap_w records), recomputed where it is needed from the kernel's arguments and the wave's number
+__device__ __forceinline__ uint32_t *pool_of(const ScanArgs &ca, uint32_t n_sub, uint32_t cap_w)
+{
+    const uint32_t wave_gid = blockIdx.x * (blockDim.x >> 6) + (uint32_t)__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    return ca.pool + (size_t)wave_gid * n_sub * cap_w;
+}
 
 // Split-phase drain: (1) settle the slots issued last time: a CAS that found the expected word is
 // done, one that lost keeps its slot with the word it saw, a slot that only loaded its word now knows
@@ -384,6 +398,65 @@ __device__ __forceinline__ void drain_lines(UpdQueue &q, const ScanArgs &a, bool
     if (lane == 0) { q.lfill[0] = f0; q.lfill[1] = f1; }
 }
 
+// Direct mode (round 6).  Ablation cuts showed what the queue -> record -> line-buffer copy of drain_lines costs beyond its stores: 223 of 1586 us on
+// configs[2], 2.3 of 14.7 ms at N = 1e10, 61 of 251 us on the text workload (profiles/r06_scan_cuts.txt: the scan without ANY drain work runs at the
+// memory floor, 1234 us) -- two LDS reads per entry, a quarter-rate multiply, two ballots and ranks, an LDS write, then the line buffer's read-back, and
+// all of it in front of the next window's loads.  Here the scorers compute the record themselves (one multiply-add where they used to write two words)
+// and write it where its 64-byte line is being gathered; what is left for the flush is: read 64 records, count them in the bin histogram, store.
+__device__ __forceinline__ void flush_direct(UpdQueue &q, const ScanArgs &a, bool final)
+{
+    const uint32_t lane = lane_id();
+    const ScanArgs &ca = cold(a);
+    const uint32_t cap_w = ca.cap_w, bin_shift = ca.bin_shift, n_sub = ca.n_sub, bin_lim = ca.n_bins;
+    const uint32_t hoff = ((uint32_t)__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)) / ca.prod_waves) * bin_lim;     // the producer group's part of the workgroup's histogram
+    if (__ballot(q.bad != 0u)) { if (q.bad) atomicOr(&cold(a).stats->flags, LIME_FLAG_DOCID); q.bad = 0u; }
+    uint32_t *const out = pool_of(ca, n_sub, cap_w);
+#pragma unroll
+    for (uint32_t sub = 0; sub < 2u; ++sub) {
+        if (sub && !q.two()) break;
+        const uint32_t n = sub ? q.n1 : q.n, nl = final ? n : n & ~15u;
+        if (!nl) continue;                                           // wave-uniform
+        uint32_t *buf = sub ? q.qg : q.qr;
+        const uint32_t base = sub ? q.base1 : q.base0;
+        for (uint32_t k0 = 0; k0 < nl; k0 += 64u) {
+            const uint32_t k = k0 + lane;
+            const bool on = k < nl;
+            const uint32_t rec = buf[on ? k : 0u], slot = base + k;
+            uint32_t bin = (rec >> bin_shift) | (sub << (32u - bin_shift));
+            bin = bin < bin_lim ? bin : bin_lim - 1u;                // (only a pass that fails with LIME_ERR_DOCID can get here with a cell beyond the table)
+            if (on && slot < cap_w && !ABL(7)) {                     // a full sub-region only counts: the pass is repeated with a larger pool
+                atomicAdd(&q.hist[hoff + bin], 1u);                  // the histogram counts exactly the records that are stored
+                if (!ABL(6)) __builtin_nontemporal_store(rec, out + (size_t)sub * cap_w + slot);
+            }
+        }
+        const uint32_t rem = n - nl;                                 // < 16 <= nl: the two ranges below do not overlap
+        const uint32_t mv = buf[lane < rem ? nl + lane : 0u];
+        if (lane < rem) buf[lane] = mv;
+        if (sub) { q.base1 = base + nl; q.n1 = rem; } else { q.base0 = base + nl; q.n = rem; }
+    }
+}
+
+// direct mode: the lanes with `hit` append the record of (read rd, genome index gd), t = 1.  All 64 lanes call.
+__device__ __forceinline__ void put_rec(UpdQueue &q, const ScanArgs &a, bool hit, uint32_t rd, uint32_t gd)
+{
+    const uint32_t rec = rd * a.n_refs + gd;                         // the cell's low 32 bits
+    q.bad |= (uint32_t)(hit && gd >= a.n_refs);
+    if (!q.two()) {
+        const uint64_t m = __ballot(hit);
+        const uint32_t tot = (uint32_t)__popcll(m);
+        while (q.n + tot > q.cap) flush_direct(q, a, false);
+        if (hit) q.qr[q.n + rank_in(m)] = rec;
+        q.n += tot;
+    } else {
+        const bool hi = rd > q.sub_rb || (rd == q.sub_rb && gd >= q.sub_gb);      // cell >= 2^32
+        const uint64_t m1 = __ballot(hit && hi), m0 = __ballot(hit && !hi);
+        const uint32_t t0 = (uint32_t)__popcll(m0), t1 = (uint32_t)__popcll(m1);
+        while (q.n + t0 > q.cap || q.n1 + t1 > q.cap) flush_direct(q, a, false);
+        if (hit) { if (hi) q.qg[q.n1 + rank_in(m1)] = rec; else q.qr[q.n + rank_in(m0)] = rec; }
+        q.n += t0; q.n1 += t1;
+    }
+}
+
 // Binned mode: the queue's entries become 4-byte pool records in the wave's own region: the LOW 32 bits of the cell; the
 // high part picks one of the wave's n_sub sub-regions and the score is implicit (a pair that scores t > 1 -- repeated
 // documents only -- leaves t records).  Every byte the scan stores costs its read stream dearly -- a gigabyte of appended
@@ -429,6 +502,8 @@ __device__ __forceinline__ void drain_bin(UpdQueue &q, const ScanArgs &a)
 }
 __device__ __forceinline__ void drain(UpdQueue &q, const ScanArgs &a)
 {
+    if (ABL(13)) { q.n = 0; q.n1 = 0; return; }            // (timing experiments: what ALL of the drains' work costs -- the entries are thrown away)
+    if (q.direct) { flush_direct(q, a, false); return; }
     if (q.async) { if (q.binned) drain_bin(q, a); else drain_async(q, a); return; }     // both flags are compile-time constants of the kernel
 #ifdef LIME_PHASE_TIMING
     const uint64_t t0 = __builtin_readcyclecounter();
@@ -474,11 +549,16 @@ __device__ __forceinline__ void drain(UpdQueue &q, const ScanArgs &a)
 // every active lane may add one update; all 64 lanes must call (wave ballots inside)
 __device__ __forceinline__ uint32_t emit(UpdQueue &q, const ScanArgs &a, bool on, uint32_t rdoc, uint32_t gdoc, uint32_t t)
 {
-    while (q.n + 64u > q.cap) drain(q, a);
+    if (!q.direct) while (q.n + 64u > q.cap) drain(q, a);
     const uint32_t g = gdoc - a.n_reads;
     const bool bad = on && (g >= a.n_refs || rdoc >= a.n_reads);
     if (__ballot(bad)) { if (bad) atomicOr(&cold(a).stats->flags, LIME_FLAG_DOCID); }
     on = on && !bad;
+    if (q.direct) {                                        // a score of t = t records (t > 1: repeated documents only)
+        uint32_t left = on ? t : 0u;
+        while (__ballot(left != 0u)) { put_rec(q, a, left != 0u, rdoc, g); left -= (uint32_t)(left != 0u); }
+        return on ? 1u : 0u;
+    }
     const uint64_t m = __ballot(on);
     if (on) {
         const uint32_t slot = q.n + (uint32_t)__popcll(m & ((1ull << lane_id()) - 1ull));
@@ -724,6 +804,7 @@ __device__ __forceinline__ uint32_t score_len2(LDS &L, const WgTables &T, UpdQue
     bool hit = on;
     if (EBWT) hit = hit && ((T.compatb[L.fl[p]] >> T.symidx[L.fl[p + 1u]]) & 1u);
     const uint32_t rd = r0 ? d0 : d1, gd = (r0 ? d1 : d0) - a.n_reads;
+    if (qu.direct) { put_rec(qu, a, hit, rd, gd); return hit ? 1u : 0u; }
     const uint64_t m = EBWT ? __ballot(hit) : __ballot(on);
     const uint32_t tot = (uint32_t)__popcll(m);
     while (qu.n + tot > qu.cap) drain(qu, a);
@@ -782,6 +863,17 @@ __device__ __forceinline__ uint32_t score_small3(LDS &L, const WgTables &T, UpdQ
     }
     if (dup || !on) hits = 0u;
     const uint32_t nh = (uint32_t)__popc(hits);
+    if (qu.direct && qu.two()) {
+        // two sub-regions: a lane's records may go either way -- slot by slot through put_rec (two ballots and ranks each)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const bool he = (hits >> e) & 1u;
+            if (e >= 2 && !__ballot(he)) continue;                            // wave-uniform
+            const uint32_t rp = (pl >> (7 * e)) & 3u, gp = (pl >> (7 * e + 2)) & 3u;
+            put_rec(qu, a, he, L.da[p + rp], L.da[p + gp] - a.n_reads);
+        }
+        return nh + nflush;
+    }
     const uint32_t incl_all = wave_incl_scan(nh), total_all = rl32(incl_all, 63);
     // a batch adds at most 4 entries per lane = 256; where the queue is shorter than that (the 16-wave EBWT=1 kernel) a batch
     // that cannot fit even an emptied queue goes in two halves, slots 0..1 then 2..3 of the pair lists (at most 128 each)
@@ -800,8 +892,14 @@ __device__ __forceinline__ uint32_t score_small3(LDS &L, const WgTables &T, UpdQ
             if (he) {
                 const uint32_t rp = (pl >> (7 * e)) & 3u, gp = (pl >> (7 * e + 2)) & 3u;
                 const uint32_t slot = (EBWT || halves != 1u) ? slot0 + (uint32_t)__popc(hp & ((1u << e) - 1u)) : slot0 + (uint32_t)e;
+                if (qu.direct) {                                              // (one sub-region: the finished record)
+                    const uint32_t gd = L.da[p + gp] - a.n_reads;
+                    qu.bad |= (uint32_t)(gd >= a.n_refs);
+                    qu.qr[slot] = L.da[p + rp] * a.n_refs + gd;
+                } else {
                 qu.qr[slot] = L.da[p + rp];
                 qu.qg[slot] = (L.da[p + gp] - a.n_reads) | (1u << T_SHIFT);
+                }
             }
         }
         qu.n += total;
@@ -851,6 +949,7 @@ __device__ __forceinline__ uint32_t score_rows3(LDS &L, const WgTables &T, UpdQu
             const uint32_t dj = L.da[p + k];
             bool hit = act;
             if (EBWT) hit = act && ((ci >> T.symidx[L.fl[p + k]]) & 1u);
+            if (qu.direct) { put_rec(qu, a, hit, ri ? di : dj, (ri ? dj : di) - a.n_reads); nupd += (uint32_t)hit; continue; }
             const uint64_t m = __ballot(hit);
             while (qu.n + 64u > qu.cap) drain(qu, a);
             if (hit) {
@@ -1035,6 +1134,7 @@ __global__ __launch_bounds__((ScanCfg<EBWT, BIN>::wg)) __attribute__((amdgpu_wav
 {
     constexpr int SCANK_WG = ScanCfg<EBWT, BIN>::wg;
     static_assert(BIN == 0 || MODE == 0, "records are made by the scoring scan only");
+    static_assert(BIN >= 0 && BIN <= 2, "0: compare-and-swap; 1: records through the update queue (any number of sub-regions); 2: records written by the scorers (one or two sub-regions)");
     typedef ScanLdsT<EBWT, BIN> ScanLds;
     __shared__ ScanLds lds[SCANK_WG / 64];
     __shared__ WgTables T;
@@ -1063,6 +1163,10 @@ __global__ __launch_bounds__((ScanCfg<EBWT, BIN>::wg)) __attribute__((amdgpu_wav
     if (!binned) { qu.nj = NJ; qu.fr = fslots + 192u * NJ * wave; qu.fg = qu.fr + 64u * NJ; qu.fe = qu.fr + 128u * NJ; }
     const uint32_t wave_gid = blockIdx.x * (SCANK_WG / 64) + wave;
     qu.binned = binned;
+    qu.direct = BIN == 2;
+    if (BIN == 2) {
+        qu.sub_rb = cold(a).sub_rb; qu.sub_gb = cold(a).sub_gb;             // (sub_rb = ~0 for one sub-region: fused_dev_impl)
+    }
     if (binned) {
         // the workgroup's waves count their records in groups of prod_waves: every group is one "producer" of k_part (more, smaller
         // producers = more partition workgroups per CU); the groups' histograms lie one after the other
@@ -1076,7 +1180,7 @@ __global__ __launch_bounds__((ScanCfg<EBWT, BIN>::wg)) __attribute__((amdgpu_wav
     auto finish_binned = [&]() {
         const uint32_t n_sub = cold(a).n_sub, cap_w = cold(a).cap_w;
         if (lane < n_sub) {
-            const uint32_t n = qu.sub_n[lane];
+            const uint32_t n = BIN == 2 ? (lane ? qu.base1 : qu.base0) : qu.sub_n[lane];
             cold(a).wave_cnt[(size_t)(blockIdx.x * (SCANK_WG / 64) + wave) * n_sub + lane] = n < cap_w ? n : cap_w;
             atomicMax(&wg_rec_max, n);
             if (n > cap_w) {                                 // the pass's first overflow also counts the pass as unsettled
@@ -1236,6 +1340,8 @@ __global__ __launch_bounds__((ScanCfg<EBWT, BIN>::wg)) __attribute__((amdgpu_wav
         // its acknowledgement when it wants to stage the loaded window (measured on configs[2]: 0.34 of 2.06 ms with the
         // stores issued from the scoring rounds).  Issued here they are older than the loads and long done by then.
         if (MODE == 0 && !ABL(8)) {
+            if (ABL(13)) { qu.n = 0; qu.n1 = 0; } else
+            if (BIN == 2) flush_direct(qu, a, false); else
             if (binned) drain_bin(qu, a); else drain(qu, a);
             asm volatile("" ::: "memory");                    // the loads below stay below
         }
@@ -1442,8 +1548,11 @@ __global__ __launch_bounds__((ScanCfg<EBWT, BIN>::wg)) __attribute__((amdgpu_wav
     }
     if (MODE == 0) {
         if (n_dup) acc_upd += dup_flush<EBWT>(L, n_dup, a, T, qu);
+        if (BIN == 2) flush_direct(qu, a, true);                               // the last, partial lines too
+        else {
         do drain(qu, a); while (qu.n != 0u || __ballot(qu.f_pend != 0u));      // until every update has landed
         if (binned && cold(a).n_sub <= 2u) drain_lines(qu, a, true);           // the records still waiting for their line
+        }
         if (binned) finish_binned();
     }
 #ifdef LIME_PHASE_TIMING
@@ -3349,7 +3458,7 @@ void launch_preload()
     static std::atomic<bool> done[MAX_DEV];
     std::atomic<bool> &d = done[cur_device()];
     if (d.load(std::memory_order_relaxed)) return;
-    for (int e = 0; e < 2; ++e) for (int b = 0; b < 2; ++b) (void)scan_grid(e, 0, b, 1u << 20, 0, 0);
+    for (int e = 0; e < 2; ++e) for (int b = 0; b < 3; ++b) (void)scan_grid(e, 0, b, 1u << 20, 0, 0);
     (void)scan_grid(0, 1, 0, 1u << 20, 0, 0);
     (void)apply_tiles_grid(1u << 20);
     hipFuncAttributes fa;
@@ -3366,6 +3475,7 @@ void launch_preload()
 uint32_t scan_grid(int ebwt, int mode, int binned, uint32_t n_tiles, uint32_t max_blocks, uint32_t probe_shift)
 {
     if (mode != 0) return scan_grid_of<2, ScanCfg<0, 0>::wg>(k_scan<0, 1, 0>, n_tiles, max_blocks);
+    if (binned == 2) return ebwt ? scan_grid_of<6, ScanCfg<1, 2>::wg>(k_scan<1, 0, 2>, n_tiles, max_blocks, probe_shift) : scan_grid_of<5, ScanCfg<0, 2>::wg>(k_scan<0, 0, 2>, n_tiles, max_blocks, probe_shift);
     if (binned) return ebwt ? scan_grid_of<4, ScanCfg<1, 1>::wg>(k_scan<1, 0, 1>, n_tiles, max_blocks, probe_shift) : scan_grid_of<3, ScanCfg<0, 1>::wg>(k_scan<0, 0, 1>, n_tiles, max_blocks, probe_shift);
     return ebwt ? scan_grid_of<1, ScanCfg<1, 0>::wg>(k_scan<1, 0, 0>, n_tiles, max_blocks) : scan_grid_of<0, ScanCfg<0, 0>::wg>(k_scan<0, 0, 0>, n_tiles, max_blocks);
 }
@@ -3544,7 +3654,10 @@ void launch_apply_bigrecs(const uint64_t *recs, uint64_t n, uint64_t cell_lo, ui
 void launch_tile(int ebwt, int mode, const ScanArgs &a, uint32_t max_blocks, hipStream_t st)
 {
     if (mode != 0) launch_scan_kernel<2, ScanCfg<0, 0>::wg>(k_scan<0, 1, 0>, a, max_blocks, st);
-    else if (a.upd_mode) {
+    else if (a.upd_mode && a.n_sub <= 2u && !a.no_direct) {                 // the scorers write finished records (k_scan<., 0, 2>)
+        if (ebwt) launch_scan_kernel<6, ScanCfg<1, 2>::wg>(k_scan<1, 0, 2>, a, max_blocks, st);
+        else      launch_scan_kernel<5, ScanCfg<0, 2>::wg>(k_scan<0, 0, 2>, a, max_blocks, st);
+    } else if (a.upd_mode) {
         if (ebwt) launch_scan_kernel<4, ScanCfg<1, 1>::wg>(k_scan<1, 0, 1>, a, max_blocks, st);
         else      launch_scan_kernel<3, ScanCfg<0, 1>::wg>(k_scan<0, 0, 1>, a, max_blocks, st);
     } else {

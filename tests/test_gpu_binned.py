@@ -394,3 +394,46 @@ def test_one_bin_of_more_than_512_tiles(monkeypatch, wide):
         assert (gnc, gml) == (nc, ml) and np.array_equal(sim, exp), int((sim != exp).sum())
     finally:
         c.close()
+
+
+@pytest.mark.parametrize("no_direct", ["0", "1"])
+@pytest.mark.parametrize("levels", [None, "1,2", "4,7"])
+def test_records_written_by_the_scorers_or_through_the_queue(monkeypatch, golden, no_direct, levels):
+    """Round 6: for tables of one or two sub-regions the scan's scorers write finished 4-byte records where their 64-byte lines are gathered
+    (k_scan<., 0, 2>); option no_direct keeps the update queue and its drains (k_scan<., 0, 1>, which tables of three and more sub-regions always
+    take).  Both on every golden vector of the reference, both builds, three bin layouts; plus a table of two sub-regions (4.4 GB) whose rows
+    straddle the 2^32 border, against the ORACLE's table compared on the device."""
+    import torch
+    import lime_amd
+    monkeypatch.setenv("LIME_UPDATE_PATH", "bin")
+    if levels:
+        monkeypatch.setenv("LIME_BIN_LEVELS", levels)
+    c = lime_amd.Context()
+    try:
+        c.set_option("no_direct", no_direct)
+        g = golden
+        for ebwt_on, key in ((True, "sim_e1"), (False, "sim_e0")):
+            sim, nc, ml = c.fused(g["lcp"], g["da"], g["ebwt"] if ebwt_on else None, g["n_reads"], g["n_refs"], g["alpha"])
+            s, rc = c.stats()
+            assert rc == 0 and nc == len(g["clrs"]) and np.array_equal(sim, g[key]), (g["name"], no_direct, levels, ebwt_on)
+        if g["name"] != "edges" or levels:
+            return
+        n, nr, ng = 3_000_000, 1_100_000, 4000                      # 4.4 GB: two sub-regions; reads around 2^32 / 4000 = 1 073 741 straddle the border
+        lcp, da, eb = O.synth(99, 0, n, nr, ng, 16, 1)
+        lo_r = (1 << 32) // ng - 3
+        sel = da < nr
+        da[sel] = (lo_r + da[sel] % 7).astype(np.uint32)            # every read id in the seven rows around the border
+        cl, nc, ml = O.detect(lcp, da, nr, 16)
+        dev = torch.device("cuda", 0)
+        tl = torch.from_numpy(lcp.view(np.int32)).to(dev); td = torch.from_numpy(da.view(np.int32)).to(dev); te = torch.from_numpy(eb).to(dev)
+        sim = torch.empty(lime_amd.sim_bytes(nr, ng), dtype=torch.uint8, device=dev)
+        for e, et in ((eb, te), (None, None)):
+            rows = O.score(np.where(da < nr, da - lo_r, da - nr + 7).astype(np.uint32), e, cl, 7, ng, threads=8)     # the same clusters with the 7 reads renumbered 0..6
+            c.fused_dev(tl, td, et, n, n, True, nr, ng, 16, sim)
+            s, rc = c.stats()
+            assert rc == 0 and (s.n_clusters, s.max_len) == (nc, ml) and s.wave_records_max > 0
+            got = sim[lo_r * ng:(lo_r + 7) * ng].cpu().numpy().reshape(7, ng)
+            assert np.array_equal(got, rows), (no_direct, e is None, int((got != rows).sum()))
+            assert int(torch.count_nonzero(sim[:lo_r * ng])) == 0 and int(torch.count_nonzero(sim[(lo_r + 7) * ng:nr * ng])) == 0
+    finally:
+        c.close()

@@ -73,7 +73,9 @@ while time.time() < t_end:
     ctx = lime_amd.Context()
     dense_min = str(rng.choice([0, 3, 64, 64, 4294967295]))           # round 6: from how many clusters on a window lists its 2-symbol clusters apart
     ctx.set_option("dense_min", dense_min)
-    desc += f" dense_min={dense_min}"
+    no_direct = str(int(rng.random() < 0.3))                          # round 6: records through the update queue instead of written by the scorers
+    ctx.set_option("no_direct", no_direct)
+    desc += f" dense_min={dense_min} no_direct={no_direct}"
     try:
         gcl, gnc, gml = ctx.detect(lcp, da, nr, alpha)
         assert (gnc, gml) == (nc, ml) and np.array_equal(gcl, cl), "detect: " + desc
