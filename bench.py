@@ -563,7 +563,10 @@ def main():
     if not args.no_also:
         also = {}
         if world == 1:
-            for name in ("c2", "c2_clustered", "text_tiled", "text_spread", "n1e10", "c5_shape", "c4_shape", "c5_clustered", "n1e10_clustered"):
+            # (the workloads with the largest arrays and record pools first: what they allocate is reused by everything after them -- torch's cached blocks,
+            # the library's block cache -- so the process takes its memory from the driver once, early, while the pages it gets are the least likely to be
+            # recycled ones that the driver clears inside hipMalloc: DESIGN.md section 7, "allocations")
+            for name in ("c5_clustered", "n1e10_clustered", "c5_shape", "n1e10", "c4_shape", "c2", "c2_clustered", "text_tiled", "text_spread"):
                 if name == wname:
                     continue
                 w2 = WORKLOADS[name]
