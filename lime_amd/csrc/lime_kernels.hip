@@ -405,6 +405,8 @@ __device__ __forceinline__ void drain_lines(UpdQueue &q, const ScanArgs &a, bool
 // and write it where its 64-byte line is being gathered; what is left for the flush is: read 64 records, count them in the bin histogram, store.
 __device__ __forceinline__ void flush_direct(UpdQueue &q, const ScanArgs &a, bool final)
 {
+    if (ABL(13)) return;
+    if (ABL(14)) { q.n = 0; q.n1 = 0; return; }                      // (timing experiments: the scorers' share of the record work without the flush)
     const uint32_t lane = lane_id();
     const ScanArgs &ca = cold(a);
     const uint32_t cap_w = ca.cap_w, bin_shift = ca.bin_shift, n_sub = ca.n_sub, bin_lim = ca.n_bins;
@@ -439,6 +441,7 @@ __device__ __forceinline__ void flush_direct(UpdQueue &q, const ScanArgs &a, boo
 // direct mode: the lanes with `hit` append the record of (read rd, genome index gd), t = 1.  All 64 lanes call.
 __device__ __forceinline__ void put_rec(UpdQueue &q, const ScanArgs &a, bool hit, uint32_t rd, uint32_t gd)
 {
+    if (ABL(13)) return;
     const uint32_t rec = rd * a.n_refs + gd;                         // the cell's low 32 bits
     q.bad |= (uint32_t)(hit && gd >= a.n_refs);
     if (!q.two()) {
@@ -464,47 +467,79 @@ __device__ __forceinline__ void put_rec(UpdQueue &q, const ScanArgs &a, bool hit
 // records are as short as they can be.  Records beyond a sub-region's capacity are only counted (the host repeats the pass
 // with a larger pool: LIME_FLAG_POOL_FULL).  One or two sub-regions (tables up to 8 GB): drain_lines above; more: here,
 // 64 records at a time as they come.
-__device__ __forceinline__ void drain_bin(UpdQueue &q, const ScanArgs &a)
+// `whole`: every entry leaves (the window's top, the kernel's end); else -- a scorer needs room in the middle of a window -- only the LAST 64: a full
+// batch (the order of the records is free), instead of a full one and the few entries behind it every time.
+__device__ __forceinline__ void drain_bin(UpdQueue &q, const ScanArgs &a, bool final = false, bool whole = true)
 {
-    if (cold(a).n_sub <= 2u) { drain_lines(q, a, false); return; }         // (re-read: a flag held through the window loop is a pair of SGPRs)
+    if (cold(a).n_sub <= 2u) { drain_lines(q, a, final); return; }         // (re-read: a flag held through the window loop is a pair of SGPRs)
+    // Three and more sub-regions.  Until round 6 the records of such a table left "as they came": every 64 queue entries split three to eight ways by a
+    // loop over the sub-regions (a ballot, a rank, an LDS read and write of the sub-region's count each), so nearly every store was a part of a
+    // 64-byte line -- the stores alone were 2.65 of the 16.7 ms of the scan at configs[4]'s shape, and where records are dense the loop was a third of
+    // the scan (5.3 of 20.7 ms on the clustered generator; profiles/r06_scan_cuts.txt).  Now there is no loop: a lane takes its record's place in its
+    // sub-region with ONE LDS atomic on the sub-region's running count (sub_n[]: the hardware serialises the lanes of one address), and only whole
+    // lines leave: a record whose place lies in a line that this batch completes is stored from its register, the others wait in LDS (lbuf[16 s + i]:
+    // record i of sub-region s's open line), and the records that waited in a line completed now are stored by the lanes 16 s + i that read them
+    // back at the top (two store instructions into one line, back to back: they meet in L2).  The order of a sub-region's records is whatever the
+    // LDS made it -- the table is a sum.
     const uint32_t lane = lane_id();
     const ScanArgs &ca = cold(a);
     const uint32_t n = q.n, n_sub = ca.n_sub, cap_w = ca.cap_w, n_refs = ca.n_refs, bin_shift = ca.bin_shift;
     const uint32_t hoff = (uint32_t)__builtin_amdgcn_readfirstlane((int)q.sub_n[MAX_SUB]);
-    for (uint32_t k0 = 0; k0 < n; k0 += 64u) {
+    uint32_t *const out = pool_of(ca, n_sub, cap_w);
+    const uint32_t ws = lane >> 4, wi = lane & 15u;               // this lane's part in storing waiting records: record wi of sub-region ws (and ws + 4)
+    // the waiting records of sub-regions ws / ws + 4 whose line the batch completed (counts c0 before, c1 after) leave
+    auto store_waiting = [&](uint32_t sub, uint32_t c0, uint32_t c1, uint32_t wrec) {
+        const uint32_t l0 = c0 & ~15u;
+        if (sub < n_sub && (c1 & ~15u) != l0 && wi < (c0 & 15u) && l0 + wi < cap_w && !ABL(7)) {     // a full sub-region only counts: the pass is repeated with a larger pool
+            atomicAdd(&q.hist[hoff + ((wrec >> bin_shift) | (sub << (32u - bin_shift)))], 1u);      // the histogram counts exactly the records that are stored
+            if (!ABL(6)) __builtin_nontemporal_store(wrec, out + (size_t)sub * cap_w + l0 + wi);
+        }
+    };
+    const uint32_t first = whole || n <= 64u ? 0u : n - 64u;      // entries [first, n) leave
+    for (uint32_t k0 = first; k0 < n; k0 += 64u) {
         const uint32_t k = k0 + lane;
         const bool on = k < n;
         const uint32_t gt = q.qg[on ? k : 0u], rd = q.qr[on ? k : 0u];
         // the scan's fast emitters do not look at the document ids: a genome id beyond the table is caught here, on
         // full waves (the entry is dropped; the pass fails with LIME_ERR_DOCID)
-        const bool bad = on && (gt & (MAX_REFS - 1u)) >= n_refs;
-        if (__ballot(bad)) { if (bad) atomicOr(&cold(a).stats->flags, LIME_FLAG_DOCID); }
         const uint64_t cell = (uint64_t)rd * n_refs + (gt & (MAX_REFS - 1u));
-        const uint32_t hi = (uint32_t)(cell >> 32);
+        const uint32_t hi = (uint32_t)(cell >> 32), rec = (uint32_t)cell;
+        const bool bad = on && ((gt & (MAX_REFS - 1u)) >= n_refs || hi >= n_sub);
+        if (__ballot(bad)) { if (bad) atomicOr(&cold(a).stats->flags, LIME_FLAG_DOCID); }
         uint32_t left = (on && !bad) ? gt >> T_SHIFT : 0u;
         while (__ballot(left != 0u)) {                            // once, unless a pair scored more than 1
-            for (uint32_t sub = 0; sub < n_sub; ++sub) {          // wave-uniform
-                const bool mine = left != 0u && hi == sub;
-                const uint64_t m = __ballot(mine);
-                if (!m) continue;
-                const uint32_t base = q.sub_n[sub];               // LDS, one address: a broadcast read
-                const uint32_t slot = base + rank_in(m);
-                if (mine && slot < cap_w && !ABL(7)) {            // a full sub-region only counts (sub_n): the pass is repeated with a larger pool
-                    atomicAdd(&q.hist[hoff + (uint32_t)(cell >> bin_shift)], 1u);     // the histogram counts exactly the records that are stored
-                    if (!ABL(6)) __builtin_nontemporal_store((uint32_t)cell, q.out + (size_t)sub * cap_w + slot);
+            const bool act = left != 0u;
+            const uint32_t wv0 = q.lbuf[lane], c00 = q.sub_n[ws];
+            uint32_t wv1 = 0, c04 = 0;
+            if (n_sub > 4u) { wv1 = q.lbuf[64u + lane]; c04 = q.sub_n[4u + ws]; }                   // wave-uniform
+            uint32_t slot = 0;
+            if (act) slot = __hip_atomic_fetch_add(&q.sub_n[hi], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            const uint32_t c1h = q.sub_n[act ? hi : 0u], c10 = q.sub_n[ws];
+            const uint32_t lim = c1h & ~15u;                      // the whole lines of this lane's sub-region end here
+            if (act) {
+                if (slot >= lim) q.lbuf[16u * hi + (slot & 15u)] = rec;
+                else if (slot < cap_w && !ABL(7)) {
+                    atomicAdd(&q.hist[hoff + (uint32_t)(cell >> bin_shift)], 1u);
+                    if (!ABL(6)) __builtin_nontemporal_store(rec, out + (size_t)hi * cap_w + slot);
                 }
-                if (lane == 0) q.sub_n[sub] = base + (uint32_t)__popcll(m);
             }
-            left -= (uint32_t)(left != 0u);
+            store_waiting(ws, c00, c10, wv0);
+            if (n_sub > 4u) store_waiting(4u + ws, c04, q.sub_n[4u + ws], wv1);
+            left -= (uint32_t)act;
         }
     }
-    q.n = 0;
+    q.n = first;
+    if (final) {                                                  // the kernel's last drain: the open lines too (c1 = c0 + 16: "completed")
+        const uint32_t c00 = q.sub_n[ws], wv0 = q.lbuf[lane];
+        store_waiting(ws, c00, c00 + 16u, wv0);
+        if (n_sub > 4u) { const uint32_t c04 = q.sub_n[4u + ws], wv1 = q.lbuf[64u + lane]; store_waiting(4u + ws, c04, c04 + 16u, wv1); }
+    }
 }
 __device__ __forceinline__ void drain(UpdQueue &q, const ScanArgs &a)
 {
     if (ABL(13)) { q.n = 0; q.n1 = 0; return; }            // (timing experiments: what ALL of the drains' work costs -- the entries are thrown away)
     if (q.direct) { flush_direct(q, a, false); return; }
-    if (q.async) { if (q.binned) drain_bin(q, a); else drain_async(q, a); return; }     // both flags are compile-time constants of the kernel
+    if (q.async) { if (q.binned) drain_bin(q, a, false, false); else drain_async(q, a); return; }     // both flags are compile-time constants of the kernel
 #ifdef LIME_PHASE_TIMING
     const uint64_t t0 = __builtin_readcyclecounter();
 #endif
@@ -1551,7 +1586,7 @@ __global__ __launch_bounds__((ScanCfg<EBWT, BIN>::wg)) __attribute__((amdgpu_wav
         if (BIN == 2) flush_direct(qu, a, true);                               // the last, partial lines too
         else {
         do drain(qu, a); while (qu.n != 0u || __ballot(qu.f_pend != 0u));      // until every update has landed
-        if (binned && cold(a).n_sub <= 2u) drain_lines(qu, a, true);           // the records still waiting for their line
+        if (binned) drain_bin(qu, a, true);                                    // the records still waiting for their line
         }
         if (binned) finish_binned();
     }
@@ -3145,7 +3180,7 @@ __global__ __launch_bounds__(SCAN_WG) void k_score_list(ScanArgs a, const lime_c
     }
     if (BIN) {                                                        // the records still waiting for their line; this wave's counts; the workgroup's histogram
         const uint32_t n_sub = cold(a).n_sub, cap_w = cold(a).cap_w;
-        if (n_sub <= 2u) drain_lines(qu, a, true);
+        drain_bin(qu, a, true);
         if (lane < n_sub) {
             const uint32_t n = qu.sub_n[lane];
             cold(a).wave_cnt[(size_t)(blockIdx.x * (SCAN_WG / 64) + wave) * n_sub + lane] = n < cap_w ? n : cap_w;

@@ -177,6 +177,32 @@ def test_exec_lint_catches_a_shuffle_under_a_condition(tmp_path):
     assert flagged and all("k_apply_tiles<1," in ln and "ds_bpermute_b32" in ln for ln in flagged), out[-2000:]
 
 
+def test_exec_lint_follows_saved_copies_and_renamed_else_masks():
+    """tools/exec_lint.py's model of EXEC on the two instruction patterns round 6 taught it (before, the first one left a restriction on the stack
+    for the rest of the kernel -- 769 "sites" in the scan kernels that ran with all lanes -- and the second one made new ones): a region run by a
+    precomputed lane set between `s_mov D, exec` and `s_or exec, exec, D`, and an if / else whose other half is kept in ANOTHER register than the
+    saved mask.  Inside the regions a cross-lane operation is reported, after them it is not."""
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    import exec_lint as L
+
+    def restricted_at(lines):
+        st, out = (), []
+        for ln in lines:
+            out.append(any(not x.startswith("~") for x in st))
+            st = L.step(st, ln)
+        return out, st
+    r, st = restricted_at(["s_mov_b64 s[18:19], exec", "s_mov_b64 exec, s[8:9]", "ds_bpermute_b32 v1, v2, v3", "s_or_b64 exec, exec, s[18:19]",
+                           "ds_bpermute_b32 v1, v2, v3"])
+    assert r == [False, False, True, True, False] and st == ()
+    r, st = restricted_at(["s_and_saveexec_b64 s[8:9], s[84:85]", "s_xor_b64 s[86:87], exec, s[8:9]", "ds_bpermute_b32 v1, v2, v3",
+                           "s_andn2_saveexec_b64 s[86:87], s[86:87]", "ds_bpermute_b32 v1, v2, v3", "s_or_b64 exec, exec, s[86:87]", "ds_bpermute_b32 v1, v2, v3"])
+    assert r == [False, True, True, True, True, True, False] and st == ()
+    # the usual shape (one register) and a copy taken INSIDE an open region stay what they were
+    r, st = restricted_at(["s_and_saveexec_b64 s[4:5], vcc", "s_mov_b64 s[6:7], exec", "s_mov_b64 exec, s[10:11]", "s_or_b64 exec, exec, s[6:7]",
+                           "v_mov_b32_dpp v1, v2 row_shr:1", "s_or_b64 exec, exec, s[4:5]", "v_mov_b32_dpp v1, v2 row_shr:1"])
+    assert r == [False, True, True, True, True, True, False] and st == ()
+
+
 def test_library_buffers_become_arrays_without_a_copy_and_are_freed_with_the_last_view():
     """lime_amd.api._LibBuf (the (idRef, sim) lists of clusterChoose come back as the library's own buffer): the array sees the buffer's words,
     is writable, and lime_free runs exactly once, when the last view dies"""

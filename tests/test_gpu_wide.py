@@ -66,15 +66,19 @@ def test_p64_with_a_pool_too_small(monkeypatch):
 
 @pytest.mark.parametrize("nr,ng,ebwt_on,mode", [
     (1_100_000, 4000, True, 1),        # 4.4 GB: two sub-regions (drain_lines), the second one a tenth of the first
-    (3_000_000, 3423, True, 1),        # configs[4]'s table, 10.3 GB: three sub-regions (drain_bin), shares 0.42 / 0.42 / 0.16
-    (2_200_000, 4000, False, 1),       # 8.8 GB, EBWT=0
+    (3_000_000, 3423, True, 1),        # configs[4]'s table, 10.3 GB: three sub-regions, shares 0.42 / 0.42 / 0.16
+    (2_200_000, 4000, False, 1),       # 8.8 GB, EBWT=0: three sub-regions
+    (4_700_000, 4000, True, 1),        # the size of configs[3]'s table, 18.8 GB: five sub-regions
 ])
-def test_tables_of_several_sub_regions_vs_oracle(monkeypatch, nr, ng, ebwt_on, mode):
+@pytest.mark.parametrize("no_direct", [0, 1])
+def test_tables_of_several_sub_regions_vs_oracle(monkeypatch, nr, ng, ebwt_on, mode, no_direct):
     """Tables beyond 4 GB: a scan wave writes its records to one sub-region per 4 GB of table, each sized for its SHARE of the wave's
     records (round 5; rounds 3-4: the wave's whole share each) -- clustered generator, 2*10^7 symbols, against the oracle's table (compared on
-    the device).  The density comes from the probe; no pass may be repeated and none may fall back."""
+    the device).  The density comes from the probe; no pass may be repeated and none may fall back.  Records written by the scorers into a
+    line buffer per sub-region (k_scan<., 0, 2> and <., 0, 3>, round 6) and, with option no_direct, through the update queue (drain_lines /
+    drain_bin of k_scan<., 0, 1> -- the path of tables beyond 24 / 32 GB)."""
     import torch
-    c = _ctx(monkeypatch, LIME_UPDATE_PATH="bin", LIME_PROBE_MIN=1 << 24)      # (the probe in front of first passes of 2^28 symbols and more by default)
+    c = _ctx(monkeypatch, LIME_UPDATE_PATH="bin", LIME_PROBE_MIN=1 << 24, LIME_NO_DIRECT=no_direct)      # (the probe in front of first passes of 2^28 symbols and more by default)
     try:
         n = 20_000_000
         lcp, da, eb = O.synth(4100 + ng, 0, n, nr, ng, 16, mode)
@@ -96,7 +100,7 @@ def test_tables_of_several_sub_regions_vs_oracle(monkeypatch, nr, ng, ebwt_on, m
         assert torch.equal(sim[:nr * ng], texp), int((sim[:nr * ng] != texp).sum())
         del texp
         # the same pass with the sub-regions far too small: overflow, repeat sized from the fullest SUB-REGION's count
-        c2 = _ctx(monkeypatch, LIME_UPDATE_PATH="bin", LIME_POOL_DENSITY="0.002", LIME_POOL_SLACK=0)
+        c2 = _ctx(monkeypatch, LIME_UPDATE_PATH="bin", LIME_POOL_DENSITY="0.002", LIME_POOL_SLACK=0, LIME_NO_DIRECT=no_direct)
         try:
             sim2 = torch.full_like(sim, 0xA5)
             c2.fused_dev(tl, td, te, n, n, True, nr, ng, 16, sim2, True)

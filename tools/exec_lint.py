@@ -17,6 +17,8 @@ How: per kernel, basic blocks from labels and branches; a forward data flow over
   s_and_b64 exec, exec, X      push "&"          (narrowed for good inside the enclosing region)
   s_or_b64 exec, exec, X       pop down to and including X   (SI_END_CF: the region's lanes are back)
   s_mov_b64 exec, -1           clear; s_mov_b64 exec, X: pop to X if X is open, else push
+  s_mov_b64 D, exec            push the marker ~D (no restriction): the `s_or_b64 exec, exec, D` that ends such a region pops down to it
+  s_xor_b64 S, exec, X         (S not exec) the open region X goes by the name S from here (its else-half opens with `s_andn2_saveexec_b64 D, S`)
   s_xor_b64 exec, ..           unchanged (the other half of an if / else: still partial)
 joins take the longer stack (a loop header inherits the back edge's restrictions).  A cross-lane operation in a block position whose stack is not
 empty is reported as (kernel, source file:line, mnemonic).  v_readlane / v_readfirstlane / v_writelane are NOT reported: they ignore EXEC and
@@ -124,17 +126,33 @@ def step(stack, insn):
     """EXEC restriction stack after one instruction"""
     if "exec" not in insn:
         return stack
-    m = re.match(r"s_\w+_saveexec_b64\s+(\S+?),", insn)
+    m = re.match(r"s_\w+_saveexec_b64\s+(\S+?),\s*(\S+)", insn)
     if m:
-        return stack if m.group(1) in stack else stack + (m.group(1),)      # (a loop's body re-entered: the same save, not a deeper one)
+        d, src = m.group(1), m.group(2)
+        if d in stack:
+            return stack                                                    # (a loop's body re-entered: the same save, not a deeper one)
+        if src in stack:                                                    # the switch to an else-half whose mask was renamed below: the same region
+            return tuple(d if x == src else x for x in stack)
+        return stack + (d,)
+    m = re.match(r"s_xor_b64\s+(\S+?),\s*exec,\s*(\S+)$", insn)
+    if m and m.group(1) != "exec":
+        # S = exec ^ X right after `s_and_saveexec X`: S holds the if's OTHER lanes; when S is another register than X, the else-half opens with
+        # `s_andn2_saveexec D, S` and the region closes with `s_or exec, exec, D` -- X is never mentioned again, so the open region goes by S from here
+        return tuple(m.group(1) if x == m.group(2) else x for x in stack)
+    m = re.match(r"s_mov_b64\s+(\S+?),\s*exec$", insn)
+    if m:
+        # a plain copy of EXEC (`s_mov D, exec; s_mov exec, X; ..; s_or exec, exec, D`: a region run by a precomputed lane set): no restriction by
+        # itself -- a marker "~D" that the closing s_or finds, so that what was pushed in between is popped with it
+        return stack if ("~" + m.group(1)) in stack else stack + ("~" + m.group(1),)
     m = re.match(r"(s_\w+_b64)\s+exec,\s*(\S+?)(?:,\s*(\S+))?$", insn)
     if not m:
         return stack
     op, a, b = m.group(1), m.group(2), m.group(3)
     other = b if a == "exec" else a
     if op == "s_or_b64":
-        if other in stack:
-            return stack[:len(stack) - 1 - stack[::-1].index(other)]
+        for key in (other, "~" + other):
+            if key in stack:
+                return stack[:len(stack) - 1 - stack[::-1].index(key)]
         return stack
     if op == "s_andn2_b64":
         return stack if other in stack else stack + (other,)
@@ -173,7 +191,7 @@ def lint_function(items):
         if st is None:
             continue            # unreachable in this model
         for insn, loc in b["insns"]:
-            if st and (CROSS.match(insn) or DPP_MOD.search(insn)):
+            if any(not x.startswith("~") for x in st) and (CROSS.match(insn) or DPP_MOD.search(insn)):
                 found.append((loc, insn.split()[0], len(st)))
             st = step(st, insn)
     return found
