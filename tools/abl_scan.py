@@ -23,7 +23,7 @@ for name in names:
     for k in cuts:
         os.environ["LIME_ABLATE"] = k
         r = bench.run_pass_series(torch, lime_amd, ldist, wl, wl["n"], 5 if wl["n"] >= 10_000_000_000 else 12, 2, 1, 0, dev, None, overlap=False,
-                                  options={"update_path": "bin", "no_probe": "1"})
+                                  options={"update_path": os.environ.get("ABL_PATH", "bin"), "no_probe": "1"})      # (ABL_PATH=cas: the compare-and-swap kernels)
         out.append((k, round(r["parts"]["scan"] * 1e3, 1)))
         del r
     print(name, " ".join(f"cut {k}: {us} us" for k, us in out), flush=True)
