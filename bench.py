@@ -68,6 +68,10 @@ WORKLOADS = {
 }
 
 
+# the secondary workloads of a default run, the largest arrays and record pools first (what they allocate is reused by everything after them)
+ALSO_ORDER = ("c5_clustered", "n1e10_clustered", "c5_shape", "n1e10", "c4_shape", "c2", "c2_clustered", "text_tiled", "text_spread")
+
+
 def describe(wl, n_total, world):
     return ((f"synthetic S (seed {SEED}, generator mode {wl['mode']})" if not wl.get("tiled") else "text-derived S") +
             f": {n_total} symbols, {wl['nr']} reads x {wl['ng']} genomes "
@@ -485,6 +489,25 @@ def main():
         n_total = int(args.n_total or wl["n"])
     else:
         n_total = int(args.n or wl["n"]) * world
+    # The library's large buffers (record pool, binned records, scratch) for everything this run will do are taken from the driver ONCE, here
+    # (lime_reserve): a hipMalloc that is served from pages some process has freed waits while the driver clears them -- 30 ms per GB, 0.4 .. 5 s for
+    # the pools of a 10^10-symbol pass, and whether a box has such pages is its history, not this program's ("allocations").
+    # Rounds 1-5 paid that inside the first pass of a workload (and subtracted it); a process that knows what it will run pays it at start-up.
+    # What is reserved: 16 bytes per expected update record (margins included) + 0.3 bytes per symbol of the largest workload of the run.
+    def lib_need(w, n_sym):
+        return int(n_sym * ((0.25 if w["mode"] != 0 else 0.13) * 16 + 0.3)) + (2 << 30)
+    planned = [(wl, n_total // world)]
+    if world == 1 and not args.no_also:
+        planned += [(WORKLOADS[k_], WORKLOADS[k_]["n"]) for k_ in ALSO_ORDER if k_ != wname]
+    reserve_bytes = max(lib_need(w_, n_) for w_, n_ in planned)
+    if world == 1 and not args.no_also:
+        reserve_bytes = max(reserve_bytes, lib_need(WORKLOADS["c4_shape"], WORKLOADS["c4_shape"]["n"]) + WORKLOADS["c4_shape"]["nr"] * WORKLOADS["c4_shape"]["ng"])
+    t_res = time.perf_counter()
+    lime_amd.reserve(reserve_bytes)
+    torch.cuda.synchronize()
+    reserve_info = {"bytes": reserve_bytes, "ms": (time.perf_counter() - t_res) * 1e3,
+                    "what": "lime_reserve at start-up: one block for the library's record pools / binned records / scratch of every workload of the run; "
+                            "`cold` passes below carve from it (cold.alloc_ms is what they still spent in the allocator)"}
     r = run_pass_series(torch, lime_amd, ldist, wl, n_total, args.steps, args.warmup, world, rank, dev, comm, overlap=False, exchange=args.exchange,
                         options={"no_probe": "1"} if args.no_probe else None)
     dt, n_clusters, max_len = r["dt"], r["n_clusters"], r["max_len"]
@@ -547,26 +570,21 @@ def main():
     del r
 
     def make_room(w, extra=0):
-        # torch keeps the blocks of the workload before (and reuses them where they fit) and the library keeps its own (lime_trim_cache); they go back to
-        # the driver only when the next workload would not fit beside them.  Not for tidiness: on this platform memory that was freed is CLEARED by the
-        # driver inside the next hipMalloc that gets it, at about 30 GB/s (tools/alloc_bench.hip) -- freeing 90 GB of arrays in front
-        # of every workload, as rounds 1-5 did, made the library's first allocations of the next one take between 1 ms and 5 s (cold.alloc_ms).
-        # What must be FREE at the driver: the library's record pool + binned records + scratch (16 bytes per expected update record, margins included,
-        # + 0.3 bytes per symbol); torch releases its own cache by itself when one of ITS allocations does not fit
-        dens = 0.25 if (w["mode"] != 0) else 0.13
-        need = int(w["n"] * (dens * 16 + 0.3)) + extra + (2 << 30)
+        # torch keeps the blocks of the workload before (and reuses them where they fit); the library's blocks come out of the block reserved at start-up.
+        # Nothing goes back to the driver between workloads unless the next one would not fit: memory that is freed comes back uncleared, and the next
+        # hipMalloc that gets it waits for the driver to clear it (tools/alloc_bench.hip) -- freeing 90 GB of arrays in front of
+        # every workload, as rounds 1-5 did, made the library's first allocations of the next one take between 1 ms and 5 s (cold.alloc_ms).
+        # (round 6, later: the library's blocks come out of the block reserved at start-up; what must be free at the driver is only a margin for
+        # torch's own allocations of the next workload beside its cached blocks -- it releases its cache by itself when one of them does not fit)
         free_b, _tot = torch.cuda.mem_get_info()
-        if free_b < need:
+        if free_b < (4 << 30):
             torch.cuda.empty_cache()
-            lime_amd.trim_cache()
 
     if not args.no_also:
         also = {}
         if world == 1:
-            # (the workloads with the largest arrays and record pools first: what they allocate is reused by everything after them -- torch's cached blocks,
-            # the library's block cache -- so the process takes its memory from the driver once, early, while the pages it gets are the least likely to be
-            # recycled ones that the driver clears inside hipMalloc: DESIGN.md section 7, "allocations")
-            for name in ("c5_clustered", "n1e10_clustered", "c5_shape", "n1e10", "c4_shape", "c2", "c2_clustered", "text_tiled", "text_spread"):
+            # (the workloads with the largest arrays first: torch's cached blocks are reused by everything after them)
+            for name in ALSO_ORDER:
                 if name == wname:
                     continue
                 w2 = WORKLOADS[name]
@@ -613,6 +631,7 @@ def main():
         out["comm"] = comm_info
         out["roofline"]["exchange_ms_rank0"] = headline_ex_ms
     if rank == 0:
+        out["reserve"] = reserve_info
         print(json.dumps(out), flush=True)
     if world > 1:
         comm.close()

@@ -105,8 +105,15 @@ int  lime_set_option(lime_ctx *ctx, const char *key, const char *value);
 /* Device blocks of 64 MB and more that the contexts of this process have released (lime_shutdown, scratch that was replaced by a larger block)
  * stay with the library for the next context instead of going back to the driver: on this platform a hipMalloc that is served from recycled
  * pages waits while the driver clears them (about 30 GB/s: seconds for a record pool).  At most a quarter of the device's
- * memory is held; a failed allocation releases it.  lime_trim_cache gives everything back now; returns the bytes released. */
+ * memory is held; a failed allocation releases it.  lime_trim_cache gives everything back now; returns the bytes released.  (Which pages are
+ * "recycled" is not in this process's hands: pages that ANY process freed stay uncleared until the driver hands them out again -- see lime_reserve.) */
 size_t lime_trim_cache(void);
+/* Takes `bytes` of device memory (current device) from the driver NOW, in one block, for the large buffers of every context of this process: record
+ * pools, binned records and the other blocks of 64 MB and more are carved from it (first fit, 2 MB granules) before anything is asked of the driver,
+ * and go back to it when their context closes.  For a process that knows what it will need (a server; bench.py): where that hipMalloc meets
+ * recycled pages it takes its 30 ms per GB here, once, at start-up, and no pass pays for an allocation again.  May be called again (another
+ * block).  lime_trim_cache releases the reserved blocks nothing is carved from.  LIME_ERR_NOMEM if the driver refuses. */
+int lime_reserve(size_t bytes);
 
 /* ---- host-pointer API (pageable host arrays; the library stages them through HBM) ------ */
 

@@ -53,6 +53,7 @@ SYMBOLS = {
     "lime_pick_device": (_i, [C.c_uint]),
     "lime_set_option": (_i, [_vp, C.c_char_p, C.c_char_p]),
     "lime_trim_cache": (_sz, []),
+    "lime_reserve": (C.c_int, [_sz]),
     "lime_detect": (_i, [_vp, _vp, _vp, _u64, _u32, _u32, _pp, _pu64, _pu64]),
     "lime_detect_to_file": (_i, [_vp, _vp, _vp, _u64, _u32, _u32, C.c_char_p, _pu64, _pu64]),
     "lime_register_file": (_i, [_vp, _sz, _i]),

@@ -254,6 +254,13 @@ def trim_cache():
     return int(_lib.load().lime_trim_cache())
 
 
+def reserve(nbytes):
+    """take `nbytes` of device memory from the driver now, once, for the large buffers of every later context (lime_reserve); LimeError if refused"""
+    rc = _lib.load().lime_reserve(int(nbytes))
+    if rc != 0:
+        raise LimeError(rc, "lime_reserve")
+
+
 def sim_bytes(n_reads, n_refs):
     return int(_lib.load().lime_sim_bytes(n_reads, n_refs))
 

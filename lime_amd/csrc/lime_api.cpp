@@ -175,6 +175,58 @@ struct BlockCache {
     static constexpr size_t MIN = (size_t)64 << 20;
     std::mutex mu;
     std::vector<B> idle, out;                               // cached blocks; blocks handed out (their true sizes)
+    // lime_reserve: blocks taken from the driver ONCE (at process start, where the time shows as what it is), from which the large buffers of every
+    // context are carved afterwards: first fit over the free extents (offset-sorted, merged on return), 2 MB granules
+    struct Ext { size_t off, bytes; };
+    struct Arena { char *base; size_t bytes; int dev; std::vector<Ext> free_; size_t live; };
+    struct Carve { void *p; size_t arena, off, bytes; };
+    static constexpr size_t GRAN = (size_t)2 << 20;
+    std::vector<Arena> arenas;
+    std::vector<Carve> carved;
+    bool add_arena(int dev, void *base, size_t bytes)
+    {
+        std::lock_guard<std::mutex> g(mu);
+        arenas.push_back(Arena{static_cast<char *>(base), bytes, dev, {Ext{0, bytes}}, 0});
+        return true;
+    }
+    void *carve(int dev, size_t bytes, size_t *got)
+    {
+        const size_t want = (bytes + GRAN - 1) / GRAN * GRAN;
+        std::lock_guard<std::mutex> g(mu);
+        for (size_t ai = 0; ai < arenas.size(); ++ai) {
+            Arena &A = arenas[ai];
+            if (A.dev != dev) continue;
+            for (size_t i = 0; i < A.free_.size(); ++i)
+                if (A.free_[i].bytes >= want) {
+                    const size_t off = A.free_[i].off;
+                    if (A.free_[i].bytes == want) A.free_.erase(A.free_.begin() + (long)i);
+                    else { A.free_[i].off += want; A.free_[i].bytes -= want; }
+                    A.live += want;
+                    carved.push_back(Carve{A.base + off, ai, off, want});
+                    *got = want;
+                    return A.base + off;
+                }
+        }
+        return nullptr;
+    }
+    bool uncarve(void *p)                                   // true: p was a piece of an arena and is free again
+    {
+        std::lock_guard<std::mutex> g(mu);
+        for (size_t ci = 0; ci < carved.size(); ++ci)
+            if (carved[ci].p == p) {
+                const Carve c = carved[ci];
+                carved.erase(carved.begin() + (long)ci);
+                Arena &A = arenas[c.arena];
+                A.live -= c.bytes;
+                size_t i = 0;
+                while (i < A.free_.size() && A.free_[i].off < c.off) ++i;
+                A.free_.insert(A.free_.begin() + (long)i, Ext{c.off, c.bytes});
+                if (i + 1 < A.free_.size() && A.free_[i].off + A.free_[i].bytes == A.free_[i + 1].off) { A.free_[i].bytes += A.free_[i + 1].bytes; A.free_.erase(A.free_.begin() + (long)i + 1); }
+                if (i > 0 && A.free_[i - 1].off + A.free_[i - 1].bytes == A.free_[i].off) { A.free_[i - 1].bytes += A.free_[i].bytes; A.free_.erase(A.free_.begin() + (long)i); }
+                return true;
+            }
+        return false;
+    }
     void *take(int dev, size_t bytes, size_t *got)
     {
         std::lock_guard<std::mutex> g(mu);
@@ -188,7 +240,13 @@ struct BlockCache {
         *got = b.bytes;
         return b.p;
     }
-    bool tracked(const void *p) { std::lock_guard<std::mutex> g(mu); for (const B &b : out) if (b.p == p) return true; return false; }
+    bool tracked(const void *p)
+    {
+        std::lock_guard<std::mutex> g(mu);
+        for (const B &b : out) if (b.p == p) return true;
+        for (const Carve &c : carved) if (c.p == p) return true;
+        return false;
+    }
     void note(int dev, void *p, size_t bytes) { if (bytes >= MIN) { std::lock_guard<std::mutex> g(mu); out.push_back(B{p, bytes, dev}); } }
     // true: the cache keeps p; false: the caller frees it
     bool give(void *p)
@@ -213,6 +271,12 @@ struct BlockCache {
             std::lock_guard<std::mutex> g(mu);
             for (size_t i = 0; i < idle.size();) if (dev < 0 || idle[i].dev == dev) { drop.push_back(idle[i]); idle.erase(idle.begin() + (long)i); } else ++i;
         }
+        {
+            // (arenas nothing is carved from any more go too; the indices of the others stay what the carve records hold: emptied in place)
+            std::lock_guard<std::mutex> g(mu);
+            for (Arena &A : arenas)
+                if (A.base && A.live == 0 && (dev < 0 || A.dev == dev)) { drop.push_back(B{A.base, A.bytes, A.dev}); A.base = nullptr; A.bytes = 0; A.free_.clear(); }
+        }
         int cur = 0; (void)hipGetDevice(&cur);
         size_t bytes = 0;
         for (const B &b : drop) { (void)hipSetDevice(b.dev); (void)hipFree(b.p); bytes += b.bytes; }
@@ -223,6 +287,17 @@ struct BlockCache {
 BlockCache g_blocks;
 }
 extern "C" size_t lime_trim_cache(void) { return g_blocks.trim(-1); }
+extern "C" int lime_reserve(size_t bytes)
+{
+    if (!bytes) return LIME_OK;
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess) return LIME_ERR_HIP;
+    void *p = nullptr;
+    const size_t want = (bytes + BlockCache::GRAN - 1) / BlockCache::GRAN * BlockCache::GRAN;
+    if (hipMalloc(&p, want) != hipSuccess) { (void)hipGetLastError(); return LIME_ERR_NOMEM; }
+    g_blocks.add_arena(dev, p, want);
+    return LIME_OK;
+}
 
 static void dev_release(void *p)
 {
@@ -230,13 +305,14 @@ static void dev_release(void *p)
     // (hipFree waits for the device before a block goes back; a block that goes to the cache instead can be handed out again at once, so it waits the
     // same way: on the success paths everything that used the block has been waited for anyway, on an error path work on it may still be queued)
     if (g_blocks.tracked(p)) (void)hipDeviceSynchronize();
+    if (g_blocks.uncarve(p)) return;
     if (!g_blocks.give(p)) (void)hipFree(p);
 }
 static hipError_t dev_acquire(void **p, size_t bytes)
 {
     int dev = 0; (void)hipGetDevice(&dev);
     size_t got = 0;
-    if (bytes >= BlockCache::MIN && (*p = g_blocks.take(dev, bytes, &got))) {
+    if (bytes >= BlockCache::MIN && ((*p = g_blocks.take(dev, bytes, &got)) || (*p = g_blocks.carve(dev, bytes, &got)))) {
         if (g_poison_cache.load(std::memory_order_relaxed)) { (void)hipMemset(*p, 0xA5, got); (void)hipDeviceSynchronize(); }
         return hipSuccess;
     }
