@@ -354,6 +354,7 @@ static int set_option(lime_ctx *c, const char *key, const char *s)
     else if (is("score_chunk")) c->score_chunk = strtoull(s, nullptr, 10);
     else if (is("force_rccl")) c->force_rccl = v != 0 || !*s;
     else if (is("debug_stats")) c->debug_stats = v != 0 || !*s;
+    else if (is("apply_group")) set_apply_group((uint32_t)v);
     else if (is("debug_alloc")) g_debug_alloc.store(v != 0 || !*s, std::memory_order_relaxed);
     else if (is("poison_cache")) g_poison_cache.store(v != 0 || !*s, std::memory_order_relaxed);
     else if (is("no_direct")) c->no_direct = v != 0 || !*s;
@@ -402,7 +403,7 @@ extern "C" int lime_init(int device, lime_ctx **out)
             {"LIME_PROBE_MIN", "probe_min"}, {"LIME_FORCE_P64", "force_p64"}, {"LIME_P64_TEST_BASE", "p64_test_base"}, {"LIME_MAX_BLOCKS", "max_blocks"},
             {"LIME_CHOOSE_FREE", "choose_free"}, {"LIME_APPLY_WIDE", "apply_wide"}, {"LIME_SORT_NT", "sort_nt"}, {"LIME_PART_LINES", "part_lines"},
             {"LIME_NO_STAGING", "no_staging"}, {"LIME_FORCE_STAGING", "force_staging"}, {"LIME_DETECT_CHUNK", "detect_chunk"}, {"LIME_SCORE_CHUNK", "score_chunk"},
-            {"LIME_FORCE_RCCL", "force_rccl"}, {"LIME_DENSE_MIN", "dense_min"}, {"LIME_NO_DIRECT", "no_direct"}, {"LIME_DEBUG_STATS", "debug_stats"}, {"LIME_DEBUG_ALLOC", "debug_alloc"}};
+            {"LIME_FORCE_RCCL", "force_rccl"}, {"LIME_DENSE_MIN", "dense_min"}, {"LIME_NO_DIRECT", "no_direct"}, {"LIME_DEBUG_STATS", "debug_stats"}, {"LIME_DEBUG_ALLOC", "debug_alloc"}, {"LIME_APPLY_GROUP", "apply_group"}};
         for (const auto &hk : hooks)
             if (const char *s = getenv(hk[0])) {
                 const int rc = set_option(c, hk[1], s);
@@ -731,6 +732,16 @@ static void bin_layout(const lime_ctx *c, size_t sim_bytes, uint32_t *n_bins, ui
         // table (N = 10^10) 477 bins of 32 regions beat 1908 of 8 by 1 ms in 11; a 5 GB table keeps its 1193 bins of 64
         if (!c->bin_levels_forced)
             while (bin_shift < REGION_SHIFT + 6 && bin_shift < BIN_SHIFT_MAX && bins_at(bin_shift + 1) >= 256) ++bin_shift;
+        // Round 6: wider bins still where that brings the table under LINES_BINS bins -- k_part_lines (whole 64-byte lines, two workgroups per CU) then
+        // does the first level instead of k_part (pieces of lines: 2 against 3.4 TB/s), and since k_apply_tiles shares a wave among short runs the
+        // second level no longer pays for the regions per bin: configs[2] (5 GB: 1193 bins of 64 regions -> 299 of 256) 3.10 -> 2.95 ms per pass,
+        // configs[4]'s shape (10.3 GB: 1229 of 128 -> 308 of 512) clustered 31.8 -> 31.0 ms.  Tables beyond 477 x 32 MB = 16 GB keep what they had.
+        constexpr uint32_t LINES_BINS = 477;                 // (what fits a CU twice, 32- and 64-bit positions: tools/kres.py gates it)
+        if (!c->bin_levels_forced && bins_at(bin_shift) > LINES_BINS) {
+            uint32_t sh = bin_shift;
+            while (sh < BIN_SHIFT_MAX && bins_at(sh) > LINES_BINS) ++sh;
+            if (bins_at(sh) <= LINES_BINS) bin_shift = sh;
+        }
     }
     *n_bins = (uint32_t)bins_at(bin_shift);               // <= BIN_MAX: want_binned checked the table size
     *bin_shift_out = bin_shift;

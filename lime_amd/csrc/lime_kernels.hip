@@ -2778,7 +2778,7 @@ __device__ __forceinline__ void fin_region(const uint4 *reg4, const ApplyFin &f,
 }
 
 template <bool WIDE, int MODE> __global__ __launch_bounds__(APPLY_WG) void k_apply_tiles(uint8_t *sim, size_t sim_bytes, const uint16_t *recs16, const uint32_t *tbase,
-                                                          const uint16_t *idx, uint32_t bin_shift, uint32_t n_regions, ApplyFin fin)
+                                                          const uint16_t *idx, uint32_t bin_shift, uint32_t n_regions, ApplyFin fin, uint32_t lg_in)
 {
     constexpr uint32_t RW = (1u << REGION_SHIFT) / 4u;           // words per region
     constexpr uint32_t NWV = APPLY_WG / 64, UR = 4;
@@ -2909,7 +2909,46 @@ template <bool WIDE, int MODE> __global__ __launch_bounds__(APPLY_WG) void k_app
             if (s.qx * 4u < s.fex) s.vx = *reinterpret_cast<const uint2 *>(recs16 + (size_t)(row_w + NWV * lx) * ROW_STRIDE + (size_t)s.qx * 4u);
         }
     };
-    uint32_t region = blockIdx.x;
+    // Short runs (round 6).  A tile row holds 8192 records of its bin, so a region's run in it has 8192 / (regions per bin) records on average: 256 at 32
+    // regions per bin (the N = 1e10 series), 64 at 128 (tables of 10 GB), 16 at 512 -- and with a whole wave per run, a lane a group of four, such runs
+    // keep 16 or 4 of the 64 lanes busy: the kernel's time followed the NUMBER of runs, not of records (configs[4]'s shape, clustered: 4.5 ms at 128
+    // regions per bin, 7.2 at 256, 13.0 at 512 for the same 1.7e9 records).  Here 2^lg lanes share a run, a lane two groups of four: 64 >> lg runs per
+    // instruction, 8 << lg records of each per pass (the mean run x 2); longer runs take further passes.
+    const uint32_t lg = lg_in ? lg_in : (f2 >= 512u ? 2u : f2 == 256u ? 3u : f2 == 128u ? 4u : f2 == 64u ? 5u : 6u);      // 6: a wave per run (below)
+    struct GStep { uint2 v0, v1; uint32_t fa, fe, q; const uint16_t *src; };
+    auto grouped_runs = [&](uint32_t a_, uint32_t e_, uint32_t nl_, uint32_t row_w) {
+        const uint32_t LG = 1u << lg, rpi = 64u >> lg, lr_in = lane >> lg, li = lane & (LG - 1u);
+        auto gload = [&](uint32_t l0, GStep &s) {
+            const uint32_t lr = l0 + lr_in;
+            const uint32_t sa = (uint32_t)__shfl((int)a_, (int)(lr & 63u)), se = (uint32_t)__shfl((int)e_, (int)(lr & 63u));      // (by all lanes, the select behind)
+            const bool valid = lr < nl_;
+            s.fa = valid ? sa : 0u; s.fe = valid ? se : 0u;
+            s.q = (s.fa >> 2) + 2u * li;                          // this lane's two groups of four: q, q + 1
+            s.src = recs16 + (size_t)(row_w + NWV * (valid ? lr : 0u)) * ROW_STRIDE;
+            s.v0 = make_uint2(0u, 0u); s.v1 = make_uint2(0u, 0u);
+            if (s.q * 4u < s.fe) s.v0 = *reinterpret_cast<const uint2 *>(s.src + (size_t)s.q * 4u);
+            if ((s.q + 1u) * 4u < s.fe) s.v1 = *reinterpret_cast<const uint2 *>(s.src + (size_t)(s.q + 1u) * 4u);
+        };
+        GStep nxt;
+        gload(0u, nxt);
+        for (uint32_t l0 = 0; l0 < nl_; l0 += rpi) {
+            const GStep cur = nxt;
+            if (l0 + rpi < nl_) gload(l0 + rpi, nxt);              // the next runs' loads go out before these are added
+            add4c(cur.q * 4u < cur.fe, cur.q * 4u, cur.v0, cur.fa, cur.fe);
+            add4c((cur.q + 1u) * 4u < cur.fe, (cur.q + 1u) * 4u, cur.v1, cur.fa, cur.fe);
+            for (uint32_t q = cur.q + 2u * LG; __ballot(q * 4u < cur.fe); q += 2u * LG) {      // runs beyond 8 << lg records
+                uint2 w0 = make_uint2(0u, 0u), w1 = make_uint2(0u, 0u);
+                if (q * 4u < cur.fe) w0 = *reinterpret_cast<const uint2 *>(cur.src + (size_t)q * 4u);
+                if ((q + 1u) * 4u < cur.fe) w1 = *reinterpret_cast<const uint2 *>(cur.src + (size_t)(q + 1u) * 4u);
+                add4c(q * 4u < cur.fe, q * 4u, w0, cur.fa, cur.fe);
+                add4c((q + 1u) * 4u < cur.fe, (q + 1u) * 4u, w1, cur.fa, cur.fe);
+            }
+        }
+    };
+    // Workgroup b runs on XCD b % 8 (round-robin dispatch), and the runs of neighbouring regions are neighbours in every tile row -- 32 to 128 bytes each
+    // at 128 to 512 regions per bin: with region = b the eight XCDs each fetched the same 128-byte lines into their own L2.  Each XCD takes a block of
+    // consecutive regions instead: its 64 resident workgroups work on 64 neighbouring regions at a time.
+    uint32_t region = (gridDim.x & 7u) ? blockIdx.x : (blockIdx.x & 7u) * (gridDim.x >> 3) + (blockIdx.x >> 3);
     if (region >= n_regions) return;
     uint32_t row0 = tbase[region >> bsh], n_rows = tbase[(region >> bsh) + 1u] - row0;
     uint32_t a, e;
@@ -2942,6 +2981,7 @@ template <bool WIDE, int MODE> __global__ __launch_bounds__(APPLY_WG) void k_app
         for (uint32_t outer = 0; outer < n_rows; outer += NWV * 64u) {
             const uint32_t nl = runs_of(n_rows, outer);
             if (outer || exact) index_of(region, row0, n_rows, outer, a, e);
+            if (MODE == 0 && lg < 6u) { if (nl) grouped_runs(a, e, nl, row0 + outer + wave); continue; }      // wave-uniform (the modes without the table: a wave per run -- with this path too they pass 128 registers and a CU holds one workgroup of them instead of two)
             Step nxt;
             if (nl) load_step(0u, nxt, a, e, nl, row0 + outer + wave);
             AP(1)
@@ -3591,6 +3631,9 @@ void launch_sort_tiles(const uint32_t *recs, const uint64_t *binbase, uint32_t n
     hipLaunchKernelGGL(k_sort_tiles, dim3(n_bins, per_bin), dim3(PART_WG), 0, st, recs, binbase, bin_shift, tbase, idx, out16, big_rows ? 1u : 0u);
 }
 
+// option apply_group (comparison runs): lanes per run of k_apply_tiles as a power of two, 2 .. 6 (6: a wave per run); 0: by the regions per bin
+static std::atomic<uint32_t> g_apply_group{0};
+void set_apply_group(uint32_t lg) { g_apply_group.store(lg >= 2u && lg <= 6u ? lg : 0u, std::memory_order_relaxed); }
 static uint32_t apply_tiles_grid(uint32_t n_regions)
 {
     static std::atomic<uint32_t> resident_of[MAX_DEV];           // workgroups that fit the device at once (two per CU: 64 KB of LDS each)
@@ -3607,11 +3650,11 @@ void launch_apply_tiles_fin(int mode, size_t sim_bytes, uint32_t bin_shift, cons
     const uint32_t n_regions = (uint32_t)((sim_bytes + ((size_t)1 << REGION_SHIFT) - 1) >> REGION_SHIFT);
     const dim3 grid(apply_tiles_grid(n_regions)), wg(APPLY_WG);
     if (mode == 1) {
-        if (many_records) hipLaunchKernelGGL((k_apply_tiles<true, 1>), grid, wg, 0, st, nullptr, sim_bytes, out16, tbase, idx, bin_shift, n_regions, fin);
-        else              hipLaunchKernelGGL((k_apply_tiles<false, 1>), grid, wg, 0, st, nullptr, sim_bytes, out16, tbase, idx, bin_shift, n_regions, fin);
+        if (many_records) hipLaunchKernelGGL((k_apply_tiles<true, 1>), grid, wg, 0, st, nullptr, sim_bytes, out16, tbase, idx, bin_shift, n_regions, fin, g_apply_group.load(std::memory_order_relaxed));
+        else              hipLaunchKernelGGL((k_apply_tiles<false, 1>), grid, wg, 0, st, nullptr, sim_bytes, out16, tbase, idx, bin_shift, n_regions, fin, g_apply_group.load(std::memory_order_relaxed));
     } else {
-        if (many_records) hipLaunchKernelGGL((k_apply_tiles<true, 2>), grid, wg, 0, st, nullptr, sim_bytes, out16, tbase, idx, bin_shift, n_regions, fin);
-        else              hipLaunchKernelGGL((k_apply_tiles<false, 2>), grid, wg, 0, st, nullptr, sim_bytes, out16, tbase, idx, bin_shift, n_regions, fin);
+        if (many_records) hipLaunchKernelGGL((k_apply_tiles<true, 2>), grid, wg, 0, st, nullptr, sim_bytes, out16, tbase, idx, bin_shift, n_regions, fin, g_apply_group.load(std::memory_order_relaxed));
+        else              hipLaunchKernelGGL((k_apply_tiles<false, 2>), grid, wg, 0, st, nullptr, sim_bytes, out16, tbase, idx, bin_shift, n_regions, fin, g_apply_group.load(std::memory_order_relaxed));
     }
 }
 
@@ -3624,8 +3667,8 @@ void launch_apply_by_tiles(uint8_t *sim, size_t sim_bytes, const uint32_t *recs,
     ApplyFin none; memset(&none, 0, sizeof none);
     // the variant for many records (a step's groups 64 .. 79 in one pass): N = 1e10 (1.2e9 records) 1.09 -> 0.84 ms, configs[4]'s shape (3.2e8)
     // 2.43 -> 2.08; the other one where there are fewer: configs[2] (1.2e8) +3 %, configs[3]'s shape +3 %, text +7 % with the first
-    if (many_records) hipLaunchKernelGGL((k_apply_tiles<true, 0>), dim3(grid), dim3(APPLY_WG), 0, st, sim, sim_bytes, out16, tbase, idx, bin_shift, n_regions, none);
-    else hipLaunchKernelGGL((k_apply_tiles<false, 0>), dim3(grid), dim3(APPLY_WG), 0, st, sim, sim_bytes, out16, tbase, idx, bin_shift, n_regions, none);
+    if (many_records) hipLaunchKernelGGL((k_apply_tiles<true, 0>), dim3(grid), dim3(APPLY_WG), 0, st, sim, sim_bytes, out16, tbase, idx, bin_shift, n_regions, none, g_apply_group.load(std::memory_order_relaxed));
+    else hipLaunchKernelGGL((k_apply_tiles<false, 0>), dim3(grid), dim3(APPLY_WG), 0, st, sim, sim_bytes, out16, tbase, idx, bin_shift, n_regions, none, g_apply_group.load(std::memory_order_relaxed));
 }
 
 // the rows of every 64 KB region of the table (k_apply_tiles, modes 1 and 2): first row, offset of the region's first byte in it, row segments,
