@@ -138,7 +138,7 @@ void launch_sort_tiles(const uint32_t *recs, const uint64_t *binbase, uint32_t n
                        hipStream_t st, bool big_rows, bool tbase_ready = false);
 void launch_apply_tiles_fin(int mode, size_t sim_bytes, uint32_t bin_shift, const uint32_t *tbase, const uint16_t *idx, const uint16_t *out16, bool many_records,
                             const ApplyFin &fin, hipStream_t st);
-void set_apply_group(uint32_t lg);    // option apply_group: lanes per run of k_apply_tiles = 2^lg (2 .. 6), 0 = by the regions per bin; process-wide
+void set_apply_group(uint32_t lg);    // option apply_group: lanes per run of k_apply_tiles = 2^lg (1 .. 6), 0 = by the regions per bin; process-wide
 void launch_region_rows(uint32_t n_regions, uint32_t n_refs, uint64_t table_bytes, const uint64_t *row_off /* mode 2; NULL for mode 1 */, void *out /* n_regions x 16 bytes */, hipStream_t st);
 // the long clusters' update records (cell | t << CELL_BITS) bucketed by 64 KB table region: cnt / cursor: n_regions words (zeroed here), off: n_regions + 1
 void launch_bigrec_buckets(const uint64_t *recs, uint32_t n, uint32_t n_regions, uint32_t *cnt, uint32_t *cursor, uint64_t *off, uint64_t *out, hipStream_t st);

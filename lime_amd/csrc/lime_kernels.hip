@@ -2854,7 +2854,10 @@ template <bool WIDE, int MODE> __global__ __launch_bounds__(APPLY_WG) void k_app
             const bool first = (pf >> i) & 1u;
             const uint64_t mf = __ballot(first);
             if (first) { const uint32_t at = qn + rank_in(mf); if (at < QW) myq[at] = (uint16_t)((i & 2u ? po23 : po01) >> (16u * (i & 1u))); }
-            qn += (uint32_t)__popcll(mf);
+            // (the count is ONE number per wave: taken through a scalar register, not a per-lane copy -- the compiler lets lanes that have no further
+            // groups leave the callers' `while (__ballot(..))` loops on their own, and a lane that sat a round out would come back with a stale count and
+            // write over queued cells: round 6, the run loop of grouped_runs with 16 runs an instruction lost 60 % of a dense region's cells that way)
+            qn = (uint32_t)__builtin_amdgcn_readfirstlane((int)(qn + (uint32_t)__popcll(mf)));
         }
         pf = 0u;
     };
@@ -2981,7 +2984,9 @@ template <bool WIDE, int MODE> __global__ __launch_bounds__(APPLY_WG) void k_app
         for (uint32_t outer = 0; outer < n_rows; outer += NWV * 64u) {
             const uint32_t nl = runs_of(n_rows, outer);
             if (outer || exact) index_of(region, row0, n_rows, outer, a, e);
-            if (MODE == 0 && lg < 6u) { if (nl) grouped_runs(a, e, nl, row0 + outer + wave); continue; }      // wave-uniform (the modes without the table: a wave per run -- with this path too they pass 128 registers and a CU holds one workgroup of them instead of two)
+            // (wave-uniform.  The modes without the table take this path for every group size, a wave per run included: with both paths compiled in they
+            // pass 128 registers and a CU holds one workgroup of them instead of two)
+            if (MODE != 0 || lg < 6u) { if (nl) grouped_runs(a, e, nl, row0 + outer + wave); continue; }
             Step nxt;
             if (nl) load_step(0u, nxt, a, e, nl, row0 + outer + wave);
             AP(1)
@@ -3631,9 +3636,9 @@ void launch_sort_tiles(const uint32_t *recs, const uint64_t *binbase, uint32_t n
     hipLaunchKernelGGL(k_sort_tiles, dim3(n_bins, per_bin), dim3(PART_WG), 0, st, recs, binbase, bin_shift, tbase, idx, out16, big_rows ? 1u : 0u);
 }
 
-// option apply_group (comparison runs): lanes per run of k_apply_tiles as a power of two, 2 .. 6 (6: a wave per run); 0: by the regions per bin
+// option apply_group (comparison runs): lanes per run of k_apply_tiles as a power of two, 1 .. 6 (6: a wave per run); 0: by the regions per bin
 static std::atomic<uint32_t> g_apply_group{0};
-void set_apply_group(uint32_t lg) { g_apply_group.store(lg >= 2u && lg <= 6u ? lg : 0u, std::memory_order_relaxed); }
+void set_apply_group(uint32_t lg) { g_apply_group.store(lg >= 1u && lg <= 6u ? lg : 0u, std::memory_order_relaxed); }
 static uint32_t apply_tiles_grid(uint32_t n_regions)
 {
     static std::atomic<uint32_t> resident_of[MAX_DEV];           // workgroups that fit the device at once (two per CU: 64 KB of LDS each)

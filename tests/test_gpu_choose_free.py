@@ -148,3 +148,25 @@ def test_choose_without_the_table_at_full_size(monkeypatch, shape):
     assert res[0][3] == res[1][3] and res[0][4] == res[1][4]
     assert np.array_equal(res[0][0], res[1][0]) and np.array_equal(res[0][1], res[1][1]) and np.array_equal(res[0][2], res[1][2])
     assert 0 < len(res[0][2]) and int((np.diff(res[0][1].astype(np.int64)) > 0).sum()) < nr      # some rows pass, not all
+
+
+@pytest.mark.parametrize("group", ["", "2", "3", "4", "6"])
+def test_choose_without_the_table_on_hot_rows(monkeypatch, group):
+    """All reads in 50 rows of a table whose rows are regions (1000 x 65536, two bins of 512 regions): a region of a hot row has thousands of cells and
+    long runs in every tile row, so k_apply_tiles<., 1> queues hundreds of first adds per wave and its run loop takes several passes per run -- with 2^lg
+    lanes a run (round 6) lanes without further groups leave that loop on their own, and while the queue's count was a per-lane copy they came back with
+    a stale one and wrote over queued cells (60 % of a hot row's cells were not counted).  Row maxima, counts and lists against the oracle's table."""
+    nr, ng, n = 1000, 65536, 1_500_000
+    lcp, da, eb = O.synth(8100 + nr, 0, n, nr, ng, 16, 1)
+    rd = da < nr
+    da[rd] = da[rd] % 50
+    cl, nc, ml = O.detect(lcp, da, nr, 16)
+    sim = O.score(da, eb, cl, nr, ng, threads=8)
+    emx, eoff, epairs = _expected(sim, 85, 0.0)
+    try:
+        mx, off, pairs, s = _run(monkeypatch, lcp, da, eb, nr, ng, 85, 0.0, LIME_UPDATE_PATH="bin", LIME_CHOOSE_FREE=1, LIME_BIN_LEVELS="1,2", LIME_APPLY_GROUP=group)
+        assert (s.n_clusters, s.max_len) == (nc, ml) and s.table_free == 1
+        assert np.array_equal(mx, emx) and np.array_equal(off, eoff) and np.array_equal(pairs, epairs)
+        assert int(np.diff(eoff.astype(np.int64)).max()) > 3000              # (the hot rows are what this is about)
+    finally:
+        _run(monkeypatch, lcp[:4096], da[:4096], eb[:4096], nr, ng, 85, 0.5, LIME_APPLY_GROUP="")      # (the option is process-wide: back to the library's choice)

@@ -330,12 +330,12 @@ def test_more_than_2_32_records_in_one_pass(nr, ng):
         torch.cuda.empty_cache()
 
 
-@pytest.mark.parametrize("group", ["", "2", "3", "4", "5", "6"])
+@pytest.mark.parametrize("group", ["", "1", "2", "3", "4", "5", "6"])
 @pytest.mark.parametrize("nr,ng,n", [(8192, 1024, 6_000_000), (16384, 2048, 5_000_000), (3000, 1400, 9_000_000)])
 def test_short_runs_of_a_region_share_a_wave(monkeypatch, nr, ng, n, group):
     """k_apply_tiles on bins of many regions (one bin of 128 / 512 / 65 regions: LIME_BIN_LEVELS=1,1): a region's run in a tile row is 64 / 16 / 126
     records on average, and 2^lg lanes share a run, two groups of four records a lane (round 6; before, a wave per run).  Every group size (option
-    apply_group: 4 .. 64 lanes; "" = by the regions per bin) against the oracle: runs shorter and longer than a pass takes, empty runs, the last
+    apply_group: 2 .. 64 lanes; "" = by the regions per bin) against the oracle: runs shorter and longer than a pass takes, empty runs, the last
     short step of a wave's runs, the bins' last, partly filled tile row."""
     c = _ctx(monkeypatch, LIME_UPDATE_PATH="bin", LIME_BIN_LEVELS="1,1", LIME_APPLY_GROUP=group)
     try:
