@@ -97,7 +97,7 @@ int  lime_pick_device(unsigned salt);    /* the device with the most free memory
  * most pick which kernel variant or update path runs.  Not a stable interface -- lime_amd/csrc/lime_api.cpp:set_option is the list:
  * update_path (cas|bin|auto), bin_levels ("one,two"), pool_density, pool_slack, scan_static_pct, second_level (tiles|sweeps), part_split, no_probe,
  * probe_min, force_p64, p64_test_base, max_blocks, choose_free, apply_wide, sort_nt, part_lines, no_staging, force_staging, detect_chunk,
- * score_chunk, force_rccl, io_threads, dense_min, debug_stats, debug_alloc, poison_cache.
+ * score_chunk, force_rccl, io_threads, dense_min, no_direct, apply_group, debug_stats, debug_alloc, poison_cache.
  * The ENVIRONMENT is read by lime_init only: LIME_IO_THREADS (host staging threads; the reference's `threads` argument, ClusterLCP.cpp:73-84)
  * always, and -- only when LIME_TEST_HOOKS=1 is set -- a LIME_<KNOB> variable per knob above (tests, experiments).  bench.py refuses to run
  * under LIME_TEST_HOOKS. */

@@ -43,7 +43,7 @@ while time.time() < t_end:
     if regime == 1:                      # long runs
         k = int(rng.integers(1, 6))
         for _ in range(k):
-            a0 = int(rng.integers(0, n)); ln = int(rng.integers(10, min(n, 70000) + 1))
+            a0 = int(rng.integers(0, n)); ln = int(rng.integers(min(10, n), min(n, 70000) + 1))
             lcp[a0:a0 + ln] = alpha + 3
     elif regime == 2:                    # dense short clusters
         per = int(rng.integers(2, 7)); lcp[:] = alpha; lcp[::per] = 0
