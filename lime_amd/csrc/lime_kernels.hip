@@ -492,7 +492,7 @@ __device__ __forceinline__ void drain_bin(UpdQueue &q, const ScanArgs &a, bool f
         const uint32_t l0 = c0 & ~15u;
         if (sub < n_sub && (c1 & ~15u) != l0 && wi < (c0 & 15u) && l0 + wi < cap_w && !ABL(7)) {     // a full sub-region only counts: the pass is repeated with a larger pool
             atomicAdd(&q.hist[hoff + ((wrec >> bin_shift) | (sub << (32u - bin_shift)))], 1u);      // the histogram counts exactly the records that are stored
-            if (!ABL(6)) __builtin_nontemporal_store(wrec, out + (size_t)sub * cap_w + l0 + wi);
+            if (!ABL(6)) out[(size_t)sub * cap_w + l0 + wi] = wrec;       // (a plain store, like the other piece of its line below: a non-temporal store of less than a line is a read-modify-write at the memory, 4.5 x a whole line's -- plain, the two pieces meet in L2)
         }
     };
     const uint32_t first = whole || n <= 64u ? 0u : n - 64u;      // entries [first, n) leave
@@ -520,7 +520,7 @@ __device__ __forceinline__ void drain_bin(UpdQueue &q, const ScanArgs &a, bool f
                 if (slot >= lim) q.lbuf[16u * hi + (slot & 15u)] = rec;
                 else if (slot < cap_w && !ABL(7)) {
                     atomicAdd(&q.hist[hoff + (uint32_t)(cell >> bin_shift)], 1u);
-                    if (!ABL(6)) __builtin_nontemporal_store(rec, out + (size_t)hi * cap_w + slot);
+                    if (!ABL(6)) out[(size_t)hi * cap_w + slot] = rec;
                 }
             }
             store_waiting(ws, c00, c10, wv0);
