@@ -27,13 +27,13 @@ ALPHA, READ_LEN = 16, 100
 NORM = READ_LEN + 1 - ALPHA                       # ClusterBWT_DA.cpp:555
 
 CASES = {
-    # BASELINE.json configs[2] as it stands: 1193 bins of 64 regions, k_part, k_apply_tiles<false>.  beta 0.02: three quarters of the rows pass (9*10^7 pairs)
+    # BASELINE.json configs[2] as it stands: 299 bins of 256 regions, k_part_lines, k_apply_tiles<false> with 8 lanes a run (1193 bins of 64, k_part until round 6).  beta 0.02: three quarters of the rows pass (9*10^7 pairs)
     "C3": dict(n=1_000_000_000, nr=1_000_000, ng=5000, ebwt=0, mode=0, beta=0.02, records=1e8),
     # the first 2*10^9 symbols of the north_star series' collection (10^6 x 1000 = 1 GB table): 477 bins of 32 regions, k_part_lines,
     # k_apply_tiles<true> (2.4*10^8 records).  beta 0.04: a row passes with a cell >= 4
     "N1E10_SLICE": dict(n=2_000_000_000, nr=1_000_000, ng=1000, ebwt=0, mode=0, beta=0.04, records=2e8),
     # the first 10^9 symbols of configs[4]'s shape on the clustered generator, the reference's default build (EBWT=1): a 10.3 GB table = three
-    # sub-regions per scan wave, 1229 bins of 128 regions, 1.7*10^8 records
+    # sub-regions per scan wave, 308 bins of 512 regions (1229 of 128 until round 6), 1.7*10^8 records
     "C5_CLUSTERED_SLICE": dict(n=1_000_000_000, nr=3_000_000, ng=3423, ebwt=1, mode=1, beta=0.02, records=1e8),
 }
 
