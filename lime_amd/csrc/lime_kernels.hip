@@ -2520,7 +2520,7 @@ __global__ __launch_bounds__(PART_WG) void k_part2(const uint32_t *recs, const u
 // taken TILE by TILE (8192), each tile is sorted by region in LDS and leaves as 16-bit offsets inside the region (the
 // region is what the position says), 16 KB per tile at out16[row * PART_TILE ..], row = the tile's number over all bins
 // (tbase[bin] + tile of the bin); where the regions' runs start inside the tile goes to the bin's index,
-// idx[tbase[bin] * (f2 + 1) + sub * T + t] (T = tiles of the bin, entry f2: the tile's record count).  k_apply_tiles
+// idx[(tbase[bin] + t) * (f2 + 1) + sub] (t: the tile of the bin; entry f2: the tile's record count).  k_apply_tiles
 // then builds a region from its run of every tile of the bin.  One read of 4 bytes and one write of 2 per record here,
 // one read of 2 there (k_part2 + k_apply: 8 + 4 and 4).
 __global__ __launch_bounds__(PART_WG) void k_tile_bases(const uint64_t *binbase, uint32_t n_bins, uint32_t *tbase)
@@ -2552,7 +2552,7 @@ __global__ __launch_bounds__(PART_WG) void k_sort_tiles(const uint32_t *recs, co
     // workgroup per BIN left the CUs unevenly loaded (477 or 1193 workgroups of 8 waves over 256 CUs, 292 on the text workload)
     const uint32_t bin = blockIdx.x, kq = blockIdx.y, nq = gridDim.y;
     const uint64_t lo = binbase[bin], hi = binbase[bin + 1];
-    const uint32_t row0 = tbase[bin], n_rows = tbase[bin + 1] - row0;
+    const uint32_t row0 = tbase[bin];
     uint16_t *bidx = idx + (size_t)row0 * (f2 + 1u);
     for (uint32_t i = tid; i < nc; i += PART_WG) cnt[i] = 0u;
     __syncthreads();
@@ -2597,8 +2597,10 @@ __global__ __launch_bounds__(PART_WG) void k_sort_tiles(const uint32_t *recs, co
             __syncthreads();
             uint32_t run = incl - c;
             for (uint32_t k = 0; k < wave; ++k) run += wsum[k];
-            if (tid < nc) { toff[tid] = run; cnt[tid] = 0u; if (!(tid & ((1u << rsh) - 1u))) bidx[(size_t)(tid >> rsh) * n_rows + row] = (uint16_t)run; }
-            if (tid == nc - 1u) { nv_s = run + c; bidx[(size_t)f2 * n_rows + row] = (uint16_t)(run + c); }
+            // (the tile's f2 + 1 entries lie together -- idx[(row0 + row) * (f2 + 1) + region] --: one or a few whole lines per tile.  Until round 6 the index
+            // was region-major, every tile writing f2 + 1 two-byte entries a row stride apart: 0.5 ms of k_sort_tiles' 2.85 at 512 regions per bin)
+            if (tid < nc) { toff[tid] = run; cnt[tid] = 0u; if (!(tid & ((1u << rsh) - 1u))) bidx[(size_t)row * (f2 + 1u) + (tid >> rsh)] = (uint16_t)run; }
+            if (tid == nc - 1u) { nv_s = run + c; bidx[(size_t)row * (f2 + 1u) + f2] = (uint16_t)(run + c); }
             __syncthreads();
         }
         ST(4)
@@ -2873,10 +2875,9 @@ template <bool WIDE, int MODE> __global__ __launch_bounds__(APPLY_WG) void k_app
     // workgroup per region paid that chain of dependent loads per region (configs[2]: 76 k regions of 1.6 k records each).
     const uint32_t bsh = bin_shift - REGION_SHIFT;
     auto index_of = [&](uint32_t r, uint32_t r0, uint32_t nr, uint32_t outer, uint32_t &a_, uint32_t &e_) {   // lane l: the index entries of tile outer + wave + NWV * l of the region's bin
-        const uint16_t *ia = idx + (size_t)r0 * (f2 + 1u) + (size_t)(r & (f2 - 1u)) * nr;
         const uint32_t t = outer + wave + NWV * lane;
         a_ = 0u; e_ = 0u;
-        if (t < nr) { a_ = ia[t]; e_ = ia[nr + t]; }
+        if (t < nr) { const uint16_t *ia = idx + (size_t)(r0 + t) * (f2 + 1u) + (r & (f2 - 1u)); a_ = ia[0]; e_ = ia[1]; }      // (tile-major: the lanes' entries lie a tile's f2 + 1 apart; the 64 regions an XCD works on at a time share their lines)
     };
     auto runs_of = [&](uint32_t nr, uint32_t outer) {             // tiles of this round: the wave's are wave, wave + NWV, ... < left
         const uint32_t left = nr - outer;
